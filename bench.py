@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py — Mpixels/s encode+decode of 4K RGBA frames on MI355X (BASELINE.json metric).
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ...
+  One process per GPU; frames shard across ranks with NO data-path collective (every image
+  is coded with state reset, qoi.h:393-400,533-537); RCCL only gathers counters/timings.
+
+A STEP = one pass of the hot path over one batch: every rank encodes its F resident
+3840x2160 RGBA frames (qoimi_encode_batch) and decodes the streams back
+(qoimi_decode_batch).  Frames are synthetic (`photo` class of qoi_amd/synth.py), generated
+on the device, distinct per frame and rank, F*33 MB >> the 256 MiB Infinity Cache, and
+already resident in HBM when the timed region starts.  value = pixels round-tripped per
+second over all ranks.  The round trip is verified bit-exact after the timed region.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel enc_slabs: algorithmic bytes (4 B read per pixel,
+                SURVEY.md §8d) / its mean launch duration measured with HIP events on the
+                launch stream during the timed steps, against the 8 TB/s HBM peak.
+  cpu_baseline  the unmodified reference (oracle/_ref, else our C port) timed on this
+                host with qoibench.c's BENCHMARK_FN semantics on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(kind: str, w: int, h: int, budget_s: float) -> dict:
+    """Reference qoi.h on ONE host core: encode+decode of the same synthetic frames,
+    timed like qoibench.c:364-376 (one warm-up discarded, malloc/free inside the region)."""
+    from oracle import oracle_py
+    from qoi_amd import synth
+    lib = oracle_py.load_ref()
+    if lib is None:
+        lib = oracle_py.load_port()
+    npx = w * h
+    frames = [np.ascontiguousarray(synth.frame_rgba(kind, w, h, f)) for f in range(2)]
+    desc = oracle_py.QoiDesc(w, h, 4, 0)
+    enc_ns = dec_ns = 0
+    runs = 0
+    t_start = time.perf_counter()
+    it = 0
+    while True:
+        fr = frames[it % len(frames)]
+        t0 = time.perf_counter_ns()
+        p, n = lib.encode_raw(fr.ctypes.data, desc)
+        t1 = time.perf_counter_ns()
+        q, _ = lib.decode_raw(p, n, 4)
+        lib.free(q)
+        t2 = time.perf_counter_ns()
+        lib.free(p)
+        if it > 0:                      # first run is the warm-up (qoibench.c:366-372)
+            enc_ns += t1 - t0
+            dec_ns += t2 - t1
+            runs += 1
+        it += 1
+        if runs >= 2 and time.perf_counter() - t_start > budget_s:
+            break
+    enc_mpps = npx * runs / (enc_ns / 1000.0)
+    dec_mpps = npx * runs / (dec_ns / 1000.0)
+    both = npx * runs / ((enc_ns + dec_ns) / 1000.0)
+    return {"value": round(both, 2), "unit": "Mpixels/s", "cores": 1, "kind": lib.kind,
+            "sample": f"{runs} x {w}x{h} {kind} frames, encode+decode, 1 warm-up discarded, malloc/free timed",
+            "encode_mpps": round(enc_mpps, 2), "decode_mpps": round(dec_mpps, 2)}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=32, help="4K frames resident per GPU (= per step)")
+    ap.add_argument("--kind", default="photo", choices=["photo", "noise", "uiflat", "constant"])
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from qoi_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ctx = api.Context(local)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    w, h, F = args.width, args.height, args.frames
+    npx = w * h
+    desc = api.QoiDesc(w, h, 4, api.QOI_SRGB)
+    pstride = (npx * 4 + 255) // 256 * 256
+    sstride = (api.encode_bound(w, h, 4) + 255) // 256 * 256
+    pixels = torch.empty(F * pstride, dtype=torch.uint8, device=dev)
+    streams = torch.empty(F * sstride, dtype=torch.uint8, device=dev)
+    decoded = torch.empty(F * pstride, dtype=torch.uint8, device=dev)
+    lens = torch.zeros(F, dtype=torch.int32, device=dev)
+    ctx.synth_frames(synth.KIND_ID[args.kind], synth.DEFAULT_SEED, rank * F, F, w, h,
+                     pixels.data_ptr(), pstride, stream)
+    torch.cuda.synchronize()
+
+    # stream lengths are data-dependent; they are constant across steps, read them once
+    ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+    ctx.encode_status(stream)
+    sizes = [int(x) for x in lens.cpu().numpy()]
+    descs = [desc] * F
+
+    def step():
+        ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+        ctx.decode_batch(streams.data_ptr(), sstride, sizes, descs, 4, decoded.data_ptr(), pstride, stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.get_profile(stream)
+    ctx.set_profiling(False)
+    ctx.encode_status(stream)
+
+    # bit-exact round trip (qoibench.c:408-417) checked outside the timed region
+    ok = bool(torch.equal(decoded.view(F, -1)[:, :npx * 4], pixels.view(F, -1)[:, :npx * 4]))
+    dstats = ctx.decode_stats()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([float(F * npx * args.steps), float(sum(sizes)) * args.steps, float(ok)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # RCCL: counters only
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_px, total_stream_bytes, n_ok = (float(x) for x in cnt.cpu().numpy())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = total_px / elapsed / 1e6
+        enc_ms = sum(prof[k][0] for k in prof if k.startswith("enc_"))
+        dec_ms = sum(prof[k][0] for k in prof if k.startswith("dec_"))
+        slabs_ms, slabs_calls = prof["enc_slabs"]
+        per_launch_ms = slabs_ms / max(1, slabs_calls)
+        alg_bytes = F * npx * 4                           # 4 B read per pixel
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        out = {
+            "metric": "Mpixels/s encode+decode, 4K RGBA", "value": round(value, 1), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"batch of {F} x {w}x{h} RGBA frames per GPU per step (BASELINE configs[4] shape; "
+                                   f"configs[1] frame size), encode + decode, content={args.kind}, HBM-resident, "
+                                   f"bit-exact round trip verified",
+                       "frames_per_gpu": F, "width": w, "height": h, "content": args.kind,
+                       "stream_bytes_per_px": round(total_stream_bytes / total_px, 4), "parallelism": f"frames sharded x{world}"},
+            "verified_bit_exact": n_ok == world,
+            "encode_mpps_kernels": round(F * npx * args.steps / (enc_ms * 1e3), 1) if enc_ms else None,
+            "decode_mpps_kernels": round(F * npx * args.steps / (dec_ms * 1e3), 1) if dec_ms else None,
+            "decode_rounds": dstats["rounds"], "decode_redo_segments": dstats["redo_segments"],
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
+            "roofline": {"bound": "hbm", "kernel": "enc_slabs", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": round(per_launch_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.kind, w, h, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

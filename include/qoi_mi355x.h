@@ -1,0 +1,149 @@
+/*
+ * qoi_mi355x.h — C-ABI of libqoi_mi355x.so, the MI355X-native QOI encode/decode path.
+ *
+ * Part 1 is the DROP-IN boundary: the same four symbols, constants and struct the
+ * reference exposes (phoboslab/qoi qoi.h:214-295).  A caller that includes the
+ * reference's qoi.h WITHOUT defining QOI_IMPLEMENTATION (prototypes only) and links
+ * this library gets the GPU path with no source change; see INTEGRATION.md.
+ *
+ * Part 2 is ADDITIVE (nothing like it exists in the reference): device-resident
+ * batch entry points for callers whose pixels/streams already live in HBM.  Plain
+ * pointers and sizes only — no torch / HIP types in any signature (a hipStream_t is
+ * passed as void*).
+ *
+ * All work is done by hand-written gfx950 kernels (the .hip files under qoi_amd/csrc).  There is no
+ * CPU fallback: without a usable GPU every entry point fails (NULL / negative status)
+ * and qoimi_last_error() says why.
+ */
+#ifndef QOI_MI355X_H
+#define QOI_MI355X_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------
+ * Part 1 — drop-in for the reference API
+ * ------------------------------------------------------------------------------------ */
+
+#ifndef QOI_H            /* the reference header may already have declared these */
+#define QOI_H
+
+#define QOI_SRGB   0     /* qoi.h:233 */
+#define QOI_LINEAR 1     /* qoi.h:234 */
+
+/* qoi.h:236-241 — 12 bytes, fields at offsets 0/4/8/9. */
+typedef struct {
+    unsigned int width;
+    unsigned int height;
+    unsigned char channels;
+    unsigned char colorspace;
+} qoi_desc;
+
+/* Replaces qoi.h:278 / implementation qoi.h:356-486.
+ * Same contract: NULL on data/desc/out_len == NULL, width or height 0, channels not 3/4,
+ * colorspace > 1 or height >= 400000000/width; otherwise a malloc()ed buffer (caller
+ * free()s it) holding a stream BYTE-IDENTICAL to the reference encoder's, *out_len set. */
+void *qoi_encode(const void *data, const qoi_desc *desc, int *out_len);
+
+/* Replaces qoi.h:289 / implementation qoi.h:488-590.
+ * Same contract incl. leniency (truncated streams repeat the last pixel, trailer content
+ * ignored, over-long runs clipped, ...): result pixels are bit-identical to the
+ * reference decoder's for EVERY input stream; desc is filled before validation. */
+void *qoi_decode(const void *data, int size, qoi_desc *desc, int channels);
+
+/* Replace qoi.h:252 / qoi.h:595-617 and qoi.h:265 / qoi.h:619-646 (stdio wrappers). */
+int   qoi_write(const char *filename, const void *data, const qoi_desc *desc);
+void *qoi_read(const char *filename, qoi_desc *desc, int channels);
+
+#endif /* QOI_H */
+
+/* ------------------------------------------------------------------------------------
+ * Part 2 — additive device-resident API
+ * ------------------------------------------------------------------------------------ */
+
+typedef struct qoimi_ctx qoimi_ctx;
+
+enum {
+    QOIMI_OK            =  0,
+    QOIMI_E_ARG         = -1,   /* argument rejected by the same rules as qoi.h:364-372 / 497-521 */
+    QOIMI_E_NO_GPU      = -2,   /* no gfx950 device / HIP runtime error */
+    QOIMI_E_NOMEM       = -3,
+    QOIMI_E_INTERNAL    = -4    /* a device-side liveness bound tripped (never expected) */
+};
+
+/* Synthetic content classes (qoi_amd/synth.py states the exact per-pixel function). */
+enum { QOIMI_NOISE = 0, QOIMI_PHOTO = 1, QOIMI_UIFLAT = 2, QOIMI_CONSTANT = 3 };
+
+/* Create / destroy a context bound to one GPU.  A context owns a growable device
+ * workspace, so steady-state calls do no hipMalloc/hipFree.  Calls on ONE context are
+ * serialised by the caller (or use one context per thread). */
+int  qoimi_ctx_create(int device, qoimi_ctx **out);
+void qoimi_ctx_destroy(qoimi_ctx *ctx);
+
+/* Thread-local description of the last failure in this thread ("" if none). */
+const char *qoimi_last_error(void);
+
+/* Worst-case stream size w*h*(channels+1)+14+8 — the reference's allocation, qoi.h:374-376.
+ * Returns 0 if desc is rejected. */
+size_t qoimi_encode_bound(const qoi_desc *desc);
+
+/* Encode n_images equally-shaped images that live in device memory.
+ *   d_pixels       device pointer; image i starts at d_pixels + i*pixel_stride (tightly
+ *                  packed row-major w*h*channels bytes, as qoi.h:406-413 reads them)
+ *   d_streams      device pointer; stream i is written at d_streams + i*stream_stride,
+ *                  stream_stride >= qoimi_encode_bound(desc)
+ *   d_stream_len   device int[n_images]; receives each stream's length (= *out_len)
+ *   stream         hipStream_t (as void*), NULL = default stream
+ * Asynchronous: kernels are enqueued on `stream`; nothing is synchronised. */
+int qoimi_encode_batch(qoimi_ctx *ctx, const void *d_pixels, size_t pixel_stride,
+                       const qoi_desc *desc, int n_images,
+                       void *d_streams, size_t stream_stride, int *d_stream_len,
+                       void *stream);
+
+/* Synchronise `stream` and return QOIMI_E_INTERNAL if the last qoimi_encode_batch on this
+ * context tripped its device-side liveness bound (never expected); QOIMI_OK otherwise. */
+int qoimi_encode_status(qoimi_ctx *ctx, void *stream);
+
+/* Decode n_images streams that live in device memory.
+ *   d_streams      stream i starts at d_streams + i*stream_stride and is sizes[i] bytes
+ *   sizes          HOST int[n_images] (the `size` argument of qoi.h:289 per image)
+ *   descs          HOST qoi_desc[n_images]: the header of each stream as parsed by the
+ *                  caller (what qoi_decode would write to *desc); all images must decode
+ *                  to the same w*h*out_channels byte count <= pixel_stride
+ *   channels       0, 3 or 4 — as qoi.h:289
+ *   d_pixels       image i is written at d_pixels + i*pixel_stride
+ * Synchronous with respect to `stream` (the exactness check of the speculative decoder
+ * is read back before returning). */
+int qoimi_decode_batch(qoimi_ctx *ctx, const void *d_streams, size_t stream_stride,
+                       const int *sizes, const qoi_desc *descs, int n_images, int channels,
+                       void *d_pixels, size_t pixel_stride, void *stream);
+
+/* Fill device memory with synthetic RGBA frames frame_id = first_frame .. first_frame+n-1
+ * (benchmark/test utility; same function of (kind, seed, frame, pixel) as synth.py). */
+int qoimi_synth_frames(qoimi_ctx *ctx, int kind, unsigned seed, unsigned first_frame,
+                       int n_frames, unsigned width, unsigned height,
+                       void *d_pixels, size_t pixel_stride, void *stream);
+
+/* Counters of the last decode on this context: [0] speculation rounds, [1] segments
+ * re-decoded after a failed check, [2] total segments, [3] reserved. */
+void qoimi_decode_stats(qoimi_ctx *ctx, long long out[4]);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (what bench.py's roofline
+ * figure is computed from).  qoimi_set_profiling(ctx,1) enables it and resets the
+ * accumulators; qoimi_get_profile synchronises `stream` and returns, per kernel index,
+ * accumulated milliseconds and launch counts (arrays of `cap` entries; return value =
+ * number of kernels); qoimi_kernel_name(i) names index i. */
+int qoimi_set_profiling(qoimi_ctx *ctx, int on);
+int qoimi_get_profile(qoimi_ctx *ctx, void *stream, double *ms, long long *calls, int cap);
+const char *qoimi_kernel_name(int index);
+
+/* Library/version string, e.g. "qoi_mi355x 0.1 gfx950". */
+const char *qoimi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QOI_MI355X_H */

@@ -1,0 +1,236 @@
+"""Python host side of the MI355X QOI path — a ctypes binding of libqoi_mi355x.so.
+
+Mirrors the reference's interface for this path (phoboslab/qoi ``qoi.h``):
+
+* :func:`qoi_encode` / :func:`qoi_decode` — same argument meaning and failure
+  behaviour (``None`` where the C functions return ``NULL``) as ``qoi.h:278`` /
+  ``qoi.h:289``; :class:`QoiDesc` is ``qoi_desc`` (``qoi.h:236-241``).
+* :class:`Context` — the additive device-resident batch API (``qoimi_*``), taking
+  raw device pointers (e.g. ``torch.Tensor.data_ptr()``) and a HIP stream handle.
+
+There is no CPU fallback here: if the shared library or the GPU is missing the
+calls raise / return ``None`` exactly as the C-ABI does.  torch is NOT imported by
+this module; bench.py and the tests use it only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+QOI_SRGB = 0
+QOI_LINEAR = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libqoi_mi355x.so")
+
+EXPORTS = (
+    # Part 1 — drop-in symbols (qoi.h:252,265,278,289)
+    "qoi_encode", "qoi_decode", "qoi_write", "qoi_read",
+    # Part 2 — additive
+    "qoimi_ctx_create", "qoimi_ctx_destroy", "qoimi_last_error", "qoimi_encode_bound",
+    "qoimi_encode_batch", "qoimi_encode_status", "qoimi_decode_batch", "qoimi_synth_frames",
+    "qoimi_decode_stats", "qoimi_version", "qoimi_set_profiling", "qoimi_get_profile", "qoimi_kernel_name",
+)
+
+
+class QoiDesc(ctypes.Structure):
+    """``qoi_desc`` (qoi.h:236-241)."""
+    _fields_ = [("width", ctypes.c_uint), ("height", ctypes.c_uint),
+                ("channels", ctypes.c_ubyte), ("colorspace", ctypes.c_ubyte)]
+
+    def __repr__(self):
+        return f"QoiDesc({self.width}x{self.height}, channels={self.channels}, colorspace={self.colorspace})"
+
+
+class QoiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libqoi_mi355x.so (built in-tree by ``__graft_entry__.build()``); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QoiError(f"{LIB_PATH} not built - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.qoi_encode.restype = vp
+    lib.qoi_encode.argtypes = [vp, ctypes.POINTER(QoiDesc), ctypes.POINTER(ci)]
+    lib.qoi_decode.restype = vp
+    lib.qoi_decode.argtypes = [vp, ci, ctypes.POINTER(QoiDesc), ci]
+    lib.qoi_write.restype = ci
+    lib.qoi_write.argtypes = [ctypes.c_char_p, vp, ctypes.POINTER(QoiDesc)]
+    lib.qoi_read.restype = vp
+    lib.qoi_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(QoiDesc), ci]
+    lib.qoimi_ctx_create.restype = ci
+    lib.qoimi_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
+    lib.qoimi_ctx_destroy.restype = None
+    lib.qoimi_ctx_destroy.argtypes = [vp]
+    lib.qoimi_last_error.restype = ctypes.c_char_p
+    lib.qoimi_last_error.argtypes = []
+    lib.qoimi_version.restype = ctypes.c_char_p
+    lib.qoimi_version.argtypes = []
+    lib.qoimi_encode_bound.restype = sz
+    lib.qoimi_encode_bound.argtypes = [ctypes.POINTER(QoiDesc)]
+    lib.qoimi_encode_batch.restype = ci
+    lib.qoimi_encode_batch.argtypes = [vp, vp, sz, ctypes.POINTER(QoiDesc), ci, vp, sz, vp, vp]
+    lib.qoimi_encode_status.restype = ci
+    lib.qoimi_encode_status.argtypes = [vp, vp]
+    lib.qoimi_decode_batch.restype = ci
+    lib.qoimi_decode_batch.argtypes = [vp, vp, sz, ctypes.POINTER(ci), ctypes.POINTER(QoiDesc), ci, ci, vp, sz, vp]
+    lib.qoimi_synth_frames.restype = ci
+    lib.qoimi_synth_frames.argtypes = [vp, ci, ctypes.c_uint, ctypes.c_uint, ci, ctypes.c_uint, ctypes.c_uint, vp, sz, vp]
+    lib.qoimi_decode_stats.restype = None
+    lib.qoimi_decode_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
+    lib.qoimi_set_profiling.restype = ci
+    lib.qoimi_set_profiling.argtypes = [vp, ci]
+    lib.qoimi_get_profile.restype = ci
+    lib.qoimi_get_profile.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), ci]
+    lib.qoimi_kernel_name.restype = ctypes.c_char_p
+    lib.qoimi_kernel_name.argtypes = [ci]
+    _lib = lib
+    return lib
+
+
+def _libc_free(p: int) -> None:
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    libc.free.restype = None
+    libc.free(p)
+
+
+def last_error() -> str:
+    return load_library().qoimi_last_error().decode()
+
+
+def encode_bound(width: int, height: int, channels: int) -> int:
+    return int(load_library().qoimi_encode_bound(ctypes.byref(QoiDesc(width, height, channels, 0))))
+
+
+# ----------------------------------------------------------------------------------
+# drop-in functions on host memory
+# ----------------------------------------------------------------------------------
+def qoi_encode(data, desc: QoiDesc) -> Optional[bytes]:
+    """``qoi_encode`` (qoi.h:278): raw RGB/RGBA bytes + desc -> QOI stream, ``None`` on failure."""
+    lib = load_library()
+    arr = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray))
+                               else np.asarray(data, dtype=np.uint8))
+    n = ctypes.c_int(0)
+    p = lib.qoi_encode(arr.ctypes.data, ctypes.byref(desc), ctypes.byref(n))
+    if not p:
+        return None
+    try:
+        return ctypes.string_at(p, n.value)
+    finally:
+        _libc_free(p)
+
+
+def qoi_decode(data: bytes, channels: int = 0, size: Optional[int] = None
+               ) -> Tuple[Optional[np.ndarray], QoiDesc]:
+    """``qoi_decode`` (qoi.h:289): QOI stream -> (pixels uint8[w*h*channels] or ``None``, desc)."""
+    lib = load_library()
+    buf = (ctypes.c_ubyte * max(len(data), 1)).from_buffer_copy(bytes(data).ljust(1, b"\0"))
+    desc = QoiDesc()
+    p = lib.qoi_decode(ctypes.addressof(buf), len(data) if size is None else size, ctypes.byref(desc), channels)
+    if not p:
+        return None, desc
+    try:
+        och = channels if channels else desc.channels
+        return np.frombuffer(ctypes.string_at(p, desc.width * desc.height * och), dtype=np.uint8).copy(), desc
+    finally:
+        _libc_free(p)
+
+
+def qoi_write(filename: str, data, desc: QoiDesc) -> int:
+    """``qoi_write`` (qoi.h:252): returns bytes written, 0 on failure."""
+    arr = np.ascontiguousarray(np.asarray(data, dtype=np.uint8))
+    return int(load_library().qoi_write(filename.encode(), arr.ctypes.data, ctypes.byref(desc)))
+
+
+def qoi_read(filename: str, channels: int = 0) -> Tuple[Optional[np.ndarray], QoiDesc]:
+    """``qoi_read`` (qoi.h:265)."""
+    lib = load_library()
+    desc = QoiDesc()
+    p = lib.qoi_read(filename.encode(), ctypes.byref(desc), channels)
+    if not p:
+        return None, desc
+    try:
+        och = channels if channels else desc.channels
+        return np.frombuffer(ctypes.string_at(p, desc.width * desc.height * och), dtype=np.uint8).copy(), desc
+    finally:
+        _libc_free(p)
+
+
+# ----------------------------------------------------------------------------------
+# device-resident batch API
+# ----------------------------------------------------------------------------------
+class Context:
+    """One GPU + workspace (``qoimi_ctx``).  Pointers are raw device addresses (ints)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.qoimi_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise QoiError(f"qoimi_ctx_create({device}) failed ({rc}): {last_error()}")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.qoimi_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise QoiError(f"{what} failed ({rc}): {last_error()}")
+
+    def encode_batch(self, d_pixels: int, pixel_stride: int, desc: QoiDesc, n_images: int,
+                     d_streams: int, stream_stride: int, d_stream_len: int, stream: int = 0) -> None:
+        self._check(self._lib.qoimi_encode_batch(self._h, d_pixels, pixel_stride, ctypes.byref(desc), n_images,
+                                                 d_streams, stream_stride, d_stream_len, stream), "qoimi_encode_batch")
+
+    def encode_status(self, stream: int = 0) -> None:
+        self._check(self._lib.qoimi_encode_status(self._h, stream), "qoimi_encode_status")
+
+    def decode_batch(self, d_streams: int, stream_stride: int, sizes: Sequence[int], descs: Sequence[QoiDesc],
+                     channels: int, d_pixels: int, pixel_stride: int, stream: int = 0) -> None:
+        n = len(sizes)
+        c_sizes = (ctypes.c_int * n)(*[int(s) for s in sizes])
+        c_descs = (QoiDesc * n)(*descs)
+        self._check(self._lib.qoimi_decode_batch(self._h, d_streams, stream_stride, c_sizes, c_descs, n, channels,
+                                                 d_pixels, pixel_stride, stream), "qoimi_decode_batch")
+
+    def synth_frames(self, kind: int, seed: int, first_frame: int, n_frames: int, width: int, height: int,
+                     d_pixels: int, pixel_stride: int, stream: int = 0) -> None:
+        self._check(self._lib.qoimi_synth_frames(self._h, kind, seed, first_frame, n_frames, width, height,
+                                                 d_pixels, pixel_stride, stream), "qoimi_synth_frames")
+
+    def set_profiling(self, on: bool) -> None:
+        self._check(self._lib.qoimi_set_profiling(self._h, 1 if on else 0), "qoimi_set_profiling")
+
+    def get_profile(self, stream: int = 0) -> dict:
+        """kernel name -> (accumulated ms, launches) since profiling was enabled (syncs stream)."""
+        ms = (ctypes.c_double * 32)()
+        calls = (ctypes.c_longlong * 32)()
+        n = self._lib.qoimi_get_profile(self._h, stream, ms, calls, 32)
+        return {self._lib.qoimi_kernel_name(i).decode(): (ms[i], calls[i]) for i in range(1, n)}
+
+    def decode_stats(self) -> dict:
+        out = (ctypes.c_longlong * 4)()
+        self._lib.qoimi_decode_stats(self._h, out)
+        return {"rounds": out[0], "redo_segments": out[1], "segments": out[2]}

@@ -1,0 +1,428 @@
+// qoi_host.hip — C-ABI shim of libqoi_mi355x.so (include/qoi_mi355x.h).
+//
+// Part 1 mirrors the reference's public functions (qoi.h:252,265,278,289): identical
+// argument validation, malloc()-owned results, NULL / 0 on failure.  Part 2 is the
+// additive device-resident batch API.  There is NO CPU codec in this library: every
+// pixel/stream byte is produced by the gfx950 kernels, and all entry points fail when
+// no GPU is usable.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/qoi_mi355x.h"
+#include "qoi_decode_core.h"
+#include "qoi_kernels.h"
+
+using namespace qoimi;
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+static thread_local std::string t_error;
+static int fail(int code, const std::string& msg) { t_error = msg; return code; }
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? QOIMI_E_NOMEM : QOIMI_E_NO_GPU,          \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+extern "C" const char* qoimi_last_error(void) { return t_error.c_str(); }
+extern "C" const char* qoimi_version(void) { return "qoi_mi355x 0.1 gfx950"; }
+
+// ------------------------------------------------------------------------------------
+// context: device + growable workspace arenas
+// ------------------------------------------------------------------------------------
+struct Arena {
+    void* base = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return QOIMI_OK;
+        if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + (1u << 20);
+        HIP_TRY(hipMalloc(&base, want));
+        cap = want;
+        return QOIMI_OK;
+    }
+    void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
+};
+
+struct Carver {   // hands out 256-byte aligned pieces of an arena
+    uint8_t* base; size_t off = 0;
+    explicit Carver(void* b) : base((uint8_t*)b) {}
+    template <class T> T* take(size_t count) {
+        off = (off + 255u) & ~(size_t)255u;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+struct qoimi_ctx {
+    int device = 0;
+    Arena enc_ws, dec_ws;       // kernel workspaces
+    Arena io_a, io_b, io_c;     // staging for the host-pointer (drop-in) path
+    uint32_t* host_word = nullptr;   // pinned word for read-backs
+    long long dec_stats[4] = {0, 0, 0, 0};
+    uint32_t seg_bytes = 2048;  // decode segment size
+    uint32_t* last_enc_err = nullptr;   // device flag of the most recent encode launch
+    KernelTimer timer;                  // optional per-kernel HIP-event timing
+    double prof_ms[kT_count] = {0};     // accumulated kernel milliseconds since profiling was (re)enabled
+    long long prof_calls[kT_count] = {0};
+};
+
+static const size_t kPixelCap = 400000000u;   // QOI_PIXELS_MAX, qoi.h:332
+
+static bool desc_ok(const qoi_desc* d) {       // qoi.h:366-369 / 514-518
+    return d && d->width != 0 && d->height != 0 && d->channels >= 3 && d->channels <= 4 &&
+           d->colorspace <= 1 && d->height < kPixelCap / d->width;
+}
+
+extern "C" size_t qoimi_encode_bound(const qoi_desc* desc) {
+    if (!desc_ok(desc)) return 0;
+    return (size_t)desc->width * desc->height * (desc->channels + 1u) + kHeaderBytes + kTrailerBytes;
+}
+
+extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
+    if (!out) return fail(QOIMI_E_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(QOIMI_E_NO_GPU, "no such GPU device");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(QOIMI_E_NO_GPU, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    qoimi_ctx* c = new qoimi_ctx();
+    c->device = device;
+    if (hipHostMalloc((void**)&c->host_word, 64) != hipSuccess) { delete c; return fail(QOIMI_E_NOMEM, "hipHostMalloc failed"); }
+    if (const char* e = getenv("QOIMI_SEG_BYTES")) {
+        long v = atol(e);
+        if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v;
+    }
+    *out = c;
+    return QOIMI_OK;
+}
+
+extern "C" void qoimi_ctx_destroy(qoimi_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    c->enc_ws.release(); c->dec_ws.release(); c->io_a.release(); c->io_b.release(); c->io_c.release();
+    if (c->host_word) (void)hipHostFree(c->host_word);
+    delete c;
+}
+
+// Per-kernel timing with HIP events on the launch stream.  on=1 resets the accumulators.
+extern "C" int qoimi_set_profiling(qoimi_ctx* c, int on) {
+    if (!c) return fail(QOIMI_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (on && !c->timer.created) {
+        for (int i = 0; i < KernelTimer::kMax; ++i) HIP_TRY(hipEventCreate(&c->timer.ev[i]));
+        c->timer.created = true;
+    }
+    c->timer.on = on != 0;
+    c->timer.n = 0;
+    if (on) for (int i = 0; i < kT_count; ++i) { c->prof_ms[i] = 0; c->prof_calls[i] = 0; }
+    return QOIMI_OK;
+}
+
+// fold the recorded events into the accumulators (the stream must be idle)
+static void timer_collect(qoimi_ctx* c) {
+    KernelTimer& t = c->timer;
+    for (int i = 1; i < t.n; ++i) {
+        if (t.tag[i] == kT_begin) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.ev[i - 1], t.ev[i]) == hipSuccess) { c->prof_ms[t.tag[i]] += ms; c->prof_calls[t.tag[i]] += 1; }
+    }
+    t.n = 0;
+}
+
+// Synchronises `stream`, then copies accumulated milliseconds and launch counts per kernel
+// (index = position in qoimi_kernel_name).  Returns the number of kernels.
+extern "C" int qoimi_get_profile(qoimi_ctx* c, void* stream, double* ms, long long* calls, int cap) {
+    if (!c) return fail(QOIMI_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    timer_collect(c);
+    for (int i = 0; i < kT_count && i < cap; ++i) { if (ms) ms[i] = c->prof_ms[i]; if (calls) calls[i] = c->prof_calls[i]; }
+    return kT_count;
+}
+
+extern "C" const char* qoimi_kernel_name(int i) {
+    static const char* names[kT_count] = {"", "enc_slab_summary", "enc_scan_groups", "enc_scan_images", "enc_slabs",
+        "dec_parse", "dec_chain_parse", "dec_slot_walk", "dec_chain_slots", "dec_summarize", "dec_chain_state",
+        "dec_segments", "dec_prepare_restart", "dec_fill"};
+    return (i >= 0 && i < kT_count) ? names[i] : "";
+}
+
+extern "C" void qoimi_decode_stats(qoimi_ctx* c, long long out[4]) {
+    for (int i = 0; i < 4; ++i) out[i] = c ? c->dec_stats[i] : 0;
+}
+
+// ------------------------------------------------------------------------------------
+// encode
+// ------------------------------------------------------------------------------------
+extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pixel_stride,
+                                  const qoi_desc* desc, int n_images,
+                                  void* d_streams, size_t stream_stride, int* d_stream_len,
+                                  void* stream) {
+    if (!c || !d_pixels || !d_streams || !d_stream_len || n_images <= 0) return fail(QOIMI_E_ARG, "NULL/empty argument");
+    if (!desc_ok(desc)) return fail(QOIMI_E_ARG, "descriptor rejected (qoi.h:364-372 rules)");
+    const size_t npx = (size_t)desc->width * desc->height;
+    if (pixel_stride < npx * desc->channels) return fail(QOIMI_E_ARG, "pixel_stride smaller than one image");
+    if (stream_stride < qoimi_encode_bound(desc)) return fail(QOIMI_E_ARG, "stream_stride smaller than qoimi_encode_bound");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+
+    EncParams p;
+    memset(&p, 0, sizeof p);
+    p.pixels = (const uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
+    p.npx = (uint32_t)npx; p.n_images = (uint32_t)n_images;
+    p.spi = (uint32_t)((npx + kEncSlabPx - 1) / kEncSlabPx);
+    p.gpi = (p.spi + 63u) / 64u;
+    p.width = desc->width; p.height = desc->height; p.channels = desc->channels; p.colorspace = desc->colorspace;
+    const size_t T = (size_t)p.n_images * p.spi, G = (size_t)p.n_images * p.gpi;
+    if (T > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (slab index overflows 32 bits)");
+
+    for (int pass = 0; pass < 2; ++pass) {      // pass 0 measures, pass 1 carves
+        Carver w(pass ? c->enc_ws.base : nullptr);
+        p.status = w.take<u64>(T); p.ticket = w.take<uint32_t>(1); p.err = w.take<uint32_t>(1);
+        const size_t zero_bytes = w.off;
+        p.sum_tab = w.take<uint32_t>(T * 64); p.sum_valid = w.take<u64>(T); p.sum_le = w.take<int>(T);
+        p.ent_tab = w.take<uint32_t>(T * 64); p.ent_valid = w.take<u64>(T); p.ent_le = w.take<int>(T);
+        p.grp_tab = w.take<uint32_t>(G * 64); p.grp_valid = w.take<u64>(G); p.grp_le = w.take<int>(G);
+        p.gent_tab = w.take<uint32_t>(G * 64); p.gent_le = w.take<int>(G);
+        if (!pass) { int rc = c->enc_ws.reserve(w.off + 256); if (rc) return rc; }
+        else HIP_TRY(hipMemsetAsync(c->enc_ws.base, 0, zero_bytes, st));   // look-back records, ticket, err
+    }
+    p.out = (uint8_t*)d_streams; p.out_stride = stream_stride; p.out_len = d_stream_len;
+    c->last_enc_err = p.err;
+    if (c->timer.n > KernelTimer::kMax - 16) { HIP_TRY(hipStreamSynchronize(st)); timer_collect(c); }
+    launch_encode(p, st, &c->timer);
+    HIP_TRY(hipGetLastError());
+    return QOIMI_OK;
+}
+
+// Synchronise `stream` and report whether the last encode on this context tripped a
+// device-side liveness bound (look-back spin limit).  Never expected; outputs of such a
+// call must be discarded.
+extern "C" int qoimi_encode_status(qoimi_ctx* c, void* stream) {
+    if (!c) return fail(QOIMI_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (!c->last_enc_err) return QOIMI_OK;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, c->last_enc_err, sizeof err, hipMemcpyDeviceToHost));
+    if (err) return fail(QOIMI_E_INTERNAL, "encode look-back exceeded its spin bound");
+    return QOIMI_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------
+extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t stream_stride,
+                                  const int* sizes, const qoi_desc* descs, int n_images, int channels,
+                                  void* d_pixels, size_t pixel_stride, void* stream) {
+    if (!c || !d_streams || !sizes || !descs || !d_pixels || n_images <= 0) return fail(QOIMI_E_ARG, "NULL/empty argument");
+    if (channels != 0 && channels != 3 && channels != 4) return fail(QOIMI_E_ARG, "channels must be 0, 3 or 4 (qoi.h:499)");
+    int och = 0;
+    std::vector<DecImage> imgs((size_t)n_images);
+    const uint32_t B = c->seg_bytes;
+    uint64_t total = 0;
+    for (int i = 0; i < n_images; ++i) {
+        if (sizes[i] < kHeaderBytes + kTrailerBytes) return fail(QOIMI_E_ARG, "stream shorter than 22 bytes (qoi.h:500)");
+        if (!desc_ok(&descs[i])) return fail(QOIMI_E_ARG, "descriptor rejected (qoi.h:513-521 rules)");
+        const int o = channels ? channels : descs[i].channels;
+        if (och && o != och) return fail(QOIMI_E_ARG, "all images of a batch must share the output channel count");
+        och = o;
+        const size_t npx = (size_t)descs[i].width * descs[i].height;
+        if (npx * (size_t)o > pixel_stride) return fail(QOIMI_E_ARG, "pixel_stride smaller than a decoded image");
+        if ((size_t)sizes[i] > stream_stride && n_images > 1) return fail(QOIMI_E_ARG, "stream longer than stream_stride");
+        DecImage& im = imgs[(size_t)i];
+        memset(&im, 0, sizeof im);
+        im.stream_off = (size_t)i * stream_stride;
+        im.chunks_end = (uint32_t)(sizes[i] - kTrailerBytes);
+        im.npx = (uint32_t)npx;
+        im.seg_base = (uint32_t)total;
+        im.nseg = (im.chunks_end - kHeaderBytes + B - 1u) / B;
+        total += im.nseg;
+    }
+    if (total > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (segment index overflows 32 bits)");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+
+    DecParams p;
+    memset(&p, 0, sizeof p);
+    p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
+    p.total_segs = (uint32_t)total; p.seg_bytes = B;
+    p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
+    const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
+    for (int pass = 0; pass < 2; ++pass) {
+        Carver w(pass ? c->dec_ws.base : nullptr);
+        p.pending = w.take<uint32_t>(2); p.redo_segs = p.pending ? p.pending + 1 : nullptr;
+        p.images = w.take<DecImage>((size_t)n_images);
+        p.first_bad = w.take<uint32_t>((size_t)n_images);
+        p.parse = w.take<ParseRec>(Q); p.entry_phase = w.take<uint8_t>(Q); p.px_off = w.take<uint32_t>(Q);
+        p.slot_rec = w.take<SlotRec>(Q); p.slot_in = w.take<uint8_t>(Q); p.alpha_in = w.take<uint8_t>(Q);
+        p.summary = w.take<u64>(Q * 65); p.entry = w.take<uint32_t>(Q * 65); p.fix = w.take<uint32_t>(Q * 65);
+        if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }
+    }
+    HIP_TRY(hipMemcpyAsync(p.images, imgs.data(), imgs.size() * sizeof(DecImage), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));       // imgs is pageable host memory
+    HIP_TRY(hipMemsetAsync(p.redo_segs, 0, sizeof(uint32_t), st));
+
+    launch_decode_parse(p, st, &c->timer);
+    long long rounds = 0;
+    for (;;) {
+        HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
+        launch_decode_round(p, och, st, &c->timer);
+        ++rounds;
+        if (!p.total_segs) break;
+        HIP_TRY(hipMemcpyAsync(c->host_word, p.pending, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        timer_collect(c);
+        if (c->host_word[0] == 0) break;
+        if (rounds > (long long)total + 2) return fail(QOIMI_E_INTERNAL, "decode repair loop did not converge");
+    }
+    launch_decode_fill(p, och, st, &c->timer);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    timer_collect(c);
+    c->dec_stats[0] = rounds;
+    c->dec_stats[1] = p.total_segs ? c->host_word[1] : 0;
+    c->dec_stats[2] = (long long)total;
+    return QOIMI_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// synthetic frames
+// ------------------------------------------------------------------------------------
+extern "C" int qoimi_synth_frames(qoimi_ctx* c, int kind, unsigned seed, unsigned first_frame,
+                                  int n_frames, unsigned width, unsigned height,
+                                  void* d_pixels, size_t pixel_stride, void* stream) {
+    if (!c || !d_pixels || n_frames <= 0 || kind < 0 || kind > 3 || width == 0 || height == 0)
+        return fail(QOIMI_E_ARG, "bad argument");
+    const size_t npx = (size_t)width * height;
+    if (npx >= kPixelCap || pixel_stride < npx * 4 || n_frames > 65535) return fail(QOIMI_E_ARG, "bad frame geometry");
+    HIP_TRY(hipSetDevice(c->device));
+    SynthParams p;
+    p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride; p.npx = (uint32_t)npx; p.width = width;
+    p.n_frames = (uint32_t)n_frames; p.first_frame = first_frame; p.seed = seed; p.kind = kind;
+    launch_synth(p, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return QOIMI_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Part 1 — drop-in entry points on host pointers
+// ------------------------------------------------------------------------------------
+static std::mutex g_mutex;
+static qoimi_ctx* g_ctx = nullptr;
+
+static qoimi_ctx* global_ctx() {   // caller holds g_mutex
+    if (!g_ctx) {
+        int dev = 0;
+        if (const char* e = getenv("QOIMI_DEVICE")) dev = atoi(e);
+        if (qoimi_ctx_create(dev, &g_ctx) != QOIMI_OK) {
+            fprintf(stderr, "qoi_mi355x: no usable MI355X (%s); there is no CPU fallback\n", t_error.c_str());
+            g_ctx = nullptr;
+        }
+    }
+    return g_ctx;
+}
+
+extern "C" void* qoi_encode(const void* data, const qoi_desc* desc, int* out_len) {
+    if (!data || !out_len || !desc_ok(desc)) return NULL;                 // qoi.h:364-372
+    std::lock_guard<std::mutex> lock(g_mutex);
+    qoimi_ctx* c = global_ctx();
+    if (!c) return NULL;
+    const size_t npx = (size_t)desc->width * desc->height;
+    const size_t in_bytes = npx * desc->channels;
+    const size_t bound = qoimi_encode_bound(desc);                        // qoi.h:374-376
+    if (c->io_a.reserve(in_bytes + 16) || c->io_b.reserve(bound + 16) || c->io_c.reserve(256)) return NULL;
+    void* result = NULL;
+    do {
+        if (hipMemcpy(c->io_a.base, data, in_bytes, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (qoimi_encode_batch(c, c->io_a.base, in_bytes, desc, 1, c->io_b.base, bound, (int*)c->io_c.base, 0) != QOIMI_OK) break;
+        int len = 0;
+        if (hipMemcpy(&len, c->io_c.base, sizeof len, hipMemcpyDeviceToHost) != hipSuccess) break;
+        const uint32_t err = qoimi_encode_status(c, 0) == QOIMI_OK ? 0u : 1u;
+        if (err != 0 || len < kHeaderBytes + kTrailerBytes || (size_t)len > bound) {
+            t_error = "encode kernel reported a liveness failure";
+            break;
+        }
+        uint8_t* bytes = (uint8_t*)malloc(bound);                          // worst case, as qoi.h:379
+        if (!bytes) break;
+        if (hipMemcpy(bytes, c->io_b.base, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) { free(bytes); break; }
+        *out_len = len;
+        result = bytes;
+    } while (0);
+    return result;
+}
+
+static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+extern "C" void* qoi_decode(const void* data, int size, qoi_desc* desc, int channels) {
+    if (!data || !desc || (channels != 0 && channels != 3 && channels != 4) ||
+        size < kHeaderBytes + kTrailerBytes) return NULL;                 // qoi.h:497-503
+    const uint8_t* bytes = (const uint8_t*)data;
+    const bool magic_ok = memcmp(bytes, "qoif", 4) == 0;
+    desc->width = be32(bytes + 4);                                        // filled before validation, qoi.h:507-511
+    desc->height = be32(bytes + 8);
+    desc->channels = bytes[12];
+    desc->colorspace = bytes[13];
+    if (!desc_ok(desc) || !magic_ok) return NULL;                         // qoi.h:513-521
+    const int och = channels ? channels : desc->channels;                 // qoi.h:523-525
+    const size_t out_bytes = (size_t)desc->width * desc->height * (size_t)och;
+
+    std::lock_guard<std::mutex> lock(g_mutex);
+    qoimi_ctx* c = global_ctx();
+    if (!c) return NULL;
+    if (c->io_a.reserve((size_t)size + 16) || c->io_b.reserve(out_bytes + 16)) return NULL;
+    if (hipMemcpy(c->io_a.base, data, (size_t)size, hipMemcpyHostToDevice) != hipSuccess) return NULL;
+    if (qoimi_decode_batch(c, c->io_a.base, (size_t)size, &size, desc, 1, channels, c->io_b.base, out_bytes, 0) != QOIMI_OK)
+        return NULL;
+    uint8_t* pixels = (uint8_t*)malloc(out_bytes);                        // qoi.h:527-531
+    if (!pixels) return NULL;
+    if (hipMemcpy(pixels, c->io_b.base, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) { free(pixels); return NULL; }
+    return pixels;
+}
+
+// stdio wrappers, same observable behaviour as qoi.h:595-646
+extern "C" int qoi_write(const char* filename, const void* data, const qoi_desc* desc) {
+    FILE* f = fopen(filename, "wb");
+    if (!f) return 0;
+    int size = 0;
+    void* encoded = qoi_encode(data, desc, &size);
+    if (!encoded) { fclose(f); return 0; }
+    fwrite(encoded, 1, (size_t)size, f);
+    fflush(f);
+    const int err = ferror(f);
+    fclose(f);
+    free(encoded);
+    return err ? 0 : size;
+}
+
+extern "C" void* qoi_read(const char* filename, qoi_desc* desc, int channels) {
+    FILE* f = fopen(filename, "rb");
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END);
+    const long size = ftell(f);
+    if (size <= 0 || size > 0x7FFFFFFFL || fseek(f, 0, SEEK_SET) != 0) { fclose(f); return NULL; }
+    void* data = malloc((size_t)size);
+    if (!data) { fclose(f); return NULL; }
+    const size_t got = fread(data, 1, (size_t)size, f);
+    fclose(f);
+    void* pixels = (got != (size_t)size) ? NULL : qoi_decode(data, (int)got, desc, channels);
+    free(data);
+    return pixels;
+}

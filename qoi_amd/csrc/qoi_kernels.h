@@ -1,0 +1,103 @@
+// qoi_kernels.h — parameter blocks and launchers shared by the kernels and the C-ABI shim.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace qoimi {
+
+typedef unsigned long long u64;
+
+constexpr int kHeaderBytes = 14, kTrailerBytes = 8;   // qoi.h:326, qoi.h:339
+
+// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's
+// roofline figure).  mark(tag) closes the interval of the kernel launched just before it.
+enum KernelTag { kT_begin = 0,
+                 kT_enc_summary, kT_enc_scan_groups, kT_enc_scan_images, kT_enc_slabs,
+                 kT_dec_parse, kT_dec_chain_parse, kT_dec_slot_walk, kT_dec_chain_slots, kT_dec_summarize,
+                 kT_dec_chain_state, kT_dec_segments, kT_dec_restart, kT_dec_fill, kT_count };
+struct KernelTimer {
+    static constexpr int kMax = 512;
+    hipEvent_t ev[kMax]; int tag[kMax]; int n = 0; bool on = false; bool created = false;
+    void mark(int t, hipStream_t st) {
+        if (!on || n >= kMax) return;
+        tag[n] = t; (void)hipEventRecord(ev[n], st); ++n;
+    }
+};
+
+// ---- encode ------------------------------------------------------------------------
+constexpr int kEncSteps = 32;                         // 64-pixel steps per slab
+constexpr uint32_t kEncSlabPx = 64u * kEncSteps;      // pixels per slab (one wavefront)
+
+struct EncParams {
+    const uint8_t* pixels;   // image i at pixels + i*pixel_stride
+    size_t pixel_stride;
+    uint32_t npx;            // width*height
+    uint32_t n_images;
+    uint32_t spi;            // slabs per image
+    uint32_t gpi;            // 64-slab groups per image
+    uint32_t width, height;
+    uint8_t channels, colorspace;
+    // workspace (see enc_workspace_bytes)
+    uint32_t* sum_tab;   u64* sum_valid;  int* sum_le;     // E1 out        [n_images*spi]
+    uint32_t* ent_tab;   u64* ent_valid;  int* ent_le;     // E2a out       [n_images*spi]
+    uint32_t* grp_tab;   u64* grp_valid;  int* grp_le;     // E2a aggregate [n_images*gpi]
+    uint32_t* gent_tab;  int* gent_le;                     // E2b out       [n_images*gpi]
+    u64* status;         // look-back records [n_images*spi]   -- zeroed before every launch
+    uint32_t* ticket;    // slab ticket counter               -- zeroed before every launch
+    uint32_t* err;       // liveness-bound flag               -- zeroed before every launch
+    // output
+    uint8_t* out; size_t out_stride; int* out_len;
+};
+
+void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm);
+
+// ---- decode ------------------------------------------------------------------------
+struct ParseRec; struct SlotRec;
+
+struct DecImage {
+    size_t   stream_off;   // stream i starts at streams + stream_off
+    uint32_t chunks_end;   // size - 8 (qoi.h:539); chunk region is [14, chunks_end)
+    uint32_t npx;          // width*height
+    uint32_t seg_base;     // global index of this image's first segment
+    uint32_t nseg;         // ceil((chunks_end-14)/seg_bytes)
+    // filled on the device
+    uint32_t total_px;     // pixels produced by all chunks, clamped to npx        (S1)
+    uint32_t n_active;     // segments that start before the pixel limit            (S1)
+    uint32_t start_seg;    // first segment still to be (re)decoded; n_active: done
+    uint32_t final_px;     // exit pixel of the last active segment                 (P4)
+};
+
+struct DecParams {
+    const uint8_t* streams;
+    DecImage* images;      // device array [n_images]
+    uint32_t n_images, total_segs, seg_bytes;
+    uint8_t* pixels; size_t pixel_stride;
+    // workspace, per global segment q
+    ParseRec* parse;           // P1
+    uint8_t*  entry_phase;     // S1
+    uint32_t* px_off;          // S1
+    SlotRec*  slot_rec;        // P2
+    uint8_t*  slot_in;         // S2
+    uint8_t*  alpha_in;        // S2
+    u64*      summary;         // P3  [q][65] symbolic words (slots 0..63, pixel)
+    uint32_t* entry;           // S3  [q][65] concrete entry state (table 0..63, pixel)
+    uint32_t* fix;             // P4  [q][65] true entry state of q where the check failed
+    uint32_t* first_bad;       // [n_images] min failing segment, 0xFFFFFFFF: none
+    uint32_t* pending;         // [1] images that need another round
+    uint32_t* redo_segs;       // [1] statistics
+};
+
+void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm);
+void launch_decode_round(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);
+void launch_decode_fill(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);
+
+// ---- synthetic frames --------------------------------------------------------------
+struct SynthParams {
+    uint8_t* pixels; size_t pixel_stride;
+    uint32_t npx, width, n_frames, first_frame, seed;
+    int kind;
+};
+void launch_synth(const SynthParams& p, hipStream_t st);
+
+}  // namespace qoimi

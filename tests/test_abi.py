@@ -1,0 +1,69 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/qoi_mi355x.h declares;
+argument validation that needs no GPU behaves like the reference (qoi.h:364-372, 497-503)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from qoi_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(api.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return api.load_library()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "qoi_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(qoi_[a-z]+|qoimi_[a-z_]+)\s*\(", hdr))
+    assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_desc_layout():
+    assert ctypes.sizeof(api.QoiDesc) == 12
+    assert (api.QoiDesc.width.offset, api.QoiDesc.height.offset,
+            api.QoiDesc.channels.offset, api.QoiDesc.colorspace.offset) == (0, 4, 8, 9)
+
+
+def test_encode_bound(lib):
+    assert api.encode_bound(3840, 2160, 4) == 3840 * 2160 * 5 + 22      # qoi.h:374-376
+    assert api.encode_bound(0, 4, 4) == 0
+    assert api.encode_bound(20000, 20000, 4) == 0                       # qoi.h:369
+    assert api.encode_bound(16384, 16384, 4) == 16384 * 16384 * 5 + 22
+
+
+def test_argument_rejections_need_no_gpu(lib):
+    px = np.zeros(64, dtype=np.uint8)
+    for w, h, ch, cs in [(0, 4, 4, 0), (4, 0, 4, 0), (4, 4, 2, 0), (4, 4, 5, 0), (4, 4, 4, 2), (20000, 20000, 4, 0)]:
+        assert api.qoi_encode(px, api.QoiDesc(w, h, ch, cs)) is None
+    out, _ = api.qoi_decode(b"qoif" + b"\0" * 10, 4)                     # size < 22
+    assert out is None
+    out, _ = api.qoi_decode(b"qoif" + b"\0" * 30, 5)                     # bad channels argument
+    assert out is None
+    out, d = api.qoi_decode(b"qoig" + bytes([0, 0, 0, 2, 0, 0, 0, 3, 4, 0]) + b"\0" * 9, 4)   # bad magic
+    assert out is None and (d.width, d.height, d.channels) == (2, 3, 4)  # desc filled before validation
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    """On a box without a GPU the codec must FAIL, not silently compute on the CPU."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    px = np.zeros(4 * 4 * 4, dtype=np.uint8)
+    assert api.qoi_encode(px, api.QoiDesc(4, 4, 4, 0)) is None
+    with pytest.raises(api.QoiError):
+        api.Context(0)

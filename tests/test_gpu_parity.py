@@ -1,0 +1,203 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the oracle.
+
+* drop-in qoi_encode: stream BYTE-IDENTICAL to the reference encoder's (golden vectors)
+* drop-in qoi_decode: pixels bit-identical to the reference decoder's for every golden
+  stream incl. truncated / malformed / adversarial ones; NULL exactly where it returns NULL
+* device-resident batch API at BASELINE sizes: synthetic frames generated on the GPU,
+  compared with the oracle (live) and through the round-trip property qoibench.c:408-417
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch  # noqa: F401  (first, so the library binds to torch's HIP runtime)
+    from qoi_amd import api as _api
+    assert torch.cuda.is_available()
+    return _api
+
+
+@pytest.fixture(scope="module")
+def ctx(api):
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def oracle(ref, port):
+    return ref or port
+
+
+# ------------------------------------------------------------------ drop-in encode
+def test_encode_golden_byte_identical(api, golden):
+    for c in cases.encode_cases():
+        s = api.qoi_encode(c["pixels"], api.QoiDesc(c["w"], c["h"], c["ch"], c["cs"]))
+        assert s is not None, (c["name"], api.last_error())
+        want = golden[f"enc/{c['name']}/stream"].tobytes()
+        assert s == want, (c["name"], len(s), len(want), first_diff(s, want))
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return i, a[max(0, i - 4):i + 8].hex(), b[max(0, i - 4):i + 8].hex()
+    return n, None, None
+
+
+def test_encode_rejections(api):
+    px = np.zeros(64, dtype=np.uint8)
+    for c in cases.encode_arg_cases():
+        assert api.qoi_encode(px, api.QoiDesc(c["w"], c["h"], c["ch"], c["cs"])) is None, c["name"]
+
+
+# ------------------------------------------------------------------ drop-in decode
+def test_decode_golden_bit_exact(api, golden, encoded_streams):
+    n = 0
+    for c in cases.decode_cases(encoded_streams):
+        px, d = api.qoi_decode(c["stream"], c["channels"], c["size"])
+        ok = bool(golden[f"dec/{c['name']}/ok"][0])
+        assert (px is not None) == ok, (c["name"], api.last_error())
+        if len(c["stream"]) >= 22 and c["channels"] in (0, 3, 4):
+            assert [d.width, d.height, d.channels, d.colorspace] == list(golden[f"dec/{c['name']}/desc"]), c["name"]
+        if ok:
+            want = golden[f"dec/{c['name']}/pixels"]
+            assert np.array_equal(px, want), (c["name"], int(np.argmax(px != want)))
+        n += 1
+    assert n > 150
+
+
+@pytest.mark.parametrize("seg", [64, 333])
+def test_decode_small_segments(api, golden, encoded_streams, seg):
+    """Same golden streams with tiny decode segments: every segment boundary case + restart loop."""
+    os.environ["QOIMI_SEG_BYTES"] = str(seg)
+    try:
+        import torch
+        c = api.Context(0)
+        for case in cases.decode_cases(encoded_streams):
+            if not bool(golden[f"dec/{case['name']}/ok"][0]):
+                continue
+            desc = golden[f"dec/{case['name']}/desc"]
+            d = api.QoiDesc(int(desc[0]), int(desc[1]), int(desc[2]), int(desc[3]))
+            och = case["channels"] or d.channels
+            s = torch.from_numpy(np.frombuffer(case["stream"] + b"\0" * 8, dtype=np.uint8).copy()).cuda()
+            out = torch.full((d.width * d.height * och + 8,), 0xAB, dtype=torch.uint8, device="cuda")
+            c.decode_batch(s.data_ptr(), s.numel(), [len(case["stream"])], [d], case["channels"],
+                           out.data_ptr(), d.width * d.height * och)
+            got = out[:d.width * d.height * och].cpu().numpy()
+            assert np.array_equal(got, golden[f"dec/{case['name']}/pixels"]), (case["name"], seg)
+            assert int(out[d.width * d.height * och]) == 0xAB, "wrote past the image"
+        c.close()
+    finally:
+        del os.environ["QOIMI_SEG_BYTES"]
+
+
+def test_round_trip_random_host_api(api, oracle):
+    rng = np.random.default_rng(7)
+    for it in range(40):
+        w = int(rng.integers(1, 300)); h = int(rng.integers(1, 60)); ch = 3 + int(rng.integers(0, 2))
+        if it % 3 == 0:
+            px = rng.integers(0, 256, size=(w * h, ch), dtype=np.uint8)
+        elif it % 3 == 1:
+            pal = rng.integers(0, 256, size=(int(rng.integers(1, 50)), ch), dtype=np.uint8)
+            px = pal[rng.integers(0, len(pal), size=w * h)]
+        else:
+            px = np.cumsum(rng.integers(-3, 4, size=(w * h, ch)), axis=0).astype(np.uint8)
+        s = api.qoi_encode(px, api.QoiDesc(w, h, ch, 0))
+        assert s == oracle.encode(px, w, h, ch), (it, w, h, ch)
+        for chn in (0, 3, 4):
+            got, _ = api.qoi_decode(s, chn)
+            want, _ = oracle.decode(s, chn)
+            assert np.array_equal(got, want), (it, chn)
+
+
+# ------------------------------------------------------------------ device batch API
+@pytest.mark.parametrize("kind", ["photo", "noise", "uiflat", "constant"])
+def test_4k_frame_device_path(api, ctx, oracle, kind):
+    """BASELINE config 2: one 3840x2160 RGBA frame, encode + decode on the GPU, bit-exact."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    w, h = 3840, 2160
+    b = DeviceBatch(ctx, w, h, 4, 1)
+    ctx.synth_frames(synth.KIND_ID[kind], synth.DEFAULT_SEED, 5, 1, w, h, b.pixels.data_ptr(), b.pixel_stride, b.stream)
+    host = synth.frame_rgba(kind, w, h, 5)
+    assert np.array_equal(b.pixels[:w * h * 4].cpu().numpy(), host.reshape(-1)), "device generator != synth.py"
+    lens = b.encode()
+    want = oracle.encode(host, w, h, 4)
+    got = b.stream_bytes(0, lens[0])
+    assert len(got) == len(want) and got == want, (kind, lens[0], len(want))
+    out = torch.zeros(b.pixel_stride, dtype=torch.uint8, device="cuda")
+    b.decode_into(out, lens)
+    assert torch.equal(out[:w * h * 4], b.pixels[:w * h * 4]), kind
+    assert ctx.decode_stats()["segments"] > 0
+
+
+def test_batch_1080p_frames(api, ctx, oracle):
+    """BASELINE config 3 shape (batch of 1920x1080 frames), 12 distinct frames, mixed content."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    w, h, n = 1920, 1080, 12
+    b = DeviceBatch(ctx, w, h, 4, n)
+    kinds = ["photo", "noise", "uiflat", "constant"]
+    for i in range(n):
+        ctx.synth_frames(synth.KIND_ID[kinds[i % 4]], synth.DEFAULT_SEED, 100 + i, 1, w, h,
+                         b.pixels.data_ptr() + i * b.pixel_stride, b.pixel_stride, b.stream)
+    lens = b.encode()
+    for i in (0, 1, 2, 3, 11):
+        host = synth.frame_rgba(kinds[i % 4], w, h, 100 + i)
+        assert b.stream_bytes(i, lens[i]) == oracle.encode(host, w, h, 4), i
+    out = torch.zeros(n * b.pixel_stride, dtype=torch.uint8, device="cuda")
+    b.decode_into(out, lens)
+    assert torch.equal(out.view(n, -1)[:, :w * h * 4], b.pixels.view(n, -1)[:, :w * h * 4])
+
+
+def test_three_channel_device_path(api, ctx, oracle):
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    w, h = 1000, 700
+    host = synth.frame_rgb("photo", w, h, 9)
+    b = DeviceBatch(ctx, w, h, 3, 2)
+    b.upload(0, host); b.upload(1, host[::-1].copy())
+    lens = b.encode()
+    assert b.stream_bytes(0, lens[0]) == oracle.encode(host, w, h, 3)
+    for och in (3, 4):
+        stride = (w * h * och + 255) // 256 * 256
+        out = torch.zeros(2 * stride, dtype=torch.uint8, device="cuda")
+        b.decode_into(out, lens, och)
+        want, _ = oracle.decode(b.stream_bytes(0, lens[0]), och)
+        assert np.array_equal(out[:w * h * och].cpu().numpy(), want)
+
+
+def test_16k_frame_round_trip(api, ctx):
+    """BASELINE config 4: 16384x16384 (268 Mpx, near the 400 Mpx cap) - scan / LDS stress.
+    Oracle-free size-independent property: decode(encode(x)) == x, plus stream well-formedness."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    w = h = 16384
+    b = DeviceBatch(ctx, w, h, 4, 1)
+    ctx.synth_frames(synth.KIND_ID["photo"], synth.DEFAULT_SEED, 1, 1, w, h, b.pixels.data_ptr(), b.pixel_stride, b.stream)
+    lens = b.encode()
+    n = int(lens[0])
+    head = b.stream_bytes(0, 14)
+    assert head[:4] == b"qoif" and int.from_bytes(head[4:8], "big") == w and int.from_bytes(head[8:12], "big") == h
+    tail = b.streams[n - 8:n].cpu().numpy().tobytes()
+    assert tail == b"\0\0\0\0\0\0\0\x01"
+    assert 1.0 < n / (w * h) < 1.5
+    out = torch.zeros(b.pixel_stride, dtype=torch.uint8, device="cuda")
+    b.decode_into(out, lens)
+    assert torch.equal(out[:w * h * 4], b.pixels[:w * h * 4])
+    # checksum-of-checksums against the CPU oracle on a 1/64 strip of the same frame is
+    # covered at 4K; here the whole-image property is the check.
