@@ -87,22 +87,18 @@ def main() -> None:
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--encode-only", action="store_true", help="diagnostics: time the encoder alone (no decode, no check)")
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     from qoi_amd import api, synth
+    from qoi_amd import dist as qdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+    rank, world, local = qdist.env_world()
     assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    qdist.init("nccl", dev)          # RCCL; only counters ever cross GPUs
     ctx = api.Context(local)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -115,7 +111,8 @@ def main() -> None:
     streams = torch.empty(F * sstride, dtype=torch.uint8, device=dev)
     decoded = torch.empty(F * pstride, dtype=torch.uint8, device=dev)
     lens = torch.zeros(F, dtype=torch.int32, device=dev)
-    ctx.synth_frames(synth.KIND_ID[args.kind], synth.DEFAULT_SEED, rank * F, F, w, h,
+    my_frames = qdist.shard_frames(rank, world, F)      # weak scaling: F distinct frames per GPU
+    ctx.synth_frames(synth.KIND_ID[args.kind], synth.DEFAULT_SEED, my_frames[0], F, w, h,
                      pixels.data_ptr(), pstride, stream)
     torch.cuda.synchronize()
 
@@ -127,11 +124,12 @@ def main() -> None:
 
     def step():
         ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+        if args.encode_only:
+            return
         ctx.decode_batch(streams.data_ptr(), sstride, sizes, descs, 4, decoded.data_ptr(), pstride, stream)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        qdist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -148,16 +146,12 @@ def main() -> None:
     ctx.encode_status(stream)
 
     # bit-exact round trip (qoibench.c:408-417) checked outside the timed region
-    ok = bool(torch.equal(decoded.view(F, -1)[:, :npx * 4], pixels.view(F, -1)[:, :npx * 4]))
+    ok = args.encode_only or bool(torch.equal(decoded.view(F, -1)[:, :npx * 4], pixels.view(F, -1)[:, :npx * 4]))
     dstats = ctx.decode_stats()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([float(F * npx * args.steps), float(sum(sizes)) * args.steps, float(ok)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # RCCL: counters only
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    total_px, total_stream_bytes, n_ok = (float(x) for x in cnt.cpu().numpy())
+    # RCCL: counters only (max elapsed; summed pixels / stream bytes / verified ranks)
+    elapsed, (total_px, total_stream_bytes, n_ok) = qdist.reduce_counters(
+        elapsed, [float(F * npx * args.steps), float(sum(sizes)) * args.steps, float(ok)], dev)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -187,10 +181,13 @@ def main() -> None:
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": round(per_launch_ms, 4)},
         }
+        if args.encode_only:
+            out["config"]["workload"] += " [ENCODE ONLY - diagnostic run, not the benchmark]"
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.kind, w, h, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

@@ -158,23 +158,36 @@ __device__ __forceinline__ void literal_chunk(uint32_t px, uint32_t prev, u64& b
     else { bytes = rgb_b; len = 4; }
 }
 
-template <int CH, int K>
-__global__ __launch_bounds__(256) void enc_slabs(EncParams p) {
-    __shared__ uint32_t s_table[4][64];
-    __shared__ u64 s_mask[4][64];
-    __shared__ uint32_t s_ticket;
+// PROBE selects how the colour table is probed/updated for the 64 pixels of a step:
+//   0  ds_or_b64 lane masks + ds_bpermute (order-independent, always valid)
+//   1  one ds_wrxchg_rtn_b32 per edge lane: relies on the LDS serving the lanes of one
+//      instruction that hit the same address in ascending lane order - MEASURED at context
+//      creation by lds_order_selftest; the host only picks 1 when that test passes.
+// LAST: the slab holds the image's last pixel (and possibly lanes beyond it).
+// ABL:  ablation bits for profiling only (1: no emission, 2: no look-back, 4: no probe).
+//
+// Chunk bytes go to a per-wave LDS staging buffer at slab-local offsets while the slab is
+// classified (one pass over the pixels); once the look-back has produced the slab's byte
+// offset the staged bytes are copied out with aligned dword stores.
+// Per-lane predicates are kept as booleans so that hipcc holds them as 64-bit lane masks
+// in SGPRs: class algebra and length bits cost scalar instructions, not VALU.
+template <int K>
+struct EncLds {
+    static constexpr uint32_t kStageBytes = 64u * K * 5u + 8u;     // <= 5 B/px + one flushed run byte, + slack
+    uint32_t table[64];
+    u64 mask[64];
+    uint32_t stage[(kStageBytes + 3u) / 4u];
+};
 
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    // Slab ids are handed out in START order so that every predecessor a look-back can
-    // wait on is already running or finished (no reliance on dispatch order; guide G16).
-    if (threadIdx.x == 0) s_ticket = atomicAdd(p.ticket, 1u);
-    __syncthreads();
-    const uint32_t g = s_ticket * 4u + wave;
-    const uint32_t total = p.n_images * p.spi;
-    if (g >= total) return;
+constexpr int kEncUnroll = 8;     // steps per unrolled group (pixels of the next group are prefetched)
+
+template <int CH, int K, int PROBE, bool LAST, int ABL>
+__device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, uint32_t lane, EncLds<K>& L) {
     const uint32_t img = g / p.spi, s = g - img * p.spi;
     const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
     const uint32_t n = p.npx, lo = s * (64u * K);
+    uint8_t* stage8 = reinterpret_cast<uint8_t*>(L.stage);
+    uint8_t* table8 = reinterpret_cast<uint8_t*>(L.table);
 
     // ---- entry state: colour table + last edge position ------------------------------
     {
@@ -182,8 +195,8 @@ __global__ __launch_bounds__(256) void enc_slabs(EncParams p) {
         const uint32_t loc = p.ent_tab[(size_t)g * 64u + lane];
         const uint32_t far = p.gent_tab[(size_t)G * 64u + lane];
         const u64 lv = p.ent_valid[g];
-        s_table[wave][lane] = ((lv >> lane) & 1ull) ? loc : far;
-        s_mask[wave][lane] = 0;
+        L.table[lane] = ((lv >> lane) & 1ull) ? loc : far;
+        if (PROBE == 0) L.mask[lane] = 0;
     }
     int last_edge = max(p.ent_le[g], p.gent_le[img * p.gpi + (s >> 6)]);   // max edge position < lo, or -1
     uint32_t carry = (lo > 0) ? load_px<CH>(pix, lo - 1) : kInitPx;
@@ -192,77 +205,120 @@ __global__ __launch_bounds__(256) void enc_slabs(EncParams p) {
     const u64 lane_bit = 1ull << lane;
     const u64 below = lane_bit - 1ull;
 
-    // ---- pass 1: classify every pixel of the slab, keep chunks in registers ------------
-    uint32_t px_reg[K];
+    uint32_t cur[kEncUnroll], nxt[kEncUnroll];
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-        const uint32_t i = lo + t * 64u + lane;
-        px_reg[t] = (i < n) ? load_px<CH>(pix, i) : 0u;
+    for (int u = 0; u < kEncUnroll; ++u) {
+        const uint32_t i = lo + u * 64u + lane;
+        cur[u] = (!LAST || i < n) ? load_px<CH>(pix, i) : 0u;
     }
-    u64 enc[K];             // bits 0..47: up to 6 chunk bytes in emission order; bits 56..58: length
-    uint32_t lane_bytes = 0;
+    uint32_t slab_pos = 0;                                 // bytes staged so far (wave-uniform)
+#pragma unroll 1
+    for (int t0 = 0; t0 < K; t0 += kEncUnroll) {
+        if (t0 + kEncUnroll < K) {                          // prefetch the next group's pixels
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-        const uint32_t base = lo + t * 64u;
-        const uint32_t i = base + lane;
-        const bool inb = i < n;
-        const uint32_t px = px_reg[t];
-        const uint32_t prev = from_lane_below(px, carry);
-        carry = read_lane(px, 63);
-        const bool edge = inb && px != prev;
-        const u64 E = __ballot(edge);
-
-        // last edge strictly before this pixel
-        const u64 eb = E & below;
-        const int le = eb ? (int)base + msb64(eb) : last_edge;
-        if (E) last_edge = (int)base + msb64(E);
-
-        // ---- colour-table probe (qoi.h:430-436) for edge pixels ------------------------
-        // Lanes of this step that share a slot: every edge lane ORs its bit into the slot's
-        // 64-bit LDS word; the word then lists all of them (order-independent).
-        const uint32_t so = slot_byte_offset(px);
-        volatile u64* mword = &s_mask[wave][so >> 2];
-        volatile uint32_t* tword = &s_table[wave][so >> 2];
-        if (edge) atomicOr((u64*)mword, lane_bit);
-        __builtin_amdgcn_wave_barrier();
-        u64 same = 0; uint32_t tval = 0;
-        if (edge) { same = *mword; tval = *tword; }
-        __builtin_amdgcn_wave_barrier();
-        if (edge) *mword = 0;
-        const u64 pred = same & below;
-        // table content seen by this pixel = nearest earlier edge lane with the same slot, else
-        // the table carried in from earlier steps/slabs
-        const uint32_t pv = gather_lane(px, pred ? (uint32_t)msb64(pred) : lane);
-        const uint32_t seen = pred ? pv : tval;
-        const bool hit = edge && seen == px;
-        // the last edge lane of each slot leaves its pixel in the table for later steps
-        if (edge && ((same >> lane) >> 1) == 0) *tword = px;
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- chunk bytes --------------------------------------------------------------
-        u64 bytes = 0; uint32_t len = 0;
-        if (edge) {
-            u64 lb; uint32_t ll;
-            literal_chunk(px, prev, lb, ll);
-            if (hit) { lb = kTagIndex | (so >> 2); ll = 1; }
-            const uint32_t pend = (uint32_t)((int)i - 1 - le) % 62u;       // repeats not yet flushed (qoi.h:425-428)
-            if (pend) { bytes = (lb << 8) | (kTagRun | (pend - 1u)); len = ll + 1u; }
-            else { bytes = lb; len = ll; }
-        } else if (inb) {
-            const uint32_t r = (uint32_t)((int)i - le);                    // repeats ending here
-            const uint32_t q = r % 62u;
-            if (q == 0u || i == n - 1u) {                                  // qoi.h:417
-                bytes = kTagRun | (q == 0u ? 61u : q - 1u); len = 1;
+            for (int u = 0; u < kEncUnroll; ++u) {
+                const uint32_t i = lo + (uint32_t)(t0 + kEncUnroll + u) * 64u + lane;
+                nxt[u] = (!LAST || i < n) ? load_px<CH>(pix, i) : 0u;
             }
         }
-        enc[t] = bytes | ((u64)len << 56);
-        lane_bytes += len;
+#pragma unroll
+        for (int u = 0; u < kEncUnroll; ++u) {
+            const uint32_t base = lo + (uint32_t)(t0 + u) * 64u;
+            const uint32_t i = base + lane;
+            const uint32_t px = cur[u];
+            const uint32_t prev = from_lane_below(px, carry);
+            carry = read_lane(px, 63);
+            const bool inb = !LAST || i < n;
+            const bool edge = LAST ? (inb && px != prev) : (px != prev);
+            const u64 E = __ballot(edge);
+
+            // d = distance to the last edge strictly before this pixel (>= 1)
+            const u64 eb = E & below;
+            const uint32_t d = eb ? lane - (uint32_t)msb64(eb) : lane + (uint32_t)((int)base - last_edge);
+            if (E) last_edge = (int)base + msb64(E);
+            const uint32_t x = d - (edge ? 1u : 0u);
+            uint32_t xm = x;
+            if (__ballot(x >= 62u)) {                     // wave-uniform: long runs are rare in busy content
+                xm = x % 62u;
+                asm volatile("" : "+v"(xm));              // keep this a real branch (the divide is quarter-rate)
+            }
+            // an edge flushes pending repeats (qoi.h:425-428); a repeat flushes at 62 or at the last pixel (qoi.h:417)
+            bool er = edge ? (xm != 0u) : (xm == 0u);
+            if (LAST) er = inb && (er || (!edge && i == n - 1u));
+            const uint32_t runb = xm ? 0xBFu + xm : 0xFDu;    // 0xC0|(xm-1); a repeat landing on xm == 0 closes a run of 62
+
+            // ---- colour-table probe/update (qoi.h:430-436) for edge pixels -----------------
+            const uint32_t so = slot_byte_offset(px);
+            uint32_t seen = ~px;
+            if (!(ABL & 4)) {
+                if (PROBE == 1) {
+                    if (edge) seen = __hip_atomic_exchange(reinterpret_cast<uint32_t*>(table8 + so), px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                } else {
+                    if (edge) __hip_atomic_fetch_or(&L.mask[so >> 2], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __builtin_amdgcn_wave_barrier();
+                    const u64 same = edge ? L.mask[so >> 2] : 0ull;    // edge lanes of this step sharing the slot
+                    const uint32_t tval = L.table[so >> 2];
+                    __builtin_amdgcn_wave_barrier();
+                    if (edge) L.mask[so >> 2] = 0;
+                    const u64 pred = same & below;
+                    const uint32_t pv = gather_lane(px, pred ? (uint32_t)msb64(pred) : lane);
+                    seen = pred ? pv : tval;                           // nearest earlier same-slot edge, else carried table
+                    if (edge && ((same >> lane) >> 1) == 0) L.table[so >> 2] = px;   // last lane per slot updates the table
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            const bool hit = edge && seen == px;
+
+            // ---- classes (qoi.h:432-474 priority: INDEX, then RGBA if alpha moved, DIFF, LUMA, RGB) ----
+            const int dr = (int)(int8_t)((px & 0xFF) - (prev & 0xFF));
+            const int dg = (int)(int8_t)(((px >> 8) & 0xFF) - ((prev >> 8) & 0xFF));
+            const int db = (int)(int8_t)(((px >> 16) & 0xFF) - ((prev >> 16) & 0xFF));
+            const int drg = (int)(int8_t)(dr - dg);
+            const int dbg = (int)(int8_t)(db - dg);
+            const bool lit = edge && !hit;
+            const bool c_rgba = lit && ((px ^ prev) >> 24) != 0;
+            const bool t_diff = ((unsigned)(dr + 2) | (unsigned)(dg + 2) | (unsigned)(db + 2)) < 4u;
+            const bool t_luma = (((unsigned)(dg + 32) >> 2) | (unsigned)(drg + 8) | (unsigned)(dbg + 8)) < 16u;
+            const bool c_diff = lit && !c_rgba && t_diff;
+            const bool c_luma = lit && !c_rgba && !t_diff && t_luma;
+            const bool c_rgb = lit && !c_rgba && !t_diff && !t_luma;
+            const bool c_one = hit || c_diff;             // 1-byte chunks
+            // length = ll + er with ll in {1 (c_one), 2 (c_luma), 4 (c_rgb), 5 (c_rgba)}: bit algebra on lane masks
+            const bool odd = c_one || c_rgba;
+            const bool l0 = odd != er, l1 = c_luma || (odd && er), l2 = c_rgb || c_rgba;
+            const u64 b0 = __ballot(l0), b1 = __ballot(l1), b2 = __ballot(l2);
+
+            if (!(ABL & 1)) {
+                // first byte / second byte of the literal chunk
+                const uint32_t diff_b = kTagDiff | ((dr + 2) << 4) | ((dg + 2) << 2) | (db + 2);
+                const uint32_t luma_b = (kTagLuma | (dg + 32)) | ((((drg + 8) << 4) | (dbg + 8)) << 8);
+                uint32_t w = (px << 8) | (c_rgba ? kTagRgba : kTagRgb);   // tag r g b   (a follows for RGBA)
+                w = c_luma ? luma_b : w;
+                w = c_diff ? diff_b : w;
+                w = hit ? (so >> 2) : w;
+                const uint32_t off = slab_pos + count_below(b0) + 2u * count_below(b1) + 4u * count_below(b2);
+                uint8_t* dst = stage8 + off;
+                if (er) dst[0] = (uint8_t)runb;
+                dst += er ? 1 : 0;
+                if (edge) dst[0] = (uint8_t)w;
+                if (__ballot(c_luma || l2)) {             // some lane has a multi-byte literal
+                    if (c_luma || l2) dst[1] = (uint8_t)(w >> 8);
+                    if (b2) {
+                        if (l2) { dst[2] = (uint8_t)(w >> 16); dst[3] = (uint8_t)(w >> 24); }
+                        if (c_rgba) dst[4] = (uint8_t)(px >> 24);
+                    }
+                }
+            }
+            slab_pos += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) + 4u * (uint32_t)__builtin_popcountll(b2);
+        }
+#pragma unroll
+        for (int u = 0; u < kEncUnroll; ++u) cur[u] = nxt[u];
     }
 
-    // ---- slab byte count and its offset: decoupled look-back over earlier slabs ---------
-    const uint32_t slab_bytes = wave_sum(lane_bytes);
+    // ---- slab byte count -> offset: decoupled look-back over earlier slabs -----------------
+    const uint32_t slab_bytes = slab_pos;
     u64 excl = 0;
-    {
+    if (!(ABL & 2)) {
         constexpr u64 kAgg = 1ull << 62, kIncl = 2ull << 62, kVal = (1ull << 62) - 1ull;
         u64* st = p.status;
         if (s == 0) {
@@ -294,44 +350,103 @@ __global__ __launch_bounds__(256) void enc_slabs(EncParams p) {
         }
     }
 
-    // ---- pass 2: emit -------------------------------------------------------------------
+    // ---- copy the staged bytes out ---------------------------------------------------------
     uint8_t* __restrict__ out = p.out + (size_t)img * p.out_stride;
     if (s == 0 && lane < (uint32_t)kHeaderBytes) {        // 14-byte header (qoi.h:384-388)
         const uint32_t w = p.width, h = p.height;
-        uint8_t b;
-        switch (lane) {
-            case 0: b = 'q'; break; case 1: b = 'o'; break; case 2: b = 'i'; break; case 3: b = 'f'; break;
-            case 4: b = w >> 24; break; case 5: b = w >> 16; break; case 6: b = w >> 8; break; case 7: b = w; break;
-            case 8: b = h >> 24; break; case 9: b = h >> 16; break; case 10: b = h >> 8; break; case 11: b = h; break;
-            case 12: b = p.channels; break; default: b = p.colorspace; break;
+        const u64 hdr_lo = 0x66696F71ull | ((u64)__builtin_bswap32(w) << 32);             // "qoif", width BE
+        const u64 hdr_hi = (u64)__builtin_bswap32(h) | ((u64)p.channels << 32) | ((u64)p.colorspace << 40);
+        out[lane] = (uint8_t)((lane < 8u ? hdr_lo : hdr_hi) >> (8u * (lane & 7u)));
+    }
+    const u64 pos = (u64)kHeaderBytes + excl;
+    if (!(ABL & 1) && slab_bytes) {
+        __builtin_amdgcn_wave_barrier();
+        uint8_t* dst = out + pos;
+        const uint32_t mis = (uint32_t)(uintptr_t)dst & 3u;
+        const uint32_t head = min(slab_bytes, (4u - mis) & 3u);           // bytes up to the first aligned dword
+        if (lane < head) dst[lane] = stage8[lane];
+        const uint32_t ndw = (slab_bytes - head) >> 2;
+        uint32_t* dst32 = reinterpret_cast<uint32_t*>(dst + head);
+        for (uint32_t j = lane; j < ndw; j += 64u) {                      // staged bytes sit `head` past a dword boundary
+            const uint32_t w0 = L.stage[j], w1 = L.stage[j + 1u];
+            dst32[j] = __builtin_amdgcn_alignbyte(w1, w0, head);
         }
-        out[lane] = b;
+        const uint32_t done_b = head + (ndw << 2);
+        if (lane < slab_bytes - done_b) dst[done_b + lane] = stage8[done_b + lane];
     }
-    u64 pos = (u64)kHeaderBytes + excl;
-#pragma unroll
-    for (int t = 0; t < K; ++t) {
-        const u64 e = enc[t];
-        const uint32_t len = (uint32_t)(e >> 56);
-        const u64 b0 = __ballot(len & 1u), b1 = __ballot(len & 2u), b2 = __ballot(len & 4u);
-        const uint32_t off = count_below(b0) + 2u * count_below(b1) + 4u * count_below(b2);
-        uint8_t* dst = out + pos + off;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if (__ballot(len > (uint32_t)k) == 0) break;
-            if (len > (uint32_t)k) dst[k] = (uint8_t)(e >> (8 * k));
+    if (LAST) {                                           // trailer (qoi.h:339,480-482) + *out_len
+        const u64 end = pos + slab_bytes;
+        if (lane < (uint32_t)kTrailerBytes) out[end + lane] = (lane == 7u) ? 1 : 0;
+        if (lane == 0) p.out_len[img] = (int)(end + kTrailerBytes);
+    }
+}
+
+template <int CH, int K, int PROBE, int ABL>
+__global__ __launch_bounds__(256) void enc_slabs(EncParams p) {
+    __shared__ EncLds<K> s_lds[4];
+    __shared__ uint32_t s_ticket;
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    // Slab ids are handed out in START order so that every predecessor a look-back can
+    // wait on is already running or finished (no reliance on dispatch order; guide G16).
+    if (p.use_ticket) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(p.ticket, 1u);
+        __syncthreads();
+    }
+    const uint32_t wg = p.use_ticket ? s_ticket : blockIdx.x;
+    const uint32_t total = p.n_images * p.spi;
+    const uint32_t g = wg * 4u + wave;
+    if (g >= total) return;
+    if ((g % p.spi) == p.spi - 1u) encode_one_slab<CH, K, PROBE, true, ABL>(p, g, lane, s_lds[wave]);
+    else encode_one_slab<CH, K, PROBE, false, ABL>(p, g, lane, s_lds[wave]);
+}
+
+// Measures whether one ds_wrxchg_rtn_b32 serves same-address lanes in ascending lane order
+// (see PROBE above).  out[0] = number of mismatching patterns (0: PROBE 1 is usable).
+__global__ __launch_bounds__(64) void lds_order_selftest(uint32_t* out) {
+    __shared__ uint32_t tab[64];
+    const uint32_t lane = lane_id();
+    uint32_t bad = 0;
+    uint32_t rng = 0x9E3779B9u * (blockIdx.x + 1u) + lane * 0x85EBCA6Bu;
+    for (int it = 0; it < 256; ++it) {
+        rng = rng * 1664525u + 1013904223u;
+        const uint32_t nb = 1u << ((it % 7));                          // 1..64 distinct slots
+        const uint32_t slot = ((rng >> 16) % nb) * (64u / nb);
+        const bool on = ((rng >> 8) & 7u) != 0u || nb == 1u;
+        tab[lane] = 0xFFFF0000u | lane;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t val = (uint32_t)it * 64u + lane;
+        uint32_t old = 0;
+        if (on) old = __hip_atomic_exchange(&tab[slot], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_wave_barrier();
+        // model: nearest lower active lane with the same slot, else the initial content
+        const u64 act = __ballot(on);
+        u64 same = 0;
+        for (uint32_t l = 0; l < 64u; ++l) {
+            const uint32_t sl = read_lane_dyn(slot, l);
+            if (sl == slot && ((act >> l) & 1ull)) same |= 1ull << l;
         }
-        pos += (u64)__builtin_popcountll(b0) + 2u * (u64)__builtin_popcountll(b1) + 4u * (u64)__builtin_popcountll(b2);
+        const u64 pred = same & ((1ull << lane) - 1ull);
+        const uint32_t want = pred ? (uint32_t)it * 64u + (uint32_t)msb64(pred) : (0xFFFF0000u | slot);
+        if (on && old != want) ++bad;
+        // final content: highest active lane per slot
+        const uint32_t fin = tab[lane];
+        u64 mine = 0;
+        for (uint32_t l = 0; l < 64u; ++l) {
+            const uint32_t sl = read_lane_dyn(slot, l);
+            if (sl == lane && ((act >> l) & 1ull)) mine |= 1ull << l;
+        }
+        const uint32_t wantf = mine ? (uint32_t)it * 64u + (uint32_t)msb64(mine) : (0xFFFF0000u | lane);
+        if (fin != wantf) ++bad;
+        __builtin_amdgcn_wave_barrier();
     }
-    if (s == p.spi - 1u) {                                // trailer (qoi.h:339,480-482) + *out_len
-        if (lane < (uint32_t)kTrailerBytes) out[pos + lane] = (lane == 7u) ? 1 : 0;
-        if (lane == 0) p.out_len[img] = (int)(pos + kTrailerBytes);
-    }
+    bad = wave_sum(bad);
+    if (lane == 0 && bad) atomicAdd(out, bad);
 }
 
 // ---------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------
-template <int CH, int K>
+template <int CH, int K, int PROBE, int ABL>
 static void launch_encode_t(const EncParams& p, hipStream_t st, KernelTimer* tm) {
     const uint32_t total = p.n_images * p.spi;
     const uint32_t blocks = (total + 3u) / 4u;
@@ -342,13 +457,36 @@ static void launch_encode_t(const EncParams& p, hipStream_t st, KernelTimer* tm)
     tm->mark(kT_enc_scan_groups, st);
     hipLaunchKernelGGL(enc_scan_images, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_images, st);
-    hipLaunchKernelGGL((enc_slabs<CH, K>), dim3(blocks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL>), dim3(blocks), dim3(256), 0, st, p);
     tm->mark(kT_enc_slabs, st);
 }
 
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm) {
-    if (p.channels == 4) launch_encode_t<4, kEncSteps>(p, st, tm);
-    else launch_encode_t<3, kEncSteps>(p, st, tm);
+    const int abl = p.ablate;
+    if (p.channels == 3) {
+        if (p.probe_xchg) launch_encode_t<3, kEncSteps, 1, 0>(p, st, tm); else launch_encode_t<3, kEncSteps, 0, 0>(p, st, tm);
+        return;
+    }
+    if (!p.probe_xchg) { launch_encode_t<4, kEncSteps, 0, 0>(p, st, tm); return; }
+    switch (abl) {   // ablation variants exist for profiling only (QOIMI_ENC_ABLATE); outputs are then invalid
+        case 1: launch_encode_t<4, kEncSteps, 1, 1>(p, st, tm); break;
+        case 2: launch_encode_t<4, kEncSteps, 1, 2>(p, st, tm); break;
+        case 4: launch_encode_t<4, kEncSteps, 1, 4>(p, st, tm); break;
+        case 7: launch_encode_t<4, kEncSteps, 1, 7>(p, st, tm); break;
+        default: launch_encode_t<4, kEncSteps, 1, 0>(p, st, tm); break;
+    }
+}
+
+// returns the number of mismatching patterns of the LDS exchange-order self-test (0 = ordered)
+int run_lds_order_selftest(hipStream_t st) {
+    uint32_t* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(uint32_t)) != hipSuccess) return -1;
+    (void)hipMemsetAsync(d, 0, sizeof(uint32_t), st);
+    hipLaunchKernelGGL(lds_order_selftest, dim3(512), dim3(64), 0, st, d);
+    uint32_t h = 1;
+    if (hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) h = 0xFFFFFFFFu;
+    (void)hipFree(d);
+    return (int)h;
 }
 
 }  // namespace qoimi

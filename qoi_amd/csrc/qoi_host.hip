@@ -74,6 +74,8 @@ struct qoimi_ctx {
     long long dec_stats[4] = {0, 0, 0, 0};
     uint32_t seg_bytes = 2048;  // decode segment size
     uint32_t* last_enc_err = nullptr;   // device flag of the most recent encode launch
+    bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
+    int enc_ablate = 0, enc_ticket = 1, enc_quads = 0;   // tuning / profiling knobs (env QOIMI_ENC_*)
     KernelTimer timer;                  // optional per-kernel HIP-event timing
     double prof_ms[kT_count] = {0};     // accumulated kernel milliseconds since profiling was (re)enabled
     long long prof_calls[kT_count] = {0};
@@ -105,6 +107,12 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     qoimi_ctx* c = new qoimi_ctx();
     c->device = device;
     if (hipHostMalloc((void**)&c->host_word, 64) != hipSuccess) { delete c; return fail(QOIMI_E_NOMEM, "hipHostMalloc failed"); }
+    // Measure (do not assume) the LDS conflict order the fast colour-table probe relies on.
+    c->xchg_ordered = run_lds_order_selftest(0) == 0;
+    if (const char* e = getenv("QOIMI_ENC_PROBE")) { if (atoi(e) == 0) c->xchg_ordered = false; }
+    if (const char* e = getenv("QOIMI_ENC_ABLATE")) c->enc_ablate = atoi(e);
+    if (const char* e = getenv("QOIMI_ENC_TICKET")) c->enc_ticket = atoi(e);
+    if (const char* e = getenv("QOIMI_ENC_QUADS")) c->enc_quads = atoi(e);
     if (const char* e = getenv("QOIMI_SEG_BYTES")) {
         long v = atol(e);
         if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v;
@@ -190,7 +198,11 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.spi = (uint32_t)((npx + kEncSlabPx - 1) / kEncSlabPx);
     p.gpi = (p.spi + 63u) / 64u;
     p.width = desc->width; p.height = desc->height; p.channels = desc->channels; p.colorspace = desc->colorspace;
+    p.probe_xchg = c->xchg_ordered ? 1 : 0;
+    p.use_ticket = c->enc_ticket ? 1 : 0;
+    p.ablate = (uint8_t)c->enc_ablate;
     const size_t T = (size_t)p.n_images * p.spi, G = (size_t)p.n_images * p.gpi;
+    p.quads_per_wg = c->enc_quads > 0 ? (uint32_t)c->enc_quads : (T > 32768 ? 4u : 1u);
     if (T > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (slab index overflows 32 bits)");
 
     for (int pass = 0; pass < 2; ++pass) {      // pass 0 measures, pass 1 carves

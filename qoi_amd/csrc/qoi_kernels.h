@@ -38,7 +38,11 @@ struct EncParams {
     uint32_t gpi;            // 64-slab groups per image
     uint32_t width, height;
     uint8_t channels, colorspace;
-    // workspace (see enc_workspace_bytes)
+    uint8_t probe_xchg;      // 1: ds_wrxchg colour-table probe (needs the LDS order self-test to have passed)
+    uint8_t use_ticket;      // 1: slab ids by atomic ticket (start order); 0: by blockIdx
+    uint8_t ablate;          // profiling only
+    uint32_t quads_per_wg;   // consecutive 4-slab groups one workgroup walks through
+    // workspace
     uint32_t* sum_tab;   u64* sum_valid;  int* sum_le;     // E1 out        [n_images*spi]
     uint32_t* ent_tab;   u64* ent_valid;  int* ent_le;     // E2a out       [n_images*spi]
     uint32_t* grp_tab;   u64* grp_valid;  int* grp_le;     // E2a aggregate [n_images*gpi]
@@ -51,6 +55,7 @@ struct EncParams {
 };
 
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm);
+int run_lds_order_selftest(hipStream_t st);
 
 // ---- decode ------------------------------------------------------------------------
 struct ParseRec; struct SlotRec;
