@@ -63,6 +63,42 @@ QOIMI_HD uint32_t luma_delta(uint32_t b1, uint32_t b2) {
     return dr | (dg << 8) | (db << 16);
 }
 
+// One unaligned 8-byte load covers the longest chunk (5 bytes).  Streams handed to the
+// decoder must be readable 8 bytes past their last chunk byte (true for every stream that
+// carries its 8-byte end marker, qoi.h:103, plus the padding the C-ABI documents).
+QOIMI_HD unsigned long long load8(const uint8_t* p) {
+    unsigned long long w;
+    __builtin_memcpy(&w, p, 8);
+    return w;
+}
+
+// Fields of the chunk whose first byte is the low byte of w - all cases computed, the
+// callers select.  No data-dependent branches: a wavefront's lanes sit on different ops.
+struct Chunk {
+    uint32_t b1;          // tag byte
+    uint32_t rgba;        // bytes 1..4 as r,g,b,a
+    uint32_t delta;       // packed (dr,dg,db,0) if DIFF/LUMA, else 0
+    uint32_t len;         // chunk length in bytes
+    bool is_rgb, is_rgba, is_index, is_rel, is_run;   // is_rel: DIFF or LUMA
+};
+QOIMI_HD Chunk crack(unsigned long long w) {
+    Chunk c;
+    c.b1 = (uint32_t)w & 0xFFu;
+    c.rgba = (uint32_t)(w >> 8);
+    const uint32_t b2 = (uint32_t)(w >> 8) & 0xFFu;
+    const uint32_t top = c.b1 >> 6;
+    c.is_rgb = c.b1 == 0xFEu;
+    c.is_rgba = c.b1 == 0xFFu;
+    c.is_index = top == 0u;
+    const bool is_diff = top == 1u, is_luma = top == 2u;
+    c.is_rel = is_diff || is_luma;
+    c.is_run = top == 3u && c.b1 < 0xFEu;
+    const uint32_t dd = diff_delta(c.b1), dl = luma_delta(c.b1, b2);
+    c.delta = is_diff ? dd : (is_luma ? dl : 0u);
+    c.len = c.is_rgb ? 4u : (c.is_rgba ? 5u : (is_luma ? 2u : 1u));
+    return c;
+}
+
 // =====================================================================================
 // P1 — parse summary of one segment for the five entry phases
 // =====================================================================================
@@ -110,27 +146,19 @@ QOIMI_HD uint32_t lin_hash(uint32_t rgb) {   // 3r+5g+7b of packed bytes (alpha 
 QOIMI_HD void slot_walk_segment(const uint8_t* in, uint32_t pos, uint32_t seg_end, SlotRec& r) {
     uint32_t hc = 0, h_rel = 1, h_alpha = 0, a_abs = 0, ac = 0;
     while (pos < seg_end) {
-        const uint32_t b = in[pos];
-        if (b == 0xFEu) {
-            const uint32_t rgb = in[pos + 1] | (in[pos + 2] << 8) | (in[pos + 3] << 16);
-            hc = lin_hash(rgb); h_rel = 0;
-            if (a_abs) { hc += 11u * ac; h_alpha = 0; } else { h_alpha = 1; }
-            pos += 4;
-        } else if (b == 0xFFu) {
-            const uint32_t rgb = in[pos + 1] | (in[pos + 2] << 8) | (in[pos + 3] << 16);
-            ac = in[pos + 4]; a_abs = 1;
-            hc = lin_hash(rgb) + 11u * ac; h_rel = 0; h_alpha = 0;
-            pos += 5;
-        } else if ((b & 0xC0u) == 0x00u) {
-            hc = b; h_rel = 0; h_alpha = 0; pos += 1;
-        } else if ((b & 0xC0u) == 0x40u) {
-            hc += lin_hash(diff_delta(b)); pos += 1;
-        } else if ((b & 0xC0u) == 0x80u) {
-            hc += lin_hash(luma_delta(b, in[pos + 1])); pos += 2;
-        } else {
-            pos += 1;
-        }
+        const Chunk c = crack(load8(in + pos));
+        const uint32_t lrgb = lin_hash(c.rgba);                    // 3r+5g+7b of the payload
+        // RGB: slot = lin(rgb) + 11*alpha (alpha absolute if an RGBA was seen, else the entry alpha)
+        const uint32_t hc_rgb = lrgb + (a_abs ? 11u * ac : 0u);
+        const uint32_t hc_rgba = lrgb + 11u * (c.rgba >> 24);
+        const bool abs_op = c.is_rgb || c.is_rgba || c.is_index;
+        hc = c.is_rgb ? hc_rgb : (c.is_rgba ? hc_rgba : (c.is_index ? c.b1 : hc + lin_hash(c.delta)));
+        h_alpha = c.is_rgb ? (a_abs ? 0u : 1u) : ((c.is_rgba || c.is_index) ? 0u : h_alpha);
+        h_rel = abs_op ? 0u : h_rel;
+        ac = c.is_rgba ? (c.rgba >> 24) : ac;
+        a_abs = c.is_rgba ? 1u : a_abs;
         hc &= 63u;
+        pos += c.len;
     }
     r.hc = (uint8_t)hc; r.h_rel = (uint8_t)h_rel; r.h_alpha = (uint8_t)h_alpha; r.a_abs = (uint8_t)a_abs; r.ac = (uint8_t)ac;
 }
@@ -170,40 +198,27 @@ template <class Tab>
 QOIMI_HD sym_t summarize_segment(const uint8_t* in, uint32_t pos, uint32_t seg_end,
                                  uint32_t slot, uint32_t alpha, Tab& tab) {
     for (uint32_t k = 0; k < 64; ++k) tab.set(k, sym_make(0u, k, 0u));
-    sym_t px = sym_make(0u, 64u, 0u);
+    uint32_t pc = 0u;               // per-channel constants of the running pixel
+    uint32_t ph = 64u;              // its source (bits 0..6) and absolute mask (bits 8..11)
     while (pos < seg_end) {
-        const uint32_t b = in[pos];
-        if (b == 0xFEu) {
-            const uint32_t rgb = in[pos + 1] | (in[pos + 2] << 8) | (in[pos + 3] << 16);
-            px = sym_make((sym_c(px) & 0xFF000000u) | rgb, sym_src(px), sym_abs(px) | 7u);
-            slot = (lin_hash(rgb) + 11u * alpha) & 63u;
-            pos += 4;
-        } else if (b == 0xFFu) {
-            const uint32_t v = in[pos + 1] | (in[pos + 2] << 8) | (in[pos + 3] << 16) | ((uint32_t)in[pos + 4] << 24);
-            px = sym_make(v, 0u, 15u);
-            alpha = v >> 24;
-            slot = hash_px(v);
-            pos += 5;
-        } else if ((b & 0xC0u) == 0x00u) {
-            px = tab.get(b);
-            slot = b;
-            pos += 1;
-        } else if ((b & 0xC0u) == 0x40u) {
-            const uint32_t d = diff_delta(b);
-            px = (px & ~(sym_t)0xFFFFFFFFull) | add_bytes(sym_c(px), d);
-            slot = (slot + lin_hash(d)) & 63u;
-            pos += 1;
-        } else if ((b & 0xC0u) == 0x80u) {
-            const uint32_t d = luma_delta(b, in[pos + 1]);
-            px = (px & ~(sym_t)0xFFFFFFFFull) | add_bytes(sym_c(px), d);
-            slot = (slot + lin_hash(d)) & 63u;
-            pos += 2;
-        } else {
-            pos += 1;                                    // RUN: pixel unchanged
-        }
-        tab.set(slot, px);                               // index update after every chunk (qoi.h:577)
+        const Chunk c = crack(load8(in + pos));
+        const sym_t t = tab.get(c.b1 & 63u);                         // read unconditionally, used if INDEX
+        const uint32_t rgb = c.rgba & 0x00FFFFFFu;
+        // constants
+        const uint32_t pc_rel = add_bytes(pc, c.delta);              // DIFF/LUMA/RUN (delta 0)
+        pc = c.is_rgba ? c.rgba : (c.is_rgb ? ((pc & 0xFF000000u) | rgb) : (c.is_index ? (uint32_t)t : pc_rel));
+        // source / absolute mask
+        ph = c.is_rgba ? (15u << 8) : (c.is_rgb ? (ph | (7u << 8)) : (c.is_index ? (uint32_t)(t >> 32) : ph));
+        // speculated slot / alpha of the new pixel
+        const uint32_t s_rgb = lin_hash(rgb) + 11u * alpha;
+        const uint32_t s_rgba = lin_hash(rgb) + 11u * (c.rgba >> 24);
+        slot = c.is_rgb ? s_rgb : (c.is_rgba ? s_rgba : (c.is_index ? c.b1 : slot + lin_hash(c.delta)));
+        slot &= 63u;
+        alpha = c.is_rgba ? (c.rgba >> 24) : alpha;
+        tab.set(slot, (sym_t)pc | ((sym_t)ph << 32));                // index update after every chunk (qoi.h:577)
+        pos += c.len;
     }
-    return px;
+    return (sym_t)pc | ((sym_t)ph << 32);
 }
 
 // =====================================================================================
@@ -216,27 +231,12 @@ QOIMI_HD uint32_t decode_segment(const uint8_t* in, uint32_t pos, uint32_t seg_e
                                  uint32_t px, Tab32& tab, uint8_t* out,
                                  uint32_t px_pos, uint32_t px_limit) {
     while (pos < seg_end && px_pos < px_limit) {
-        const uint32_t b = in[pos];
-        uint32_t n = 1;
-        if (b == 0xFEu) {
-            px = (px & 0xFF000000u) | in[pos + 1] | (in[pos + 2] << 8) | (in[pos + 3] << 16);
-            pos += 4;
-        } else if (b == 0xFFu) {
-            px = in[pos + 1] | (in[pos + 2] << 8) | (in[pos + 3] << 16) | ((uint32_t)in[pos + 4] << 24);
-            pos += 5;
-        } else if ((b & 0xC0u) == 0x00u) {
-            px = tab.get(b);
-            pos += 1;
-        } else if ((b & 0xC0u) == 0x40u) {
-            px = add_bytes(px, diff_delta(b));
-            pos += 1;
-        } else if ((b & 0xC0u) == 0x80u) {
-            px = add_bytes(px, luma_delta(b, in[pos + 1]));
-            pos += 2;
-        } else {
-            n = (b & 0x3Fu) + 1u;
-            pos += 1;
-        }
+        const Chunk c = crack(load8(in + pos));
+        const uint32_t t = tab.get(c.b1 & 63u);                      // read unconditionally, used if INDEX
+        const uint32_t rel = add_bytes(px, c.delta);
+        px = c.is_rgba ? c.rgba : (c.is_rgb ? ((px & 0xFF000000u) | (c.rgba & 0x00FFFFFFu)) : (c.is_index ? t : rel));
+        const uint32_t n = c.is_run ? (c.b1 & 0x3Fu) + 1u : 1u;
+        pos += c.len;
         tab.set(hash_px(px), px);
         uint32_t stop = px_pos + n;
         if (stop > px_limit) stop = px_limit;            // over-long run clipped (Appendix B item 8)

@@ -174,9 +174,11 @@ __device__ __forceinline__ void literal_chunk(uint32_t px, uint32_t prev, u64& b
 template <int K>
 struct EncLds {
     static constexpr uint32_t kStageBytes = 64u * K * 5u + 8u;     // <= 5 B/px + one flushed run byte, + slack
+    static constexpr uint32_t kStageDwords = ((kStageBytes + 15u) / 16u) * 4u;
+    alignas(16) uint32_t stage[kStageDwords];
     uint32_t table[64];
+    uint32_t dummy[64];          // exchange target of lanes that must not touch the table (PROBE 1); must follow table
     u64 mask[64];
-    uint32_t stage[(kStageBytes + 3u) / 4u];
 };
 
 constexpr int kEncUnroll = 8;     // steps per unrolled group (pixels of the next group are prefetched)
@@ -252,7 +254,10 @@ __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, 
             uint32_t seen = ~px;
             if (!(ABL & 4)) {
                 if (PROBE == 1) {
-                    if (edge) seen = __hip_atomic_exchange(reinterpret_cast<uint32_t*>(table8 + so), px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    // every lane exchanges (no exec-masked block -> the scheduler can overlap the LDS round trip
+                    // with the delta arithmetic below); repeats hit a private dummy word instead of the table
+                    const uint32_t addr = edge ? so : 256u + 4u * lane;
+                    seen = __hip_atomic_exchange(reinterpret_cast<uint32_t*>(table8 + addr), px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 } else {
                     if (edge) __hip_atomic_fetch_or(&L.mask[so >> 2], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     __builtin_amdgcn_wave_barrier();
@@ -315,8 +320,19 @@ __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, 
         for (int u = 0; u < kEncUnroll; ++u) cur[u] = nxt[u];
     }
 
-    // ---- slab byte count -> offset: decoupled look-back over earlier slabs -----------------
     const uint32_t slab_bytes = slab_pos;
+    if (p.scratch) {
+        // ---- order-free mode: park the slab's bytes in its scratch slot, E4 compacts ------------
+        if (lane == 0) p.slab_size[g] = slab_bytes;
+        __builtin_amdgcn_wave_barrier();
+        uint4* dst = reinterpret_cast<uint4*>(p.scratch + (size_t)g * kEncScratchStride);
+        const uint4* src = reinterpret_cast<const uint4*>(L.stage);
+        const uint32_t n16 = (slab_bytes + 15u) >> 4;
+        for (uint32_t j = lane; j < n16; j += 64u) dst[j] = src[j];
+        return;
+    }
+
+    // ---- slab byte count -> offset: decoupled look-back over earlier slabs -----------------
     u64 excl = 0;
     if (!(ABL & 2)) {
         constexpr u64 kAgg = 1ull << 62, kIncl = 2ull << 62, kVal = (1ull << 62) - 1ull;
@@ -386,18 +402,95 @@ __global__ __launch_bounds__(256) void enc_slabs(EncParams p) {
     __shared__ EncLds<K> s_lds[4];
     __shared__ uint32_t s_ticket;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    // Slab ids are handed out in START order so that every predecessor a look-back can
-    // wait on is already running or finished (no reliance on dispatch order; guide G16).
-    if (p.use_ticket) {
-        if (threadIdx.x == 0) s_ticket = atomicAdd(p.ticket, 1u);
+    // A workgroup serves image (blockIdx % n_images): the slabs in flight spread over all images, so
+    // every per-image look-back chain has few unfinished predecessors.  Within its image the
+    // workgroup takes the next `quads_per_wg` groups of 4 slabs from the image's ticket counter:
+    // slab ids are handed out in START order, hence every predecessor a look-back can wait on
+    // is already running or finished (no reliance on dispatch order; guide G16).  One counter
+    // per image keeps the atomics off a single hot word.
+    const uint32_t img = blockIdx.x % p.n_images;
+    uint32_t quad = blockIdx.x / p.n_images;              // order-free (scratch) mode: any order will do
+    if (p.use_ticket && !p.scratch) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(&p.ticket[img], 1u);
+        __syncthreads();
+        quad = s_ticket;
+    }
+    const uint32_t first_quad = quad * p.quads_per_wg;
+#pragma unroll 1
+    for (uint32_t r = 0; r < p.quads_per_wg; ++r) {
+        const uint32_t s_pos = (first_quad + r) * 4u + wave;
+        if (s_pos >= p.spi) return;
+        const uint32_t g = img * p.spi + s_pos;
+        if (s_pos == p.spi - 1u) encode_one_slab<CH, K, PROBE, true, ABL>(p, g, lane, s_lds[wave]);
+        else encode_one_slab<CH, K, PROBE, false, ABL>(p, g, lane, s_lds[wave]);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// E4a: exclusive scan of the slab byte counts of one image (one workgroup per image);
+// also writes the 14-byte header (qoi.h:384-388), the 8-byte end marker (qoi.h:339,480-482)
+// and *out_len (qoi.h:484).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_offsets(EncParams p) {
+    __shared__ uint32_t s_part[256];
+    const uint32_t img = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* __restrict__ sz = p.slab_size + (size_t)img * p.spi;
+    uint32_t* __restrict__ off = p.slab_off + (size_t)img * p.spi;
+    const uint32_t per = (p.spi + 255u) / 256u;
+    const uint32_t lo = tid * per, hi = min(p.spi, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += sz[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256u; d <<= 1) {           // Hillis-Steele inclusive scan of the partials
+        const uint32_t v = tid >= d ? s_part[tid - d] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
         __syncthreads();
     }
-    const uint32_t wg = p.use_ticket ? s_ticket : blockIdx.x;
-    const uint32_t total = p.n_images * p.spi;
-    const uint32_t g = wg * 4u + wave;
-    if (g >= total) return;
-    if ((g % p.spi) == p.spi - 1u) encode_one_slab<CH, K, PROBE, true, ABL>(p, g, lane, s_lds[wave]);
-    else encode_one_slab<CH, K, PROBE, false, ABL>(p, g, lane, s_lds[wave]);
+    uint32_t run = tid ? s_part[tid - 1] : 0u;
+    for (uint32_t i = lo; i < hi; ++i) { off[i] = run; run += sz[i]; }
+    uint8_t* out = p.out + (size_t)img * p.out_stride;
+    const uint32_t total = s_part[255];
+    if (tid < (uint32_t)kHeaderBytes) {
+        const uint32_t w = p.width, h = p.height;
+        const u64 hdr_lo = 0x66696F71ull | ((u64)__builtin_bswap32(w) << 32);             // "qoif", width BE
+        const u64 hdr_hi = (u64)__builtin_bswap32(h) | ((u64)p.channels << 32) | ((u64)p.colorspace << 40);
+        out[tid] = (uint8_t)((tid < 8u ? hdr_lo : hdr_hi) >> (8u * (tid & 7u)));
+    }
+    if (tid < (uint32_t)kTrailerBytes) out[(size_t)kHeaderBytes + total + tid] = (tid == 7u) ? 1 : 0;
+    if (tid == 0) p.out_len[img] = (int)(kHeaderBytes + total + kTrailerBytes);
+}
+
+// E4b: move every slab's bytes from its scratch slot to its place in the stream
+// (one wavefront per slab; aligned 16-byte stores, source re-aligned with v_alignbyte).
+__global__ __launch_bounds__(256) void enc_compact(EncParams p) {
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t g = blockIdx.x * 4u + wave;
+    if (g >= p.n_images * p.spi) return;
+    const uint32_t img = g / p.spi;
+    const uint32_t n = p.slab_size[g];
+    if (n == 0) return;
+    const uint8_t* __restrict__ src = p.scratch + (size_t)g * kEncScratchStride;      // 16-byte aligned
+    uint8_t* __restrict__ dst = p.out + (size_t)img * p.out_stride + kHeaderBytes + p.slab_off[g];
+    const uint32_t mis = (uint32_t)(uintptr_t)dst & 15u;
+    const uint32_t head = min(n, (16u - mis) & 15u);                 // bytes before dst becomes 16-byte aligned
+    if (lane < head) dst[lane] = src[lane];
+    const uint32_t n16 = (n - head) >> 4;
+    uint4* __restrict__ d16 = reinterpret_cast<uint4*>(dst + head);
+    const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(src) + (head >> 2);
+    const uint32_t sh = head & 3u;
+    for (uint32_t j = lane; j < n16; j += 64u) {
+        const uint32_t* q = s32 + 4u * j;
+        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+        uint4 v;
+        v.x = __builtin_amdgcn_alignbyte(w1, w0, sh); v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        v.z = __builtin_amdgcn_alignbyte(w3, w2, sh); v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+        d16[j] = v;
+    }
+    const uint32_t done = head + (n16 << 4);
+    if (lane < n - done) dst[done + lane] = src[done + lane];
 }
 
 // Measures whether one ds_wrxchg_rtn_b32 serves same-address lanes in ascending lane order
@@ -457,8 +550,16 @@ static void launch_encode_t(const EncParams& p, hipStream_t st, KernelTimer* tm)
     tm->mark(kT_enc_scan_groups, st);
     hipLaunchKernelGGL(enc_scan_images, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_images, st);
-    hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL>), dim3(blocks), dim3(256), 0, st, p);
+    const uint32_t quads_per_image = (p.spi + 3u) / 4u;
+    const uint32_t wgs_per_image = (quads_per_image + p.quads_per_wg - 1u) / p.quads_per_wg;
+    hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL>), dim3(wgs_per_image * p.n_images), dim3(256), 0, st, p);
     tm->mark(kT_enc_slabs, st);
+    if (p.scratch) {
+        hipLaunchKernelGGL(enc_offsets, dim3(p.n_images), dim3(256), 0, st, p);
+        tm->mark(kT_enc_offsets, st);
+        hipLaunchKernelGGL(enc_compact, dim3(blocks), dim3(256), 0, st, p);
+        tm->mark(kT_enc_compact, st);
+    }
 }
 
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm) {

@@ -76,6 +76,7 @@ struct qoimi_ctx {
     uint32_t* last_enc_err = nullptr;   // device flag of the most recent encode launch
     bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
     int enc_ablate = 0, enc_ticket = 1, enc_quads = 0;   // tuning / profiling knobs (env QOIMI_ENC_*)
+    int enc_lookback = 0;               // 1: single-pass decoupled look-back instead of scratch + compaction
     KernelTimer timer;                  // optional per-kernel HIP-event timing
     double prof_ms[kT_count] = {0};     // accumulated kernel milliseconds since profiling was (re)enabled
     long long prof_calls[kT_count] = {0};
@@ -113,6 +114,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_ABLATE")) c->enc_ablate = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_TICKET")) c->enc_ticket = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_QUADS")) c->enc_quads = atoi(e);
+    if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
     if (const char* e = getenv("QOIMI_SEG_BYTES")) {
         long v = atol(e);
         if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v;
@@ -166,7 +168,7 @@ extern "C" int qoimi_get_profile(qoimi_ctx* c, void* stream, double* ms, long lo
 }
 
 extern "C" const char* qoimi_kernel_name(int i) {
-    static const char* names[kT_count] = {"", "enc_slab_summary", "enc_scan_groups", "enc_scan_images", "enc_slabs",
+    static const char* names[kT_count] = {"", "enc_slab_summary", "enc_scan_groups", "enc_scan_images", "enc_slabs", "enc_offsets", "enc_compact",
         "dec_parse", "dec_chain_parse", "dec_slot_walk", "dec_chain_slots", "dec_summarize", "dec_chain_state",
         "dec_segments", "dec_prepare_restart", "dec_fill"};
     return (i >= 0 && i < kT_count) ? names[i] : "";
@@ -202,17 +204,21 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.use_ticket = c->enc_ticket ? 1 : 0;
     p.ablate = (uint8_t)c->enc_ablate;
     const size_t T = (size_t)p.n_images * p.spi, G = (size_t)p.n_images * p.gpi;
-    p.quads_per_wg = c->enc_quads > 0 ? (uint32_t)c->enc_quads : (T > 32768 ? 4u : 1u);
+    p.quads_per_wg = c->enc_quads > 0 ? (uint32_t)c->enc_quads : (p.spi / (uint32_t)n_images > 16384u ? 4u : 1u);
     if (T > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (slab index overflows 32 bits)");
 
     for (int pass = 0; pass < 2; ++pass) {      // pass 0 measures, pass 1 carves
         Carver w(pass ? c->enc_ws.base : nullptr);
-        p.status = w.take<u64>(T); p.ticket = w.take<uint32_t>(1); p.err = w.take<uint32_t>(1);
+        p.status = w.take<u64>(T); p.ticket = w.take<uint32_t>((size_t)n_images); p.err = w.take<uint32_t>(1);
         const size_t zero_bytes = w.off;
         p.sum_tab = w.take<uint32_t>(T * 64); p.sum_valid = w.take<u64>(T); p.sum_le = w.take<int>(T);
         p.ent_tab = w.take<uint32_t>(T * 64); p.ent_valid = w.take<u64>(T); p.ent_le = w.take<int>(T);
         p.grp_tab = w.take<uint32_t>(G * 64); p.grp_valid = w.take<u64>(G); p.grp_le = w.take<int>(G);
         p.gent_tab = w.take<uint32_t>(G * 64); p.gent_le = w.take<int>(G);
+        if (!c->enc_lookback) {
+            p.slab_size = w.take<uint32_t>(T); p.slab_off = w.take<uint32_t>(T);
+            p.scratch = w.take<uint8_t>(T * kEncScratchStride);
+        }
         if (!pass) { int rc = c->enc_ws.reserve(w.off + 256); if (rc) return rc; }
         else HIP_TRY(hipMemsetAsync(c->enc_ws.base, 0, zero_bytes, st));   // look-back records, ticket, err
     }

@@ -13,7 +13,7 @@ constexpr int kHeaderBytes = 14, kTrailerBytes = 8;   // qoi.h:326, qoi.h:339
 // Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's
 // roofline figure).  mark(tag) closes the interval of the kernel launched just before it.
 enum KernelTag { kT_begin = 0,
-                 kT_enc_summary, kT_enc_scan_groups, kT_enc_scan_images, kT_enc_slabs,
+                 kT_enc_summary, kT_enc_scan_groups, kT_enc_scan_images, kT_enc_slabs, kT_enc_offsets, kT_enc_compact,
                  kT_dec_parse, kT_dec_chain_parse, kT_dec_slot_walk, kT_dec_chain_slots, kT_dec_summarize,
                  kT_dec_chain_state, kT_dec_segments, kT_dec_restart, kT_dec_fill, kT_count };
 struct KernelTimer {
@@ -26,8 +26,9 @@ struct KernelTimer {
 };
 
 // ---- encode ------------------------------------------------------------------------
-constexpr int kEncSteps = 32;                         // 64-pixel steps per slab
+constexpr int kEncSteps = 16;                         // 64-pixel steps per slab
 constexpr uint32_t kEncSlabPx = 64u * kEncSteps;      // pixels per slab (one wavefront)
+constexpr uint32_t kEncScratchStride = ((kEncSlabPx * 5u + 8u + 15u) / 16u) * 16u;   // scratch slot of one slab
 
 struct EncParams {
     const uint8_t* pixels;   // image i at pixels + i*pixel_stride
@@ -48,8 +49,12 @@ struct EncParams {
     uint32_t* grp_tab;   u64* grp_valid;  int* grp_le;     // E2a aggregate [n_images*gpi]
     uint32_t* gent_tab;  int* gent_le;                     // E2b out       [n_images*gpi]
     u64* status;         // look-back records [n_images*spi]   -- zeroed before every launch
-    uint32_t* ticket;    // slab ticket counter               -- zeroed before every launch
+    uint32_t* ticket;    // per-image slab ticket counters [n_images] -- zeroed before every launch
     uint32_t* err;       // liveness-bound flag               -- zeroed before every launch
+    // order-free mode (scratch != nullptr): slabs park their bytes in scratch slots, E4 compacts
+    uint8_t* scratch;    // [n_images*spi][kEncScratchStride]
+    uint32_t* slab_size; // [n_images*spi]
+    uint32_t* slab_off;  // [n_images*spi]
     // output
     uint8_t* out; size_t out_stride; int* out_len;
 };
