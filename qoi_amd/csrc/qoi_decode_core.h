@@ -106,28 +106,43 @@ struct ParseRec {
     uint32_t exit_phase;   // 3 bits per entry phase: phase handed to the next segment
     uint32_t pixels[5];    // pixels produced by the chunks that START in this segment
 };
-
+// Five parse chains start on bytes base+0..4; a chain's next position depends only on the
+// byte it stands on, so chains that meet stay together.  All chains sit within 5 bytes of
+// the front (their minimum), which only moves forward: one sequential reader serves them.
+struct ParseState { uint32_t p0, p1, p2, p3, p4, c0, c1, c2, c3, c4; };
+QOIMI_HD void parse_init(ParseState& s, uint32_t base) {
+    s.p0 = base; s.p1 = base + 1; s.p2 = base + 2; s.p3 = base + 3; s.p4 = base + 4;
+    s.c0 = s.c1 = s.c2 = s.c3 = s.c4 = 0;
+}
+QOIMI_HD uint32_t parse_front(const ParseState& s) {
+    uint32_t m = s.p0 < s.p1 ? s.p0 : s.p1; m = m < s.p2 ? m : s.p2; m = m < s.p3 ? m : s.p3; m = m < s.p4 ? m : s.p4;
+    return m;
+}
+// b = stream byte at the front position m
+QOIMI_HD void parse_step(ParseState& s, uint32_t m, uint32_t b) {
+    const uint32_t len = chunk_len(b), npx = chunk_pixels(b);
+    if (s.p0 == m) { s.p0 += len; s.c0 += npx; }
+    if (s.p1 == m) { s.p1 += len; s.c1 += npx; }
+    if (s.p2 == m) { s.p2 += len; s.c2 += npx; }
+    if (s.p3 == m) { s.p3 += len; s.c3 += npx; }
+    if (s.p4 == m) { s.p4 += len; s.c4 += npx; }
+}
+QOIMI_HD void parse_finish(const ParseState& s, uint32_t base, uint32_t B, ParseRec& r) {
+    const uint32_t nom = base + B;
+    const uint32_t e0 = s.p0 > nom ? s.p0 - nom : 0, e1 = s.p1 > nom ? s.p1 - nom : 0, e2 = s.p2 > nom ? s.p2 - nom : 0,
+                   e3 = s.p3 > nom ? s.p3 - nom : 0, e4 = s.p4 > nom ? s.p4 - nom : 0;
+    r.exit_phase = e0 | (e1 << 3) | (e2 << 6) | (e3 << 9) | (e4 << 12);
+    r.pixels[0] = s.c0; r.pixels[1] = s.c1; r.pixels[2] = s.c2; r.pixels[3] = s.c3; r.pixels[4] = s.c4;
+}
 // in: stream base; [base, seg_end) is this segment clipped to the chunk region; B = nominal size
 QOIMI_HD void parse_segment(const uint8_t* in, uint32_t base, uint32_t seg_end, uint32_t B, ParseRec& r) {
-    uint32_t p0 = base, p1 = base + 1, p2 = base + 2, p3 = base + 3, p4 = base + 4;
-    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    ParseState s; parse_init(s, base);
     for (;;) {
-        uint32_t m = p0 < p1 ? p0 : p1; m = m < p2 ? m : p2; m = m < p3 ? m : p3; m = m < p4 ? m : p4;
+        const uint32_t m = parse_front(s);
         if (m >= seg_end) break;
-        const uint32_t b = in[m];
-        const uint32_t len = chunk_len(b), npx = chunk_pixels(b);
-        // chains standing on the same byte advance together (they have merged)
-        if (p0 == m) { p0 += len; c0 += npx; }
-        if (p1 == m) { p1 += len; c1 += npx; }
-        if (p2 == m) { p2 += len; c2 += npx; }
-        if (p3 == m) { p3 += len; c3 += npx; }
-        if (p4 == m) { p4 += len; c4 += npx; }
+        parse_step(s, m, in[m]);
     }
-    const uint32_t nom = base + B;
-    const uint32_t e0 = p0 > nom ? p0 - nom : 0, e1 = p1 > nom ? p1 - nom : 0, e2 = p2 > nom ? p2 - nom : 0,
-                   e3 = p3 > nom ? p3 - nom : 0, e4 = p4 > nom ? p4 - nom : 0;
-    r.exit_phase = e0 | (e1 << 3) | (e2 << 6) | (e3 << 9) | (e4 << 12);
-    r.pixels[0] = c0; r.pixels[1] = c1; r.pixels[2] = c2; r.pixels[3] = c3; r.pixels[4] = c4;
+    parse_finish(s, base, B, r);
 }
 
 // =====================================================================================
@@ -138,35 +153,52 @@ QOIMI_HD void parse_segment(const uint8_t* in, uint32_t base, uint32_t seg_end, 
 // whose alpha does not change through the table; anything else is caught by P4's check).
 // =====================================================================================
 struct SlotRec { uint8_t hc, h_rel, h_alpha, a_abs, ac; };
+struct SlotState { uint32_t hc, h_rel, h_alpha, a_abs, ac; };
 
 QOIMI_HD uint32_t lin_hash(uint32_t rgb) {   // 3r+5g+7b of packed bytes (alpha ignored)
     return (rgb & 0xFF) * 3u + ((rgb >> 8) & 0xFF) * 5u + ((rgb >> 16) & 0xFF) * 7u;
 }
-
+QOIMI_HD void slot_init(SlotState& s) { s.hc = 0; s.h_rel = 1; s.h_alpha = 0; s.a_abs = 0; s.ac = 0; }
+QOIMI_HD void slot_step(SlotState& s, const Chunk& c) {
+    const uint32_t lrgb = lin_hash(c.rgba);                    // 3r+5g+7b of the payload
+    // RGB: slot = lin(rgb) + 11*alpha (alpha absolute if an RGBA was seen, else the entry alpha)
+    const uint32_t hc_rgb = lrgb + (s.a_abs ? 11u * s.ac : 0u);
+    const uint32_t hc_rgba = lrgb + 11u * (c.rgba >> 24);
+    const bool abs_op = c.is_rgb || c.is_rgba || c.is_index;
+    s.hc = (c.is_rgb ? hc_rgb : (c.is_rgba ? hc_rgba : (c.is_index ? c.b1 : s.hc + lin_hash(c.delta)))) & 63u;
+    s.h_alpha = c.is_rgb ? (s.a_abs ? 0u : 1u) : ((c.is_rgba || c.is_index) ? 0u : s.h_alpha);
+    s.h_rel = abs_op ? 0u : s.h_rel;
+    s.ac = c.is_rgba ? (c.rgba >> 24) : s.ac;
+    s.a_abs = c.is_rgba ? 1u : s.a_abs;
+}
+QOIMI_HD void slot_finish(const SlotState& s, SlotRec& r) {
+    r.hc = (uint8_t)s.hc; r.h_rel = (uint8_t)s.h_rel; r.h_alpha = (uint8_t)s.h_alpha; r.a_abs = (uint8_t)s.a_abs; r.ac = (uint8_t)s.ac;
+}
 QOIMI_HD void slot_walk_segment(const uint8_t* in, uint32_t pos, uint32_t seg_end, SlotRec& r) {
-    uint32_t hc = 0, h_rel = 1, h_alpha = 0, a_abs = 0, ac = 0;
+    SlotState s; slot_init(s);
     while (pos < seg_end) {
         const Chunk c = crack(load8(in + pos));
-        const uint32_t lrgb = lin_hash(c.rgba);                    // 3r+5g+7b of the payload
-        // RGB: slot = lin(rgb) + 11*alpha (alpha absolute if an RGBA was seen, else the entry alpha)
-        const uint32_t hc_rgb = lrgb + (a_abs ? 11u * ac : 0u);
-        const uint32_t hc_rgba = lrgb + 11u * (c.rgba >> 24);
-        const bool abs_op = c.is_rgb || c.is_rgba || c.is_index;
-        hc = c.is_rgb ? hc_rgb : (c.is_rgba ? hc_rgba : (c.is_index ? c.b1 : hc + lin_hash(c.delta)));
-        h_alpha = c.is_rgb ? (a_abs ? 0u : 1u) : ((c.is_rgba || c.is_index) ? 0u : h_alpha);
-        h_rel = abs_op ? 0u : h_rel;
-        ac = c.is_rgba ? (c.rgba >> 24) : ac;
-        a_abs = c.is_rgba ? 1u : a_abs;
-        hc &= 63u;
+        slot_step(s, c);
         pos += c.len;
     }
-    r.hc = (uint8_t)hc; r.h_rel = (uint8_t)h_rel; r.h_alpha = (uint8_t)h_alpha; r.a_abs = (uint8_t)a_abs; r.ac = (uint8_t)ac;
+    slot_finish(s, r);
 }
 
 QOIMI_HD void slot_apply(const SlotRec& r, uint32_t& slot, uint32_t& alpha) {
     const uint32_t s = (r.hc + (r.h_rel ? slot : 0u) + (r.h_alpha ? 11u * alpha : 0u)) & 63u;
     const uint32_t a = r.a_abs ? r.ac : alpha;
     slot = s; alpha = a;
+}
+// r = b after a (both as transfers): closed under composition
+QOIMI_HD SlotRec slot_compose(const SlotRec& a, const SlotRec& b) {
+    SlotRec r;
+    const uint32_t alpha_term = b.h_alpha ? (a.a_abs ? 11u * a.ac : 0u) : 0u;       // b reads the alpha a leaves
+    r.hc = (uint8_t)((b.hc + (b.h_rel ? a.hc : 0u) + alpha_term) & 63u);
+    r.h_rel = (uint8_t)(b.h_rel && a.h_rel);
+    r.h_alpha = (uint8_t)(((b.h_rel && a.h_alpha) || (b.h_alpha && !a.a_abs)) ? 1u : 0u);
+    r.a_abs = (uint8_t)(b.a_abs || a.a_abs);
+    r.ac = b.a_abs ? b.ac : a.ac;
+    return r;
 }
 
 // =====================================================================================
@@ -191,54 +223,74 @@ QOIMI_HD uint32_t sym_eval(sym_t s, uint32_t src_value) {
     const uint32_t m = abs_bytemask(sym_abs(s));
     return add_bytes(src_value & ~m, sym_c(s));
 }
+// symbolic word b (expressed in the exit state of an earlier summary) re-expressed in that
+// summary's entry state; a_src = the earlier summary's word that b's source points at
+QOIMI_HD sym_t sym_compose(sym_t b, sym_t a_src) {
+    const uint32_t mb = abs_bytemask(sym_abs(b));
+    const uint32_t c = add_bytes(sym_c(a_src) & ~mb, sym_c(b));
+    return sym_make(c, sym_src(a_src), sym_abs(b) | sym_abs(a_src));
+}
 
-// Tab: accessor with get(slot) / set(slot, sym_t).  slot/alpha: speculated entry values.
-// Processes every chunk that starts in [pos, seg_end).
+struct SymState { uint32_t pc, ph, slot, alpha; };   // running pixel: constants, source|absmask<<8; speculated slot/alpha
+// Tab: accessor with get(slot) / set(slot, sym_t).
+template <class Tab>
+QOIMI_HD void sym_init(SymState& s, uint32_t slot, uint32_t alpha, Tab& tab) {
+    for (uint32_t k = 0; k < 64; ++k) tab.set(k, sym_make(0u, k, 0u));
+    s.pc = 0u; s.ph = 64u; s.slot = slot; s.alpha = alpha;
+}
+template <class Tab>
+QOIMI_HD void sym_step(SymState& s, const Chunk& c, Tab& tab) {
+    const sym_t t = tab.get(c.b1 & 63u);                         // read unconditionally, used if INDEX
+    const uint32_t rgb = c.rgba & 0x00FFFFFFu;
+    const uint32_t pc_rel = add_bytes(s.pc, c.delta);            // DIFF/LUMA/RUN (delta 0)
+    s.pc = c.is_rgba ? c.rgba : (c.is_rgb ? ((s.pc & 0xFF000000u) | rgb) : (c.is_index ? (uint32_t)t : pc_rel));
+    s.ph = c.is_rgba ? (15u << 8) : (c.is_rgb ? (s.ph | (7u << 8)) : (c.is_index ? (uint32_t)(t >> 32) : s.ph));
+    const uint32_t s_rgb = lin_hash(rgb) + 11u * s.alpha;
+    const uint32_t s_rgba = lin_hash(rgb) + 11u * (c.rgba >> 24);
+    s.slot = (c.is_rgb ? s_rgb : (c.is_rgba ? s_rgba : (c.is_index ? c.b1 : s.slot + lin_hash(c.delta)))) & 63u;
+    s.alpha = c.is_rgba ? (c.rgba >> 24) : s.alpha;
+    tab.set(s.slot, (sym_t)s.pc | ((sym_t)s.ph << 32));          // index update after every chunk (qoi.h:577)
+}
+QOIMI_HD sym_t sym_pixel(const SymState& s) { return (sym_t)s.pc | ((sym_t)s.ph << 32); }
+
+// Processes every chunk that starts in [pos, seg_end).  slot/alpha: speculated entry values.
 template <class Tab>
 QOIMI_HD sym_t summarize_segment(const uint8_t* in, uint32_t pos, uint32_t seg_end,
                                  uint32_t slot, uint32_t alpha, Tab& tab) {
-    for (uint32_t k = 0; k < 64; ++k) tab.set(k, sym_make(0u, k, 0u));
-    uint32_t pc = 0u;               // per-channel constants of the running pixel
-    uint32_t ph = 64u;              // its source (bits 0..6) and absolute mask (bits 8..11)
+    SymState s; sym_init(s, slot, alpha, tab);
     while (pos < seg_end) {
         const Chunk c = crack(load8(in + pos));
-        const sym_t t = tab.get(c.b1 & 63u);                         // read unconditionally, used if INDEX
-        const uint32_t rgb = c.rgba & 0x00FFFFFFu;
-        // constants
-        const uint32_t pc_rel = add_bytes(pc, c.delta);              // DIFF/LUMA/RUN (delta 0)
-        pc = c.is_rgba ? c.rgba : (c.is_rgb ? ((pc & 0xFF000000u) | rgb) : (c.is_index ? (uint32_t)t : pc_rel));
-        // source / absolute mask
-        ph = c.is_rgba ? (15u << 8) : (c.is_rgb ? (ph | (7u << 8)) : (c.is_index ? (uint32_t)(t >> 32) : ph));
-        // speculated slot / alpha of the new pixel
-        const uint32_t s_rgb = lin_hash(rgb) + 11u * alpha;
-        const uint32_t s_rgba = lin_hash(rgb) + 11u * (c.rgba >> 24);
-        slot = c.is_rgb ? s_rgb : (c.is_rgba ? s_rgba : (c.is_index ? c.b1 : slot + lin_hash(c.delta)));
-        slot &= 63u;
-        alpha = c.is_rgba ? (c.rgba >> 24) : alpha;
-        tab.set(slot, (sym_t)pc | ((sym_t)ph << 32));                // index update after every chunk (qoi.h:577)
+        sym_step(s, c, tab);
         pos += c.len;
     }
-    return (sym_t)pc | ((sym_t)ph << 32);
+    return sym_pixel(s);
 }
 
 // =====================================================================================
 // P4 — genuine decode of one segment from a concrete entry state (qoi.h:540-587)
 // =====================================================================================
-// Tab32: get(slot)/set(slot,uint32_t).  Writes pixels [px_pos, px_limit) at most.
-// OCH = output channels (3 or 4).  Returns the exit pixel; tab holds the exit table.
+// one chunk: new pixel, table updated (qoi.h:547-577).  Tab32: get(slot)/set(slot,uint32_t)
+template <class Tab32>
+QOIMI_HD uint32_t pixel_step(uint32_t px, const Chunk& c, Tab32& tab) {
+    const uint32_t t = tab.get(c.b1 & 63u);                      // read unconditionally, used if INDEX
+    const uint32_t rel = add_bytes(px, c.delta);
+    px = c.is_rgba ? c.rgba : (c.is_rgb ? ((px & 0xFF000000u) | (c.rgba & 0x00FFFFFFu)) : (c.is_index ? t : rel));
+    tab.set(hash_px(px), px);
+    return px;
+}
+QOIMI_HD uint32_t chunk_run(const Chunk& c) { return c.is_run ? (c.b1 & 0x3Fu) + 1u : 1u; }   // qoi.h:573-575
+
+// Writes pixels [px_pos, px_limit) at most.  OCH = output channels (3 or 4).
+// Returns the exit pixel; tab holds the exit table.
 template <int OCH, class Tab32>
 QOIMI_HD uint32_t decode_segment(const uint8_t* in, uint32_t pos, uint32_t seg_end,
                                  uint32_t px, Tab32& tab, uint8_t* out,
                                  uint32_t px_pos, uint32_t px_limit) {
     while (pos < seg_end && px_pos < px_limit) {
         const Chunk c = crack(load8(in + pos));
-        const uint32_t t = tab.get(c.b1 & 63u);                      // read unconditionally, used if INDEX
-        const uint32_t rel = add_bytes(px, c.delta);
-        px = c.is_rgba ? c.rgba : (c.is_rgb ? ((px & 0xFF000000u) | (c.rgba & 0x00FFFFFFu)) : (c.is_index ? t : rel));
-        const uint32_t n = c.is_run ? (c.b1 & 0x3Fu) + 1u : 1u;
+        px = pixel_step(px, c, tab);
         pos += c.len;
-        tab.set(hash_px(px), px);
-        uint32_t stop = px_pos + n;
+        uint32_t stop = px_pos + chunk_run(c);
         if (stop > px_limit) stop = px_limit;            // over-long run clipped (Appendix B item 8)
         for (; px_pos < stop; ++px_pos) {
             if (OCH == 4) {

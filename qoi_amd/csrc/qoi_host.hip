@@ -255,7 +255,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     int och = 0;
     std::vector<DecImage> imgs((size_t)n_images);
     const uint32_t B = c->seg_bytes;
-    uint64_t total = 0;
+    uint64_t total = 0, total_g = 0;
     for (int i = 0; i < n_images; ++i) {
         if (sizes[i] < kHeaderBytes + kTrailerBytes) return fail(QOIMI_E_ARG, "stream shorter than 22 bytes (qoi.h:500)");
         if (!desc_ok(&descs[i])) return fail(QOIMI_E_ARG, "descriptor rejected (qoi.h:513-521 rules)");
@@ -272,7 +272,10 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
         im.npx = (uint32_t)npx;
         im.seg_base = (uint32_t)total;
         im.nseg = (im.chunks_end - kHeaderBytes + B - 1u) / B;
+        im.grp_base = (uint32_t)total_g;
+        im.ngrp = (im.nseg + 63u) / 64u;
         total += im.nseg;
+        total_g += im.ngrp;
     }
     if (total > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (segment index overflows 32 bits)");
     HIP_TRY(hipSetDevice(c->device));
@@ -281,7 +284,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     DecParams p;
     memset(&p, 0, sizeof p);
     p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
-    p.total_segs = (uint32_t)total; p.seg_bytes = B;
+    p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
     const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
     for (int pass = 0; pass < 2; ++pass) {
@@ -292,6 +295,10 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
         p.parse = w.take<ParseRec>(Q); p.entry_phase = w.take<uint8_t>(Q); p.px_off = w.take<uint32_t>(Q);
         p.slot_rec = w.take<SlotRec>(Q); p.slot_in = w.take<uint8_t>(Q); p.alpha_in = w.take<uint8_t>(Q);
         p.summary = w.take<u64>(Q * 65); p.entry = w.take<uint32_t>(Q * 65); p.fix = w.take<uint32_t>(Q * 65);
+        const size_t NG = total_g + 1;
+        p.grp_parse = w.take<ParseRec>(NG); p.grp_phase = w.take<uint8_t>(NG); p.grp_off = w.take<uint32_t>(NG);
+        p.grp_slot = w.take<SlotRec>(NG); p.grp_slot_in = w.take<uint8_t>(NG); p.grp_alpha_in = w.take<uint8_t>(NG);
+        p.grp_summary = w.take<u64>(NG * 65); p.grp_entry = w.take<uint32_t>(NG * 65);
         if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }
     }
     HIP_TRY(hipMemcpyAsync(p.images, imgs.data(), imgs.size() * sizeof(DecImage), hipMemcpyHostToDevice, st));

@@ -71,6 +71,8 @@ struct DecImage {
     uint32_t npx;          // width*height
     uint32_t seg_base;     // global index of this image's first segment
     uint32_t nseg;         // ceil((chunks_end-14)/seg_bytes)
+    uint32_t grp_base;     // global index of this image's first 64-segment group
+    uint32_t ngrp;         // ceil(nseg/64)
     // filled on the device
     uint32_t total_px;     // pixels produced by all chunks, clamped to npx        (S1)
     uint32_t n_active;     // segments that start before the pixel limit            (S1)
@@ -81,7 +83,7 @@ struct DecImage {
 struct DecParams {
     const uint8_t* streams;
     DecImage* images;      // device array [n_images]
-    uint32_t n_images, total_segs, seg_bytes;
+    uint32_t n_images, total_segs, total_grps, seg_bytes;
     uint8_t* pixels; size_t pixel_stride;
     // workspace, per global segment q
     ParseRec* parse;           // P1
@@ -93,6 +95,15 @@ struct DecParams {
     u64*      summary;         // P3  [q][65] symbolic words (slots 0..63, pixel)
     uint32_t* entry;           // S3  [q][65] concrete entry state (table 0..63, pixel)
     uint32_t* fix;             // P4  [q][65] true entry state of q where the check failed
+    // per 64-segment group G (two-level chains)
+    ParseRec* grp_parse;       // S1 l1
+    uint8_t*  grp_phase;       // S1 l2
+    uint32_t* grp_off;         // S1 l2
+    SlotRec*  grp_slot;        // S2 l1
+    uint8_t*  grp_slot_in;     // S2 l2
+    uint8_t*  grp_alpha_in;    // S2 l2
+    u64*      grp_summary;     // S3 l1 [G][65]
+    uint32_t* grp_entry;       // S3 l2 [G][65]
     uint32_t* first_bad;       // [n_images] min failing segment, 0xFFFFFFFF: none
     uint32_t* pending;         // [1] images that need another round
     uint32_t* redo_segs;       // [1] statistics

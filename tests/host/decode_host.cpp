@@ -24,8 +24,16 @@ struct Tab32 { uint32_t v[64]; uint32_t get(uint32_t k) const { return v[k]; } v
 }
 
 // returns 0; stats[0] = rounds, stats[1] = segments re-decoded, stats[2] = segments
+// GRP: segments per group of the two-level chains (the kernels use 64)
+extern "C" int host_decode_pipeline_g(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
+                                      uint8_t* out, long long* stats);
 extern "C" int host_decode_pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B,
                                     uint8_t* out, long long* stats) {
+    return host_decode_pipeline_g(in, size, npx, och, B, 64, out, stats);
+}
+
+extern "C" int host_decode_pipeline_g(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
+                                      uint8_t* out, long long* stats) {
     const uint32_t chunks_end = (uint32_t)size - 8u;
     const uint32_t nseg = (chunks_end - 14u + B - 1u) / B;
     std::vector<ParseRec> parse(nseg);
@@ -35,14 +43,35 @@ extern "C" int host_decode_pipeline(const uint8_t* in, int size, uint32_t npx, i
         const uint32_t base = 14u + j * B, end = base + B < chunks_end ? base + B : chunks_end;
         parse_segment(in, base, end, B, parse[j]);
     }
-    // S1
-    uint32_t ph = 0, off = 0, n_active = 0;
-    for (uint32_t j = 0; j < nseg; ++j) {
-        phase[j] = ph; px_off[j] = off;
-        if (off < npx) n_active = j + 1;
-        const unsigned long long t = (unsigned long long)off + parse[j].pixels[ph];
-        ph = (parse[j].exit_phase >> (3u * ph)) & 7u;
-        off = t > npx ? npx : (uint32_t)t;
+    // S1, two-level like the kernels: (1) per group and entry phase: exit phase + pixels,
+    // (2) chain the groups, (3) chain inside every group from its entry
+    const uint32_t ngrp = (nseg + GRP - 1) / GRP;
+    std::vector<uint32_t> g_exit(ngrp * 5u), g_phase(ngrp);
+    std::vector<unsigned long long> g_px(ngrp * 5u), g_off(ngrp);
+    for (uint32_t g = 0; g < ngrp; ++g)
+        for (uint32_t ph0 = 0; ph0 < 5; ++ph0) {
+            uint32_t ph = ph0; unsigned long long sum = 0;
+            for (uint32_t j = g * GRP; j < nseg && j < (g + 1) * GRP; ++j) {
+                sum += parse[j].pixels[ph];
+                ph = (parse[j].exit_phase >> (3u * ph)) & 7u;
+            }
+            g_exit[g * 5u + ph0] = ph; g_px[g * 5u + ph0] = sum;
+        }
+    uint32_t ph = 0; unsigned long long off64 = 0;
+    for (uint32_t g = 0; g < ngrp; ++g) {
+        g_phase[g] = ph; g_off[g] = off64 > npx ? npx : off64;
+        off64 = g_off[g] + g_px[g * 5u + ph];
+        ph = g_exit[g * 5u + ph];
+    }
+    uint32_t off = (uint32_t)(off64 > npx ? npx : off64), n_active = 0;
+    for (uint32_t g = 0; g < ngrp; ++g) {
+        uint32_t p2 = g_phase[g]; unsigned long long o2 = g_off[g];
+        for (uint32_t j = g * GRP; j < nseg && j < (g + 1) * GRP; ++j) {
+            phase[j] = p2; px_off[j] = (uint32_t)o2;
+            if (o2 < npx && j + 1 > n_active) n_active = j + 1;
+            o2 += parse[j].pixels[p2]; if (o2 > npx) o2 = npx;
+            p2 = (parse[j].exit_phase >> (3u * p2)) & 7u;
+        }
     }
     const uint32_t total_px = off;
 
@@ -60,10 +89,23 @@ extern "C" int host_decode_pipeline(const uint8_t* in, int size, uint32_t npx, i
             const uint32_t base = 14u + j * B, end = base + B < chunks_end ? base + B : chunks_end;
             slot_walk_segment(in, base + phase[j], end, srec[j]);
         }
-        uint32_t slot = hash_px(entry[(size_t)start * 65u + 64u]), alpha = entry[(size_t)start * 65u + 64u] >> 24;
-        for (uint32_t j = start; j < n_active; ++j) {
-            slot_in[j] = (uint8_t)slot; alpha_in[j] = (uint8_t)alpha;
-            slot_apply(srec[j], slot, alpha);
+        {   // S2, two-level: compose the transfers of each group, chain groups, apply inside groups
+            const uint32_t g0 = start / GRP, g1 = (n_active + GRP - 1) / GRP;
+            std::vector<SlotRec> gt(g1);
+            for (uint32_t g = g0; g < g1; ++g) {
+                SlotRec acc = {0, 1, 0, 0, 0};
+                for (uint32_t j = (g * GRP < start ? start : g * GRP); j < n_active && j < (g + 1) * GRP; ++j) acc = slot_compose(acc, srec[j]);
+                gt[g] = acc;
+            }
+            uint32_t slot = hash_px(entry[(size_t)start * 65u + 64u]), alpha = entry[(size_t)start * 65u + 64u] >> 24;
+            for (uint32_t g = g0; g < g1; ++g) {
+                uint32_t s2 = slot, a2 = alpha;
+                for (uint32_t j = (g * GRP < start ? start : g * GRP); j < n_active && j < (g + 1) * GRP; ++j) {
+                    slot_in[j] = (uint8_t)s2; alpha_in[j] = (uint8_t)a2;
+                    slot_apply(srec[j], s2, a2);
+                }
+                slot_apply(gt[g], slot, alpha);
+            }
         }
         // P3
         for (uint32_t j = start; j < n_active; ++j) {
@@ -73,13 +115,35 @@ extern "C" int host_decode_pipeline(const uint8_t* in, int size, uint32_t npx, i
             for (int k = 0; k < 64; ++k) summary[(size_t)j * 65u + k] = t.v[k];
             summary[(size_t)j * 65u + 64u] = px;
         }
-        // S3
-        for (uint32_t j = start; j + 1 < n_active; ++j) {
-            const uint32_t* cur = &entry[(size_t)j * 65u];
-            uint32_t* nxt = &entry[(size_t)(j + 1) * 65u];
-            for (int e = 0; e < 65; ++e) {
-                const sym_t s = summary[(size_t)j * 65u + e];
-                nxt[e] = sym_eval(s, cur[sym_src(s)]);
+        // S3, two-level: compose the symbolic summaries of each group, apply group summaries in
+        // sequence to the concrete state, then apply segment summaries inside every group
+        {
+            const uint32_t g0 = start / GRP, g1 = (n_active + GRP - 1) / GRP;
+            std::vector<sym_t> gsum((size_t)g1 * 65u);
+            for (uint32_t g = g0; g < g1; ++g) {
+                sym_t P[65];
+                for (int e = 0; e < 65; ++e) P[e] = sym_make(0u, (uint32_t)e, 0u);     // identity
+                for (uint32_t j = (g * GRP < start ? start : g * GRP); j < n_active && j < (g + 1) * GRP; ++j) {
+                    sym_t N[65];
+                    for (int e = 0; e < 65; ++e) { const sym_t b2 = summary[(size_t)j * 65u + e]; N[e] = sym_compose(b2, P[sym_src(b2)]); }
+                    memcpy(P, N, sizeof P);
+                }
+                memcpy(&gsum[(size_t)g * 65u], P, sizeof P);
+            }
+            uint32_t cur[65];
+            memcpy(cur, &entry[(size_t)start * 65u], 260);
+            for (uint32_t g = g0; g < g1; ++g) {
+                uint32_t st[65];
+                memcpy(st, cur, 260);
+                for (uint32_t j = (g * GRP < start ? start : g * GRP); j < n_active && j < (g + 1) * GRP; ++j) {
+                    if (j > start) memcpy(&entry[(size_t)j * 65u], st, 260);
+                    uint32_t nx[65];
+                    for (int e = 0; e < 65; ++e) { const sym_t s3 = summary[(size_t)j * 65u + e]; nx[e] = sym_eval(s3, st[sym_src(s3)]); }
+                    memcpy(st, nx, 260);
+                }
+                uint32_t nc[65];
+                for (int e = 0; e < 65; ++e) { const sym_t s3 = gsum[(size_t)g * 65u + e]; nc[e] = sym_eval(s3, cur[sym_src(s3)]); }
+                memcpy(cur, nc, 260);
             }
         }
         // P4 + check

@@ -25,19 +25,19 @@ def host_lib(tmp_path_factory):
     src = os.path.join(ROOT, "tests", "host", "decode_host.cpp")
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src], check=True)
     lib = ctypes.CDLL(out)
-    lib.host_decode_pipeline.restype = ctypes.c_int
-    lib.host_decode_pipeline.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32,
-                                         ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
+    lib.host_decode_pipeline_g.restype = ctypes.c_int
+    lib.host_decode_pipeline_g.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32,
+                                           ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
     return lib
 
 
-def run(lib, stream: bytes, och: int, B: int):
+def run(lib, stream: bytes, och: int, B: int, grp: int = 64):
     w, h = struct.unpack(">II", stream[4:12])
     npx = w * h
     buf = np.frombuffer(stream + b"\0" * 8, dtype=np.uint8).copy()
     out = np.full(npx * och + 8, 0xAB, dtype=np.uint8)
     stats = (ctypes.c_longlong * 4)()
-    lib.host_decode_pipeline(buf.ctypes.data, len(stream), npx, och, B, out.ctypes.data, stats)
+    lib.host_decode_pipeline_g(buf.ctypes.data, len(stream), npx, och, B, grp, out.ctypes.data, stats)
     return out[:npx * och], list(stats)
 
 
@@ -49,9 +49,9 @@ def test_scheme_matches_golden(host_lib, golden, encoded_streams):
         desc = golden[f"dec/{c['name']}/desc"]
         och = c["channels"] if c["channels"] else int(desc[2])
         want = golden[f"dec/{c['name']}/pixels"]
-        for B in (5, 7, 16, 64, 333, 2048):
-            got, stats = run(host_lib, c["stream"], och, B)
-            assert np.array_equal(got, want), (c["name"], B, stats)
+        for B, grp in ((5, 3), (7, 64), (16, 2), (64, 5), (333, 64), (2048, 64)):
+            got, stats = run(host_lib, c["stream"], och, B, grp)
+            assert np.array_equal(got, want), (c["name"], B, grp, stats)
         n += 1
     assert n > 100
 
