@@ -24,7 +24,7 @@ if [ "${DO_BENCH:-1}" = 1 ]; then
 fi
 if [ "${DO_PROF:-1}" = 1 ]; then
   echo "== rocprofv3 kernel trace"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o trace -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu ${BENCH_ARGS:-}) > "$OUT/prof.log" 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o trace -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu ${BENCH_ARGS:-}) > "$OUT/prof.log" 2>&1
   echo "rc=$?" >> "$OUT/prof.log"; tail -3 "$OUT/prof.log"
   find "$OUT/prof" -name "*stats*" | head
 fi
