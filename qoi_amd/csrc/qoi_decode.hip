@@ -158,7 +158,7 @@ struct LaneWriter {
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dec_parse(DecParams p) {
     __shared__ uint32_t s_ring[4][LaneReader::RD * 64];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
     const bool have = q < p.total_segs;
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void dec_chain_parse_l3(DecParams p) {
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dec_slot_walk(DecParams p) {
     __shared__ uint32_t s_ring[4][LaneReader::RD * 64];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
     bool have = q < p.total_segs;
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);

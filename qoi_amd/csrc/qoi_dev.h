@@ -46,6 +46,10 @@ __device__ __forceinline__ uint32_t gather_lane(uint32_t v, uint32_t src_lane) {
 __device__ __forceinline__ uint32_t count_below(u64 mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+// base + number of set bits of `mask` strictly below this lane (base: any per-lane value)
+__device__ __forceinline__ uint32_t count_below_from(u64 mask, uint32_t base) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, base));
+}
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

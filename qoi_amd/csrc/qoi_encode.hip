@@ -55,7 +55,7 @@ __device__ __forceinline__ u64 wave_sum64_upto(u64 v, uint32_t lane, int stop) {
 template <int CH, int K>
 __global__ __launch_bounds__(256) void enc_slab_summary(EncParams p) {
     __shared__ u64 s_key[4][64];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t g = blockIdx.x * 4u + wave;
     const uint32_t total = p.n_images * p.spi;
     if (g >= total) return;
@@ -64,14 +64,22 @@ __global__ __launch_bounds__(256) void enc_slab_summary(EncParams p) {
     const uint32_t n = p.npx, lo = s * (64u * K);
 
     s_key[wave][lane] = 0;
+    // all K loads of the slab in flight at once (a streaming kernel with 4 loads per lane in flight
+    // is bound by HBM latency, ~3 TB/s)
+    uint32_t cur[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        const uint32_t i = lo + t * 64u + lane;
+        cur[t] = i < n ? load_px<CH>(pix, i) : 0u;
+    }
     uint32_t carry = (lo > 0) ? load_px<CH>(pix, lo - 1) : kInitPx;
     int le = -1;
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
+#pragma unroll
     for (int t = 0; t < K; ++t) {
         const uint32_t i = lo + t * 64u + lane;
         const bool inb = i < n;
-        const uint32_t px = inb ? load_px<CH>(pix, i) : 0u;
+        const uint32_t px = cur[t];
         const uint32_t prev = from_lane_below(px, carry);
         const bool edge = inb && px != prev;
         if (edge) {
@@ -166,159 +174,287 @@ __device__ __forceinline__ void literal_chunk(uint32_t px, uint32_t prev, u64& b
 // LAST: the slab holds the image's last pixel (and possibly lanes beyond it).
 // ABL:  ablation bits for profiling only (1: no emission, 2: no look-back, 4: no probe).
 //
-// Chunk bytes go to a per-wave LDS staging buffer at slab-local offsets while the slab is
-// classified (one pass over the pixels); once the look-back has produced the slab's byte
-// offset the staged bytes are copied out with aligned dword stores.
-// Per-lane predicates are kept as booleans so that hipcc holds them as 64-bit lane masks
-// in SGPRs: class algebra and length bits cost scalar instructions, not VALU.
+// Instruction budget (profiles/r01_s3_issue_rates.txt): a wave64 VALU op costs ~1.25 ns of a SIMD,
+// an SALU op ~1.8 ns (one scalar unit per CU) and overlaps with VALU only up to about half the
+// VALU count, a DS op 4 LDS cycles of the CU whatever its width.  So the step below is written
+// for few instructions of every kind:
+//   * every pixel emits at most ONE chunk: a repeat pixel carries the run byte of the run it
+//     closes (qoi.h:417-421,425-428 put that byte in front of the next edge's chunk, which is
+//     the same stream position), so chunk length is in {0,1,2,4,5} per lane;
+//   * per-lane predicates live as 64-bit lane masks in SGPRs (ballot results); the few mask
+//     combinations are explicit scalar ops and come back as exec / v_cndmask masks through
+//     inverse_ballot;
+//   * work that a step does not need is skipped by wave-uniform branches (no repeats: no run
+//     arithmetic; no edges: no hash/probe/deltas; no literal: no deltas; no 4/5-byte chunk: no
+//     third offset count).
+// Chunk bytes go to a per-wave LDS staging buffer at slab-local offsets; once the slab's byte
+// offset is known the staged bytes are copied out with aligned dword stores.
 template <int K>
 struct EncLds {
-    static constexpr uint32_t kStageBytes = 64u * K * 5u + 8u;     // <= 5 B/px + one flushed run byte, + slack
+    static constexpr uint32_t kStageBytes = 64u * K * 5u + 8u;     // <= 5 B/px, + slack
     static constexpr uint32_t kStageDwords = ((kStageBytes + 15u) / 16u) * 4u;
+    alignas(256) uint32_t table[64];   // 256-byte aligned: slot address = base | (4*slot)
+    u64 mask[64];                      // PROBE 0 only
     alignas(16) uint32_t stage[kStageDwords];
-    uint32_t table[64];
-    uint32_t dummy[64];          // exchange target of lanes that must not touch the table (PROBE 1); must follow table
-    u64 mask[64];
 };
 
-constexpr int kEncUnroll = 8;     // steps per unrolled group (pixels of the next group are prefetched)
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const lds_u8*)p; }
 
-template <int CH, int K, int PROBE, bool LAST, int ABL>
-__device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, uint32_t lane, EncLds<K>& L) {
+__device__ __forceinline__ bool in_mask(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// v_ffbh_u32: number of leading zeros, 0xFFFFFFFF for 0
+__device__ __forceinline__ uint32_t ffbh(uint32_t v) {
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// lane l: v of lane l-1; lane 0: `before` of lane 63 (the previous 64 pixels).  Two DPP moves,
+// no trip through an SGPR.
+__device__ __forceinline__ uint32_t prev_pixels(uint32_t v, uint32_t before) {
+    const int first = __builtin_amdgcn_mov_dpp((int)before, 0x13C, 0xf, 0xf, false);              // wave_ror:1 (every lane has a source)
+    return (uint32_t)__builtin_amdgcn_update_dpp(first, (int)v, 0x138, 0xf, 0xf, false);          // wave_shr:1, lane 0 keeps `first`
+}
+
+// Byte 0 of every chunk and byte 1 of the 2+-byte chunks of one step into the LDS staging buffer.
+// Runs with all 64 lanes enabled (the slab loop is wave-uniform), so exec is switched with plain
+// moves: 3 scalar + 1 vector op around the two stores.  LDS ops of a wave complete in issue order,
+// so the later (compiler-visible) reads of the staging buffer see these stores.
+// a lane mask the compiler may have lost track of as wave-uniform -> SGPR pair (free when it already is one)
+__device__ __forceinline__ u64 uniform64(u64 m) {
+    return (u64)__builtin_amdgcn_readfirstlane((uint32_t)m) | ((u64)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32);
+}
+__device__ __forceinline__ void stage_short(uint32_t addr, uint32_t w, u64 any, u64 second) {
+    uint32_t hi;
+    asm volatile("s_mov_b64 exec, %3\n\t"
+                 "ds_write_b8 %1, %2\n\t"
+                 "v_lshrrev_b32 %0, 8, %2\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "ds_write_b8 %1, %0 offset:1\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "=&v"(hi) : "v"(addr), "v"(w), "s"(any), "s"(second) : "memory");
+}
+// Colour-table probe of one step (PROBE 1): the edge lanes swap their pixel into their slot and get
+// what the slot held.  Lanes of one instruction that hit the same slot are served in ascending lane
+// order (lds_order_selftest), i.e. in pixel order - exactly the sequential probe/update of
+// qoi.h:430-436.  The result is only defined for the lanes in `edges`; wait with probe_wait().
+__device__ __forceinline__ uint32_t probe_swap(uint32_t addr, uint32_t px, u64 edges) {
+    uint32_t seen;
+    asm volatile("s_mov_b64 exec, %3\n\t"
+                 "ds_wrxchg_rtn_b32 %0, %1, %2\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "=&v"(seen) : "v"(addr), "v"(px), "s"(edges) : "memory");
+    return seen;
+}
+__device__ __forceinline__ void probe_wait(uint32_t& seen) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(seen) : : "memory"); }
+
+// byte k of a minus byte k of b in the low byte of the result (upper bits: don't care)
+__device__ __forceinline__ uint32_t sub_byte1(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t sub_byte2(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// a != b on the scalar unit (hipcc turns a uniform bool -> int into v_cndmask and the masks built from it into VGPRs)
+__device__ __forceinline__ uint32_t scalar_ne(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("s_cmp_lg_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
+}
+
+// chunk word tags (bits 16..18, above the two bytes a short chunk stores): length class of the lane
+constexpr uint32_t kLenOne = 0u, kLenTwo = 1u << 17, kLenLong = 1u << 18;   // 1-byte chunks need no tag: nothing tests for them
+
+// Everything a slab reads from global memory before its first step; fetched one slab ahead so
+// that every wavefront always has a slab's worth of loads in flight (without it the kernel is
+// bound by HBM latency: ~3 TB/s whatever the content).
+template <int K>
+struct SlabIn {
+    uint32_t px[K];              // pixel t*64 + lane of the slab
+    uint32_t carry0;             // pixel before the slab (qoi.h:396-399 start value for slab 0)
+    uint32_t next_first;         // first pixel of the next slab
+    uint32_t tab_loc, tab_far;   // entry colour table: group-local part / image-level part (lane = slot)
+    u64 tab_valid;
+    int le_loc, le_far;          // last edge before the slab: group-local / image-level
+};
+
+template <int CH, int K>
+__device__ __forceinline__ void load_slab(const EncParams& p, uint32_t g, uint32_t lane, SlabIn<K>& in) {
     const uint32_t img = g / p.spi, s = g - img * p.spi;
     const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
     const uint32_t n = p.npx, lo = s * (64u * K);
-    uint8_t* stage8 = reinterpret_cast<uint8_t*>(L.stage);
-    uint8_t* table8 = reinterpret_cast<uint8_t*>(L.table);
+    if (lo + 64u * K < n) {                                  // interior slab: no bounds checks
+#pragma unroll
+        for (int t = 0; t < K; ++t) in.px[t] = load_px<CH>(pix, lo + t * 64u + lane);
+        in.next_first = load_px<CH>(pix, lo + 64u * K);
+    } else {
+#pragma unroll
+        for (int t = 0; t < K; ++t) { const uint32_t i = lo + t * 64u + lane; in.px[t] = i < n ? load_px<CH>(pix, i) : 0u; }
+        in.next_first = 0;
+    }
+    in.carry0 = (lo > 0) ? load_px<CH>(pix, lo - 1) : kInitPx;
+    const uint32_t G = img * p.gpi + (s >> 6);
+    in.tab_loc = p.ent_tab[(size_t)g * 64u + lane];
+    in.tab_far = p.gent_tab[(size_t)G * 64u + lane];
+    in.tab_valid = p.ent_valid[g];
+    in.le_loc = p.ent_le[g];
+    in.le_far = p.gent_le[G];
+}
 
-    // ---- entry state: colour table + last edge position ------------------------------
+template <int CH, int K, int PROBE, bool LAST, int ABL>
+__device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, uint32_t lane, EncLds<K>& L, const SlabIn<K>& in) {
+    const uint32_t img = g / p.spi, s = g - img * p.spi;
+    const uint32_t n = p.npx, lo = s * (64u * K);
+    uint8_t* stage8 = reinterpret_cast<uint8_t*>(L.stage);
+    const uint32_t* cur = in.px;
+    // same value in every lane, but loaded into VGPRs: make them provably wave-uniform
+    const uint32_t carry0 = __builtin_amdgcn_readfirstlane(in.carry0);
+    const uint32_t next_first = __builtin_amdgcn_readfirstlane(in.next_first);
+
+    // ---- entry state: colour table + distance to the last edge ---------------------------
     {
-        const uint32_t G = img * p.gpi + (s >> 6);
-        const uint32_t loc = p.ent_tab[(size_t)g * 64u + lane];
-        const uint32_t far = p.gent_tab[(size_t)G * 64u + lane];
-        const u64 lv = p.ent_valid[g];
-        L.table[lane] = ((lv >> lane) & 1ull) ? loc : far;
+        const u64 lv = uniform64(in.tab_valid);
+        L.table[lane] = ((lv >> lane) & 1ull) ? in.tab_loc : in.tab_far;
         if (PROBE == 0) L.mask[lane] = 0;
     }
-    int last_edge = max(p.ent_le[g], p.gent_le[img * p.gpi + (s >> 6)]);   // max edge position < lo, or -1
-    uint32_t carry = (lo > 0) ? load_px<CH>(pix, lo - 1) : kInitPx;
+    const int last_edge = max(__builtin_amdgcn_readfirstlane(in.le_loc), __builtin_amdgcn_readfirstlane(in.le_far));   // max edge position < lo, or -1
+    // ccp = 63 + (first pixel of the step - last edge before the step): stands in for clz(edges below the lane)
+    uint32_t ccp = 63u + (uint32_t)((int)lo - last_edge);
     __builtin_amdgcn_wave_barrier();
 
-    const u64 lane_bit = 1ull << lane;
-    const u64 below = lane_bit - 1ull;
+    // lane constants
+    const uint32_t below_lo = lane < 32u ? (1u << lane) - 1u : 0xFFFFFFFFu;
+    const uint32_t below_hi = lane < 32u ? 0u : (1u << (lane - 32u)) - 1u;
+    const uint32_t lane_run = lane + 128u + kLenOne;       // + clz(edges below) = 0xBF + run length, tagged 1-byte
+    uint32_t tbase = lds_addr(L.table);                    // 256-byte aligned
+    asm volatile("" : "+v"(tbase));                        // keep in a VGPR: slot address = one v_and_or
+    const uint32_t sbase = lds_addr(L.stage);
 
-    uint32_t cur[kEncUnroll], nxt[kEncUnroll];
+    uint32_t spos = 0;                                     // bytes staged so far (wave-uniform)
+    // edges of step 0
+    uint32_t prev_n = from_lane_below(cur[0], carry0);
+    u64 E = __ballot(cur[0] != prev_n);
+    if (LAST) { const uint32_t r = n - lo; if (r < 64u) E &= (1ull << r) - 1ull; }
 #pragma unroll
-    for (int u = 0; u < kEncUnroll; ++u) {
-        const uint32_t i = lo + u * 64u + lane;
-        cur[u] = (!LAST || i < n) ? load_px<CH>(pix, i) : 0u;
-    }
-    uint32_t slab_pos = 0;                                 // bytes staged so far (wave-uniform)
-#pragma unroll 1
-    for (int t0 = 0; t0 < K; t0 += kEncUnroll) {
-        if (t0 + kEncUnroll < K) {                          // prefetch the next group's pixels
-#pragma unroll
-            for (int u = 0; u < kEncUnroll; ++u) {
-                const uint32_t i = lo + (uint32_t)(t0 + kEncUnroll + u) * 64u + lane;
-                nxt[u] = (!LAST || i < n) ? load_px<CH>(pix, i) : 0u;
+    for (int t = 0; t < K; ++t) {
+        const uint32_t px = cur[t];
+        const uint32_t prev = prev_n;
+        const u64 Ec = E;
+        // ---- lane masks of this step -------------------------------------------------------
+        u64 V = ~0ull, lastbit = 0ull;                     // LAST: valid lanes, lane of the image's last pixel
+        if (LAST) {
+            const int r = (int)(n - lo) - t * 64;         // pixels of the image left at this step
+            V = r >= 64 ? ~0ull : (r <= 0 ? 0ull : (1ull << r) - 1ull);
+            lastbit = (r >= 1 && r <= 64) ? 1ull << (r - 1) : 0ull;
+        }
+        // edges of the next step (its lane 0 tells lane 63 whether its run ends here)
+        u64 nb;
+        if (t + 1 < K) {
+            prev_n = prev_pixels(cur[t + 1], px);
+            E = __ballot(cur[t + 1] != prev_n);
+            if (LAST) { const int r = (int)(n - lo) - (t + 1) * 64; E &= r >= 64 ? ~0ull : (r <= 0 ? 0ull : (1ull << r) - 1ull); }
+            nb = E & 1ull;
+        } else {
+            nb = LAST ? 0ull : (u64)scalar_ne(next_first, read_lane(px, 63));    // 1: the next slab starts with an edge
+        }
+        if (LAST && V == 0ull) continue;
+        const u64 En = (Ec >> 1) | (nb << 63) | lastbit;  // lanes whose successor is an edge (or that end the image)
+        const u64 NE = ~Ec & V;                            // repeat pixels
+        u64 RB = NE & En;                                  // repeat pixels that close a run: they carry its run byte
+
+        // ---- repeats: run byte 0xC0|(run-1) on the pixel that closes a run (qoi.h:416-421,425-428) ----
+        // clz of the edges below the lane; ccp stands in when the run began before this step
+        uint32_t w;
+        {
+            const uint32_t fhi = ffbh((uint32_t)(Ec >> 32) & below_hi);
+            const uint32_t flo = ffbh((uint32_t)Ec & below_lo) | 32u;
+            const uint32_t m = min(min(fhi, flo), ccp);
+            w = m + lane_run;                              // 0xBF + count (tagged), count = repeats since the last edge
+            if (__ballot(w > (0xFCu | kLenOne)) & NE) {    // some run reaches 62: wave-uniform slow path (flat content)
+                const uint32_t cnt = w - (0xBFu | kLenOne);
+                const uint32_t xm = cnt % 62u;
+                w = (xm ? 0xBFu + xm : 0xFDu) | kLenOne;   // a repeat landing on a multiple of 62 closes a full run
+                RB |= NE & __ballot(xm == 0u);
             }
         }
-#pragma unroll
-        for (int u = 0; u < kEncUnroll; ++u) {
-            const uint32_t base = lo + (uint32_t)(t0 + u) * 64u;
-            const uint32_t i = base + lane;
-            const uint32_t px = cur[u];
-            const uint32_t prev = from_lane_below(px, carry);
-            carry = read_lane(px, 63);
-            const bool inb = !LAST || i < n;
-            const bool edge = LAST ? (inb && px != prev) : (px != prev);
-            const u64 E = __ballot(edge);
-
-            // d = distance to the last edge strictly before this pixel (>= 1)
-            const u64 eb = E & below;
-            const uint32_t d = eb ? lane - (uint32_t)msb64(eb) : lane + (uint32_t)((int)base - last_edge);
-            if (E) last_edge = (int)base + msb64(E);
-            const uint32_t x = d - (edge ? 1u : 0u);
-            uint32_t xm = x;
-            if (__ballot(x >= 62u)) {                     // wave-uniform: long runs are rare in busy content
-                xm = x % 62u;
-                asm volatile("" : "+v"(xm));              // keep this a real branch (the divide is quarter-rate)
-            }
-            // an edge flushes pending repeats (qoi.h:425-428); a repeat flushes at 62 or at the last pixel (qoi.h:417)
-            bool er = edge ? (xm != 0u) : (xm == 0u);
-            if (LAST) er = inb && (er || (!edge && i == n - 1u));
-            const uint32_t runb = xm ? 0xBFu + xm : 0xFDu;    // 0xC0|(xm-1); a repeat landing on xm == 0 closes a run of 62
-
-            // ---- colour-table probe/update (qoi.h:430-436) for edge pixels -----------------
-            const uint32_t so = slot_byte_offset(px);
+        const u64 any = Ec | RB;                           // lanes that emit a chunk
+        if (Ec) {
+            ccp = (uint32_t)__builtin_clzll(Ec) + 64u;
+            // ---- colour-table probe/update (qoi.h:430-436) for edge pixels ---------------------
+            const uint32_t hsh = __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);   // 4 * QOI_COLOR_HASH (qoi.h:322)
             uint32_t seen = ~px;
             if (!(ABL & 4)) {
                 if (PROBE == 1) {
-                    // every lane exchanges (no exec-masked block -> the scheduler can overlap the LDS round trip
-                    // with the delta arithmetic below); repeats hit a private dummy word instead of the table
-                    const uint32_t addr = edge ? so : 256u + 4u * lane;
-                    seen = __hip_atomic_exchange(reinterpret_cast<uint32_t*>(table8 + addr), px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    seen = probe_swap((hsh & 0xFCu) | tbase, px, Ec);
                 } else {
+                    const uint32_t so = hsh & 0xFCu;
+                    const bool edge = in_mask(Ec);
+                    const u64 lane_bit = 1ull << lane;
                     if (edge) __hip_atomic_fetch_or(&L.mask[so >> 2], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     __builtin_amdgcn_wave_barrier();
                     const u64 same = edge ? L.mask[so >> 2] : 0ull;    // edge lanes of this step sharing the slot
                     const uint32_t tval = L.table[so >> 2];
                     __builtin_amdgcn_wave_barrier();
                     if (edge) L.mask[so >> 2] = 0;
-                    const u64 pred = same & below;
+                    const u64 pred = same & (lane_bit - 1ull);
                     const uint32_t pv = gather_lane(px, pred ? (uint32_t)msb64(pred) : lane);
                     seen = pred ? pv : tval;                           // nearest earlier same-slot edge, else carried table
                     if (edge && ((same >> lane) >> 1) == 0) L.table[so >> 2] = px;   // last lane per slot updates the table
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            const bool hit = edge && seen == px;
-
-            // ---- classes (qoi.h:432-474 priority: INDEX, then RGBA if alpha moved, DIFF, LUMA, RGB) ----
-            const int dr = (int)(int8_t)((px & 0xFF) - (prev & 0xFF));
-            const int dg = (int)(int8_t)(((px >> 8) & 0xFF) - ((prev >> 8) & 0xFF));
-            const int db = (int)(int8_t)(((px >> 16) & 0xFF) - ((prev >> 16) & 0xFF));
-            const int drg = (int)(int8_t)(dr - dg);
-            const int dbg = (int)(int8_t)(db - dg);
-            const bool lit = edge && !hit;
-            const bool c_rgba = lit && ((px ^ prev) >> 24) != 0;
-            const bool t_diff = ((unsigned)(dr + 2) | (unsigned)(dg + 2) | (unsigned)(db + 2)) < 4u;
-            const bool t_luma = (((unsigned)(dg + 32) >> 2) | (unsigned)(drg + 8) | (unsigned)(dbg + 8)) < 16u;
-            const bool c_diff = lit && !c_rgba && t_diff;
-            const bool c_luma = lit && !c_rgba && !t_diff && t_luma;
-            const bool c_rgb = lit && !c_rgba && !t_diff && !t_luma;
-            const bool c_one = hit || c_diff;             // 1-byte chunks
-            // length = ll + er with ll in {1 (c_one), 2 (c_luma), 4 (c_rgb), 5 (c_rgba)}: bit algebra on lane masks
-            const bool odd = c_one || c_rgba;
-            const bool l0 = odd != er, l1 = c_luma || (odd && er), l2 = c_rgb || c_rgba;
-            const u64 b0 = __ballot(l0), b1 = __ballot(l1), b2 = __ballot(l2);
-
-            if (!(ABL & 1)) {
-                // first byte / second byte of the literal chunk
-                const uint32_t diff_b = kTagDiff | ((dr + 2) << 4) | ((dg + 2) << 2) | (db + 2);
-                const uint32_t luma_b = (kTagLuma | (dg + 32)) | ((((drg + 8) << 4) | (dbg + 8)) << 8);
-                uint32_t w = (px << 8) | (c_rgba ? kTagRgba : kTagRgb);   // tag r g b   (a follows for RGBA)
-                w = c_luma ? luma_b : w;
-                w = c_diff ? diff_b : w;
-                w = hit ? (so >> 2) : w;
-                const uint32_t off = slab_pos + count_below(b0) + 2u * count_below(b1) + 4u * count_below(b2);
-                uint8_t* dst = stage8 + off;
-                if (er) dst[0] = (uint8_t)runb;
-                dst += er ? 1 : 0;
-                if (edge) dst[0] = (uint8_t)w;
-                if (__ballot(c_luma || l2)) {             // some lane has a multi-byte literal
-                    if (c_luma || l2) dst[1] = (uint8_t)(w >> 8);
-                    if (b2) {
-                        if (l2) { dst[2] = (uint8_t)(w >> 16); dst[3] = (uint8_t)(w >> 24); }
-                        if (c_rgba) dst[4] = (uint8_t)(px >> 24);
-                    }
+            // ---- chunk of an edge pixel (qoi.h:432-474): INDEX, else RGBA if alpha moved, else DIFF, LUMA, RGB ----
+            // wrapped byte deltas live in the low byte of d*; consumers sign-extend that byte (SDWA)
+            const uint32_t d_r = px - prev, d_g = sub_byte1(px, prev), d_b = sub_byte2(px, prev);
+            const uint32_t tr = (int)(int8_t)d_r + 2, tg = (int)(int8_t)d_g + 2, tb = (int)(int8_t)d_b + 2;
+            const uint32_t tg8 = (int)(int8_t)d_g - 6, ug = (int)(int8_t)d_g + 32;
+            const uint32_t ur = tr - tg8, ub = tb - tg8;   // dr-dg+8, db-dg+8
+            const bool is_diff = (tr | tg | tb) < 4u;
+            const bool is_luma = ((ug >> 2) | ur | ub) < 16u;
+            const bool is_ad = (px ^ prev) > 0x00FFFFFFu;  // alpha differs
+            const uint32_t w_diff = (kTagDiff | kLenOne) | (tr << 4) | (tg << 2) | tb;
+            const uint32_t w_luma = (kTagLuma | kLenTwo | ug) | (ur << 12) | (ub << 8);
+            uint32_t we = is_luma ? w_luma : kLenLong;
+            we = is_diff ? w_diff : we;
+            we = is_ad ? kLenLong : we;
+            asm volatile("" : "+v"(we));                   // keep the literal classes branch-free (no sinking under !hit)
+            if (PROBE == 1 && !(ABL & 4)) probe_wait(seen);
+            const bool is_hit = seen == px;
+            we = is_hit ? (((hsh >> 2) & 63u) | kLenOne) : we;         // QOI_OP_INDEX (qoi.h:432-434)
+            w = in_mask(Ec) ? we : w;
+            const u64 lng = __ballot(w >= kLenLong);
+            if (__builtin_expect(lng != 0ull, 0)) {
+                // rare in natural images: some lane carries QOI_OP_RGB / QOI_OP_RGBA (qoi.h:461-474)
+                const u64 five = lng & __ballot(is_ad);
+                const u64 two = __ballot(w >= kLenTwo) & ~lng;
+                const u64 b0 = (any & ~(two | lng)) | five;            // odd lengths: 1-byte chunks and RGBA
+                const uint32_t w_long = (px << 8) | (in_mask(five) ? kTagRgba : kTagRgb);   // tag r g b (a follows for RGBA)
+                w = in_mask(lng) ? w_long : w;
+                const uint32_t off = sbase + spos + count_below(b0) + 2u * count_below(two) + 4u * count_below(lng);
+                spos += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(two) + 4u * (uint32_t)__builtin_popcountll(lng);
+                if (!(ABL & 1)) {
+                    stage_short(off, w, any, two | lng);
+                    lds_u8* dst = (lds_u8*)off;
+                    if (in_mask(lng)) { dst[2] = (uint8_t)(w >> 16); dst[3] = (uint8_t)(w >> 24); }
+                    if (in_mask(five)) dst[4] = (uint8_t)(px >> 24);
                 }
+                continue;
             }
-            slab_pos += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) + 4u * (uint32_t)__builtin_popcountll(b2);
+        } else {
+            ccp += 64u;
         }
-#pragma unroll
-        for (int u = 0; u < kEncUnroll; ++u) cur[u] = nxt[u];
+        // ---- common case: chunk lengths 1 and 2 only.  offset = #chunks below + #LUMA chunks below ----
+        const u64 two = __ballot(w >= kLenTwo) & any;
+        const uint32_t off = count_below_from(two, count_below_from(any, sbase + spos));
+        spos += (uint32_t)__builtin_popcountll(any) + (uint32_t)__builtin_popcountll(two);
+        if (!(ABL & 1)) stage_short(off, w, any, two);
     }
+    const uint32_t slab_pos = spos;
 
     const uint32_t slab_bytes = slab_pos;
     if (p.scratch) {
@@ -397,33 +533,46 @@ __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, 
     }
 }
 
-template <int CH, int K, int PROBE, int ABL>
+// PREFETCH: a wavefront walks through quads_per_wg slabs and loads the next one while it encodes the
+// current one (costs 26 VGPRs = one wavefront per SIMD; measured slower on MI355X because the kernel is
+// VALU-bound, not latency-bound - kept selectable with QOIMI_ENC_PREFETCH=1).
+template <int CH, int K, int PROBE, int ABL, bool PREFETCH>
 __global__ __launch_bounds__(256) void enc_slabs(EncParams p) {
     __shared__ EncLds<K> s_lds[4];
     __shared__ uint32_t s_ticket;
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     // A workgroup serves image (blockIdx % n_images): the slabs in flight spread over all images, so
     // every per-image look-back chain has few unfinished predecessors.  Within its image the
-    // workgroup takes the next `quads_per_wg` groups of 4 slabs from the image's ticket counter:
-    // slab ids are handed out in START order, hence every predecessor a look-back can wait on
-    // is already running or finished (no reliance on dispatch order; guide G16).  One counter
-    // per image keeps the atomics off a single hot word.
+    // workgroup takes the next `quads_per_wg` groups of 4 slabs (one slab per wavefront and group);
+    // in look-back mode the groups are handed out by the image's ticket counter, i.e. in START
+    // order, hence every predecessor a look-back can wait on is already running or finished (no
+    // reliance on dispatch order; guide G16).  One counter per image keeps the atomics off a
+    // single hot word.
     const uint32_t img = blockIdx.x % p.n_images;
     uint32_t quad = blockIdx.x / p.n_images;              // order-free (scratch) mode: any order will do
     if (p.use_ticket && !p.scratch) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(&p.ticket[img], 1u);
         __syncthreads();
-        quad = s_ticket;
+        quad = __builtin_amdgcn_readfirstlane(s_ticket);
     }
     const uint32_t first_quad = quad * p.quads_per_wg;
+    uint32_t s_pos = first_quad * 4u + wave;
+    if (s_pos >= p.spi) return;
+    SlabIn<K> in;
+    load_slab<CH, K>(p, img * p.spi + s_pos, lane, in);
 #pragma unroll 1
     for (uint32_t r = 0; r < p.quads_per_wg; ++r) {
-        const uint32_t s_pos = (first_quad + r) * 4u + wave;
-        if (s_pos >= p.spi) return;
         const uint32_t g = img * p.spi + s_pos;
-        if (s_pos == p.spi - 1u) encode_one_slab<CH, K, PROBE, true, ABL>(p, g, lane, s_lds[wave]);
-        else encode_one_slab<CH, K, PROBE, false, ABL>(p, g, lane, s_lds[wave]);
+        const uint32_t s_next = s_pos + 4u;
+        const bool more = r + 1u < p.quads_per_wg && s_next < p.spi;
+        SlabIn<K> nxt;
+        if (PREFETCH && more) load_slab<CH, K>(p, g + 4u, lane, nxt);  // next slab's loads fly while this one is encoded
+        if (s_pos == p.spi - 1u) encode_one_slab<CH, K, PROBE, true, ABL>(p, g, lane, s_lds[wave], in);
+        else encode_one_slab<CH, K, PROBE, false, ABL>(p, g, lane, s_lds[wave], in);
+        if (!more) return;
         __builtin_amdgcn_wave_barrier();
+        if (PREFETCH) in = nxt; else load_slab<CH, K>(p, g + 4u, lane, in);
+        s_pos = s_next;
     }
 }
 
@@ -466,7 +615,7 @@ __global__ __launch_bounds__(256) void enc_offsets(EncParams p) {
 // E4b: move every slab's bytes from its scratch slot to its place in the stream
 // (one wavefront per slab; aligned 16-byte stores, source re-aligned with v_alignbyte).
 __global__ __launch_bounds__(256) void enc_compact(EncParams p) {
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t g = blockIdx.x * 4u + wave;
     if (g >= p.n_images * p.spi) return;
     const uint32_t img = g / p.spi;
@@ -539,7 +688,7 @@ __global__ __launch_bounds__(64) void lds_order_selftest(uint32_t* out) {
 // ---------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------
-template <int CH, int K, int PROBE, int ABL>
+template <int CH, int K, int PROBE, int ABL, bool PREFETCH>
 static void launch_encode_t(const EncParams& p, hipStream_t st, KernelTimer* tm) {
     const uint32_t total = p.n_images * p.spi;
     const uint32_t blocks = (total + 3u) / 4u;
@@ -552,7 +701,7 @@ static void launch_encode_t(const EncParams& p, hipStream_t st, KernelTimer* tm)
     tm->mark(kT_enc_scan_images, st);
     const uint32_t quads_per_image = (p.spi + 3u) / 4u;
     const uint32_t wgs_per_image = (quads_per_image + p.quads_per_wg - 1u) / p.quads_per_wg;
-    hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL>), dim3(wgs_per_image * p.n_images), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL, PREFETCH>), dim3(wgs_per_image * p.n_images), dim3(256), 0, st, p);
     tm->mark(kT_enc_slabs, st);
     if (p.scratch) {
         hipLaunchKernelGGL(enc_offsets, dim3(p.n_images), dim3(256), 0, st, p);
@@ -563,18 +712,16 @@ static void launch_encode_t(const EncParams& p, hipStream_t st, KernelTimer* tm)
 }
 
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm) {
-    const int abl = p.ablate;
     if (p.channels == 3) {
-        if (p.probe_xchg) launch_encode_t<3, kEncSteps, 1, 0>(p, st, tm); else launch_encode_t<3, kEncSteps, 0, 0>(p, st, tm);
+        if (p.probe_xchg) launch_encode_t<3, kEncSteps, 1, 0, false>(p, st, tm); else launch_encode_t<3, kEncSteps, 0, 0, false>(p, st, tm);
         return;
     }
-    if (!p.probe_xchg) { launch_encode_t<4, kEncSteps, 0, 0>(p, st, tm); return; }
-    switch (abl) {   // ablation variants exist for profiling only (QOIMI_ENC_ABLATE); outputs are then invalid
-        case 1: launch_encode_t<4, kEncSteps, 1, 1>(p, st, tm); break;
-        case 2: launch_encode_t<4, kEncSteps, 1, 2>(p, st, tm); break;
-        case 4: launch_encode_t<4, kEncSteps, 1, 4>(p, st, tm); break;
-        case 7: launch_encode_t<4, kEncSteps, 1, 7>(p, st, tm); break;
-        default: launch_encode_t<4, kEncSteps, 1, 0>(p, st, tm); break;
+    if (!p.probe_xchg) { launch_encode_t<4, kEncSteps, 0, 0, false>(p, st, tm); return; }
+    if (p.prefetch) { launch_encode_t<4, kEncSteps, 1, 0, true>(p, st, tm); return; }
+    switch (p.ablate) {   // ablation variants exist for profiling only (QOIMI_ENC_ABLATE); outputs are then invalid
+        case 1: launch_encode_t<4, kEncSteps, 1, 1, false>(p, st, tm); break;
+        case 4: launch_encode_t<4, kEncSteps, 1, 4, false>(p, st, tm); break;
+        default: launch_encode_t<4, kEncSteps, 1, 0, false>(p, st, tm); break;
     }
 }
 

@@ -75,7 +75,7 @@ struct qoimi_ctx {
     uint32_t seg_bytes = 2048;  // decode segment size
     uint32_t* last_enc_err = nullptr;   // device flag of the most recent encode launch
     bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
-    int enc_ablate = 0, enc_ticket = 1, enc_quads = 0;   // tuning / profiling knobs (env QOIMI_ENC_*)
+    int enc_ablate = 0, enc_ticket = 1, enc_quads = 0, enc_prefetch = 0;   // tuning / profiling knobs (env QOIMI_ENC_*)
     int enc_lookback = 0;               // 1: single-pass decoupled look-back instead of scratch + compaction
     KernelTimer timer;                  // optional per-kernel HIP-event timing
     double prof_ms[kT_count] = {0};     // accumulated kernel milliseconds since profiling was (re)enabled
@@ -114,6 +114,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_ABLATE")) c->enc_ablate = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_TICKET")) c->enc_ticket = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_QUADS")) c->enc_quads = atoi(e);
+    if (const char* e = getenv("QOIMI_ENC_PREFETCH")) c->enc_prefetch = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
     if (const char* e = getenv("QOIMI_SEG_BYTES")) {
         long v = atol(e);
@@ -204,7 +205,13 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.use_ticket = c->enc_ticket ? 1 : 0;
     p.ablate = (uint8_t)c->enc_ablate;
     const size_t T = (size_t)p.n_images * p.spi, G = (size_t)p.n_images * p.gpi;
-    p.quads_per_wg = c->enc_quads > 0 ? (uint32_t)c->enc_quads : (p.spi / (uint32_t)n_images > 16384u ? 4u : 1u);
+    {   // slabs one wavefront walks through (it prefetches the next while it encodes one): enough of them that
+        // the load latency is hidden, few enough that the grid still fills 256 CUs x 6 workgroups several times
+        const size_t total_quads = (size_t)n_images * ((p.spi + 3u) / 4u);
+        size_t r = c->enc_prefetch ? total_quads / 6144u : 1u;
+        p.prefetch = c->enc_prefetch ? 1 : 0;
+        p.quads_per_wg = c->enc_quads > 0 ? (uint32_t)c->enc_quads : (uint32_t)(r < 1 ? 1 : (r > 16 ? 16 : r));
+    }
     if (T > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (slab index overflows 32 bits)");
 
     for (int pass = 0; pass < 2; ++pass) {      // pass 0 measures, pass 1 carves

@@ -42,6 +42,7 @@ struct EncParams {
     uint8_t probe_xchg;      // 1: ds_wrxchg colour-table probe (needs the LDS order self-test to have passed)
     uint8_t use_ticket;      // 1: slab ids by atomic ticket (start order); 0: by blockIdx
     uint8_t ablate;          // profiling only
+    uint8_t prefetch;        // 1: wavefronts walk quads_per_wg slabs and prefetch the next one
     uint32_t quads_per_wg;   // consecutive 4-slab groups one workgroup walks through
     // workspace
     uint32_t* sum_tab;   u64* sum_valid;  int* sum_le;     // E1 out        [n_images*spi]
