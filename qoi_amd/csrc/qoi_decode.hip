@@ -43,113 +43,148 @@ __device__ __forceinline__ uint32_t find_image_by_group(const DecImage* __restri
 }
 
 // ---------------------------------------------------------------------------------
-// LaneReader: sequential byte source of one lane (see file header).
-// Ring of RD dwords per lane; consumption is at most 5 bytes per step (longest chunk,
-// qoi.h:552-557), refill() must be called by the whole wavefront every kPeriod steps.
+// LaneReader: byte source of one lane (see file header).  Ring of RD dwords per lane in LDS
+// ([dword][lane] layout, bank = lane) plus one mirror dword (slot RD repeats slot 0), so the two
+// dwords that hold a chunk's first bytes are always at ring[k] and ring[k + 1]: a chunk is read with
+// ONE ds_read2_b32 at its byte position and one v_alignbit - no shifting window, no per-chunk
+// top-up.  A step consumes at most 5 bytes (longest chunk, qoi.h:552-557); refill() must be
+// called by the whole wavefront every kPeriod steps: it lands the 16-byte loads issued one
+// period earlier (their latency hides behind the chunk arithmetic) and issues the next ones.
 // ---------------------------------------------------------------------------------
-struct LaneReader {
-    static constexpr uint32_t RD = 16;          // ring dwords per lane
-    static constexpr uint32_t kPeriod = 4;      // steps between refills: <= 20 bytes consumed, 32 fetched
-    uint32_t* ring;            // &lds[0][lane]; dword k of the ring at ring[k * 64]
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// Stream bytes are read through GLOBAL-address-space pointers.  Left generic, hipcc emits flat_load here (the
+// pointer travels through struct members and loop phis); a FLAT load in flight counts on both vmcnt and lgkmcnt
+// and may return out of order with LDS data, so every wait for an LDS read would also drain the prefetch loads.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const u32x4 gconst_u32x4;
+__device__ __forceinline__ uint4 load_global16(const uint8_t* p) {
+    const u32x4 v = *(gconst_u32x4*)(uintptr_t)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+
+// RD_: ring dwords per lane (power of two).  NP_: 16-byte loads a lane keeps in flight.  PERIOD_: steps
+// between refills.  The passes are bound by the latency of these per-lane streams (a lane consumes ~1.2
+// bytes per step; with 32 bytes in flight it waits for memory every few steps), so bytes in flight per
+// lane is the number that matters: ring 128 B + 64 B in flight here.  Invariant (dwords, o = landed and
+// unread): a period consumes <= 5*PERIOD_ bytes (+5 for the one-chunk look-ahead of the callers), a refill
+// tops the ring up in 16-byte pieces; with RD_=32, NP_=4, PERIOD_=8: o >= 17 after every refill, so the 8 bytes
+// a peek reads are always there.
+template <int RD_, int NP_, int PERIOD_>
+struct LaneReaderT {
+    static constexpr uint32_t RD = RD_;
+    static constexpr uint32_t kSlots = RD + 1;
+    static constexpr uint32_t kPeriod = PERIOD_;
+    static_assert((RD_ & (RD_ - 1)) == 0 && RD_ >= 16, "ring size");
+    static_assert(4 * RD_ - 16 - 12 - (5 * PERIOD_ + 5) >= 8 + 3, "ring too small for the period");
+    uint32_t ring;             // LDS byte address of ring[0][lane]; dword k of the ring at ring + k*256
     const uint8_t* abase;      // 16-byte aligned start of the fetched range
     const uint8_t* aend;       // first byte that must not be read (stream + size)
-    uint32_t rd, wr;           // dwords pulled from / written to the ring, counted from abase
-    u64 win; uint32_t nv;      // register window: next nv (>= 5) stream bytes
-    uint4 pend0, pend1; uint32_t npend;
+    uint32_t aoff;             // abase - stream: stream position p sits at ring byte (p - aoff)
+    uint32_t wr;               // dwords landed in the ring, counted from abase
+    uint4 pend[NP_]; uint32_t npend;
 
     __device__ __forceinline__ uint4 load16(const uint8_t* p) const {
         // an aligned 16-byte granule that starts inside the stream never crosses a page
-        return p < aend ? *reinterpret_cast<const uint4*>(p) : make_uint4(0u, 0u, 0u, 0u);
+        return p < aend ? load_global16(p) : make_uint4(0u, 0u, 0u, 0u);
     }
-    __device__ __forceinline__ void put4(uint32_t at, const uint4& v) {
-        ring[((at + 0u) & (RD - 1u)) * 64u] = v.x; ring[((at + 1u) & (RD - 1u)) * 64u] = v.y;
-        ring[((at + 2u) & (RD - 1u)) * 64u] = v.z; ring[((at + 3u) & (RD - 1u)) * 64u] = v.w;
+    __device__ __forceinline__ void put4(uint32_t at, const uint4& v) {       // at: multiple of 4
+        const uint32_t a = ring + (at & (RD - 1u)) * 256u;
+        lds_u32* q = (lds_u32*)a;
+        q[0] = v.x; q[64] = v.y; q[128] = v.z; q[192] = v.w;
+        if ((at & (RD - 1u)) == 0u) ((lds_u32*)ring)[RD * 64u] = v.x;         // mirror of slot 0
     }
-    __device__ __forceinline__ void pull() {
-        const uint32_t d = ring[(rd & (RD - 1u)) * 64u];
-        win |= (u64)d << (8u * nv);
-        nv += 4u; ++rd;
-    }
-    __device__ __forceinline__ void top_up() { if (nv <= 4u) pull(); if (nv <= 4u) pull(); }
-
-    __device__ __forceinline__ void init(uint32_t* lds_col, const uint8_t* stream, uint32_t pos0, uint32_t size) {
-        ring = lds_col;
+    __device__ __forceinline__ void init(uint32_t ring_addr, const uint8_t* stream, uint32_t pos0, uint32_t size) {
+        ring = ring_addr;
         const uint8_t* p = stream + pos0;
         abase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)15);
         aend = stream + size;
+        aoff = pos0 - (uint32_t)(p - abase);
 #pragma unroll
         for (uint32_t r = 0; r < RD / 4u; ++r) put4(4u * r, load16(abase + 16u * r));
         wr = RD; npend = 0;
-        const uint32_t skip = (uint32_t)(p - abase);
-        rd = skip >> 2;
-        const uint32_t d = ring[rd * 64u]; ++rd;
-        win = (u64)(d >> (8u * (skip & 3u))); nv = 4u - (skip & 3u);
-        top_up();
     }
-    __device__ __forceinline__ u64 peek() const { return win; }
-    __device__ __forceinline__ void advance(uint32_t n) { win >>= 8u * n; nv -= n; top_up(); }
-    // wave-uniform call: land the loads issued one period ago, issue the next ones
-    __device__ __forceinline__ void refill() {
-        if (npend > 0u) { put4(wr, pend0); wr += 4u; }
-        if (npend > 1u) { put4(wr, pend1); wr += 4u; }
-        const uint32_t space = RD - (wr - rd);
-        npend = min(2u, space >> 2);
-        if (npend > 0u) pend0 = load16(abase + (size_t)wr * 4u);
-        if (npend > 1u) pend1 = load16(abase + (size_t)wr * 4u + 16u);
+    // chunk bytes 0..3 (w32) and byte 4 (b5) of the chunk at stream position pos
+    __device__ __forceinline__ void peek(uint32_t pos, uint32_t& w32, uint32_t& b5) const {
+        const uint32_t rp = pos - aoff;
+        const lds_u32* q = (const lds_u32*)(ring + ((rp >> 2) & (RD - 1u)) * 256u);
+        const uint32_t d0 = q[0], d1 = q[64];
+        const uint32_t sh = (rp & 3u) * 8u;
+        w32 = __builtin_amdgcn_alignbit(d1, d0, sh);
+        b5 = (d1 >> sh) & 0xFFu;
     }
+    // wave-uniform call; pos = the lane's current stream position
+    __device__ __forceinline__ void refill(uint32_t pos) {
+#pragma unroll
+        for (int i = 0; i < NP_; ++i) if ((uint32_t)i < npend) put4(wr + 4u * i, pend[i]);
+        wr += 4u * npend;
+        const uint32_t space = RD - (wr - ((pos - aoff) >> 2));
+        npend = min((uint32_t)NP_, space >> 2);
+#pragma unroll
+        for (int i = 0; i < NP_; ++i) if ((uint32_t)i < npend) pend[i] = load16(abase + (size_t)wr * 4u + 16u * i);
+    }
+    __device__ __forceinline__ bool due(uint32_t it) const { return (it % kPeriod) == 0u; }
 };
+typedef LaneReaderT<16, 2, 4> LaneReader;
+
+// 256-entry chunk table (qoi_decode_core.h: lut_entry) in LDS; built by the first 256 threads / by 64 lanes x 4
+struct LdsLut {
+    uint32_t delta[256], info[256];
+};
+__device__ __forceinline__ void build_lut(LdsLut& L, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t b = tid; b < 256u; b += nthreads) lut_entry(b, L.delta[b], L.info[b]);
+    __syncthreads();
+}
 
 // ---------------------------------------------------------------------------------
-// LaneWriter: pixel sink of one lane; pixels are gathered per 16-pixel aligned group in LDS
-// ([k][lane] layout) and leave as whole 64-byte (OCH 4) / 48-byte (OCH 3) lines.
+// LaneWriter: pixel sink of one lane.  A lane produces its segment's pixels in order into a 16-pixel
+// ring in LDS ([k][lane] layout, 4 KiB per wavefront); drain() writes every complete, 4-pixel aligned
+// group as one 16-byte (OCH 4) / 12-byte (OCH 3) store.  The kernels drain once per block of steps,
+// right before they issue their next stream loads: the stores are then OLDER than the loads the
+// wavefront next waits for, so no step ever waits for a store acknowledgement (memory operations
+// retire in order; a store issued after the loads would make every wait for the loads a wait for the
+// store as well).  Pixels of a group shared with the neighbouring segment (head / tail) are written
+// one by one.
 // ---------------------------------------------------------------------------------
 template <int OCH>
 struct LaneWriter {
-    uint32_t* buf;        // &lds[0][lane]; pixel k of the group at buf[k * 64]
+    static constexpr uint32_t kRing = 16;
+    uint32_t row;         // LDS byte address of row[0][lane]; pixel i at row + (i & 15)*256
     uint8_t* out;
     uint32_t ppos;        // next pixel index
-    uint32_t gstart;      // first pixel of the current group owned by this lane (head of a segment)
+    uint32_t fpos;        // first pixel still in the ring
 
-    __device__ __forceinline__ void init(uint32_t* lds_col, uint8_t* image, uint32_t px_pos) {
-        buf = lds_col; out = image; ppos = px_pos; gstart = px_pos & 15u;
+    __device__ __forceinline__ void init(uint32_t row_addr, uint8_t* image, uint32_t px_pos) {
+        row = row_addr; out = image; ppos = px_pos; fpos = px_pos;
     }
-    __device__ __forceinline__ void flush(uint32_t base, uint32_t hi) {     // pixels [base+gstart, base+hi)
-        if (gstart == 0u && hi == 16u) {
-            uint32_t v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = buf[k * 64];
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return *(const lds_u32*)(row + (i & (kRing - 1u)) * 256u); }
+    __device__ __forceinline__ void store_one(uint32_t i, uint32_t px) {
+        if (OCH == 4) reinterpret_cast<uint32_t*>(out)[i] = px;
+        else { uint8_t* d = out + (size_t)i * 3u; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
+    }
+    // write out every complete aligned group; a leading partial group (segment head) pixel by pixel
+    __device__ __forceinline__ void drain() {
+        while ((fpos & 3u) != 0u && fpos < ppos) { store_one(fpos, at(fpos)); ++fpos; }
+        while (fpos + 4u <= ppos) {
+            const uint32_t v0 = at(fpos), v1 = at(fpos + 1u), v2 = at(fpos + 2u), v3 = at(fpos + 3u);
             if (OCH == 4) {
-                uint4* d = reinterpret_cast<uint4*>(out + (size_t)base * 4u);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) d[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-            } else {
-                uint4* d = reinterpret_cast<uint4*>(out + (size_t)base * 3u);  // 48*(base/16): 16-byte aligned
-                uint32_t w[12];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {                  // 4 pixels -> 3 dwords of packed r,g,b
-                    const uint32_t a = v[4 * k] & 0xFFFFFFu, b = v[4 * k + 1] & 0xFFFFFFu, c = v[4 * k + 2] & 0xFFFFFFu, e = v[4 * k + 3] & 0xFFFFFFu;
-                    w[3 * k] = a | (b << 24); w[3 * k + 1] = (b >> 8) | (c << 16); w[3 * k + 2] = (c >> 16) | (e << 8);
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) d[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+                *reinterpret_cast<uint4*>(out + (size_t)fpos * 4u) = make_uint4(v0, v1, v2, v3);
+            } else {                                                      // 4 pixels -> 3 dwords of packed r,g,b
+                const uint32_t a = v0 & 0xFFFFFFu, b = v1 & 0xFFFFFFu, c = v2 & 0xFFFFFFu, e = v3 & 0xFFFFFFu;
+                uint32_t* d = reinterpret_cast<uint32_t*>(out + (size_t)fpos * 3u);
+                d[0] = a | (b << 24); d[1] = (b >> 8) | (c << 16); d[2] = (c >> 16) | (e << 8);
             }
-        } else {
-            for (uint32_t k = gstart; k < hi; ++k) {
-                const uint32_t px = buf[k * 64u];
-                if (OCH == 4) reinterpret_cast<uint32_t*>(out)[base + k] = px;
-                else { uint8_t* d = out + (size_t)(base + k) * 3u; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
-            }
+            fpos += 4u;
         }
-        gstart = 0u;
     }
     __device__ __forceinline__ void put(uint32_t px) {
-        buf[(ppos & 15u) * 64u] = px;
+        if (__builtin_expect(ppos - fpos == kRing, 0)) drain();           // only long runs fill the ring between drains
+        *(lds_u32*)(row + (ppos & (kRing - 1u)) * 256u) = px;
         ++ppos;
-        if ((ppos & 15u) == 0u) flush(ppos - 16u, 16u);
     }
-    __device__ __forceinline__ void finish() {
-        const uint32_t hi = ppos & 15u;
-        if (hi > gstart) flush(ppos & ~15u, hi);
+    __device__ __forceinline__ void finish() {                            // everything left, tail group pixel by pixel
+        drain();
+        while (fpos < ppos) { store_one(fpos, at(fpos)); ++fpos; }
     }
 };
 
@@ -157,8 +192,10 @@ struct LaneWriter {
 // P1: parse summaries (lane = segment)
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dec_parse(DecParams p) {
-    __shared__ uint32_t s_ring[4][LaneReader::RD * 64];
+    __shared__ uint32_t s_ring[4][LaneReader::kSlots * 64];
+    __shared__ LdsLut s_lut;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    build_lut(s_lut, threadIdx.x, 256u);
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
     const bool have = q < p.total_segs;
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
@@ -168,21 +205,220 @@ __global__ __launch_bounds__(256) void dec_parse(DecParams p) {
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
     const uint8_t* stream = p.streams + im.stream_off;
     LaneReader R;
-    R.init(&s_ring[wave][lane], stream, base, im.chunks_end + kTrailerBytes);
+    R.init(lds_addr_of(&s_ring[wave][lane]), stream, base, im.chunks_end + kTrailerBytes);
+    // Five chains (one per possible entry phase) until they stand on the same byte - a chain's next
+    // position depends only on the byte it stands on, so chains that meet stay together - then ONE cursor.
     ParseState s; parse_init(s, base);
-    uint32_t m = base;
+    uint32_t m = base, add = 0;
+    bool merged = false;
     bool active = have && m < end;
     for (uint32_t it = 0; __ballot(active); ++it) {
-        if ((it & (LaneReader::kPeriod - 1u)) == 0u) R.refill();
+        if (R.due(it)) R.refill(m);
         if (active) {
-            parse_step(s, m, (uint32_t)R.peek() & 0xFFu);
-            const uint32_t m2 = parse_front(s);
-            R.advance(m2 - m);
-            m = m2;
+            uint32_t w32, b5; R.peek(m, w32, b5);
+            const uint32_t b1 = w32 & 0xFFu;
+            if (!merged) {
+                parse_step(s, m, b1);
+                m = parse_front(s);
+                merged = s.p0 == s.p1 && s.p1 == s.p2 && s.p2 == s.p3 && s.p3 == s.p4;
+            } else {
+                add += lut_pixels(s_lut.info[b1]);
+                m += len_of(b1);
+            }
             active = m < end;
         }
     }
+    if (merged) {
+        s.p0 = s.p1 = s.p2 = s.p3 = s.p4 = m;
+        s.c0 += add; s.c1 += add; s.c2 += add; s.c3 += add; s.c4 += add;
+    }
     if (have) { ParseRec r; parse_finish(s, base, p.seg_bytes, r); p.parse[q] = r; }
+}
+
+
+// ---------------------------------------------------------------------------------
+// Fine-grained P1 / P2.  These two passes write only a few bytes per segment, so a segment is cut
+// into 128-byte pieces, one LANE per piece, and the pieces' records are composed back into the
+// segment's record inside the kernel (both records compose associatively).  A wavefront then runs
+// ~100 steps instead of ~1700 and the grid has 16x the wavefronts: the lane-per-segment versions are
+// bound by the serial instruction stream of their few, long-lived wavefronts (each step costs a
+// wavefront ~9 cycles per instruction), not by memory or by the SIMDs.  A lane's 128 bytes (+ the 8
+// bytes a chunk that starts at its end may reach, + alignment) are loaded up front into a LINEAR
+// per-lane LDS buffer ([dword][lane]): no ring, no refill.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t slot_pack(const SlotRec& r) {
+    return r.hc | ((uint32_t)r.h_rel << 8) | ((uint32_t)r.h_alpha << 9) | ((uint32_t)r.a_abs << 10) | ((uint32_t)r.ac << 16);
+}
+__device__ __forceinline__ SlotRec slot_unpack(uint32_t w) {
+    SlotRec t; t.hc = w & 63u; t.h_rel = (w >> 8) & 1u; t.h_alpha = (w >> 9) & 1u; t.a_abs = (w >> 10) & 1u; t.ac = (w >> 16) & 0xFFu;
+    return t;
+}
+
+constexpr uint32_t kFineBytes = 128;
+constexpr uint32_t kFinePieces = 10;                    // 16-byte loads per lane: 15 (alignment) + 128 + 8 <= 160
+constexpr uint32_t kFineDwords = kFinePieces * 4;
+
+struct FineBuf {
+    uint32_t buf;              // LDS byte address of buf[0][lane]; dword k at buf + k*256
+    uint32_t aoff;             // stream position of buffer byte 0
+    __device__ __forceinline__ void init(uint32_t buf_addr, const uint8_t* stream, uint32_t pos0, uint32_t size) {
+        buf = buf_addr;
+        const uint8_t* p = stream + pos0;
+        const uint8_t* abase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)15);
+        const uint8_t* aend = stream + size;
+        aoff = pos0 - (uint32_t)(p - abase);
+        uint4 v[kFinePieces];
+#pragma unroll
+        for (uint32_t r = 0; r < kFinePieces; ++r)
+            v[r] = abase + 16u * r < aend ? load_global16(abase + 16u * r) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (uint32_t r = 0; r < kFinePieces; ++r) {
+            lds_u32* q = (lds_u32*)(buf + r * 1024u);
+            q[0] = v[r].x; q[64] = v[r].y; q[128] = v[r].z; q[192] = v[r].w;
+        }
+    }
+    __device__ __forceinline__ uint32_t byte(uint32_t pos) const {
+        const uint32_t rp = pos - aoff;
+        const uint32_t d = *(const lds_u32*)(buf + (rp >> 2) * 256u);
+        return (d >> ((rp & 3u) * 8u)) & 0xFFu;
+    }
+    __device__ __forceinline__ void peek(uint32_t pos, uint32_t& w32, uint32_t& b5) const {
+        const uint32_t rp = pos - aoff;
+        const lds_u32* q = (const lds_u32*)(buf + (rp >> 2) * 256u);
+        const uint32_t d0 = q[0], d1 = q[64];
+        const uint32_t sh = (rp & 3u) * 8u;
+        w32 = __builtin_amdgcn_alignbit(d1, d0, sh);
+        b5 = (d1 >> sh) & 0xFFu;
+    }
+};
+
+__global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
+    __shared__ uint32_t s_buf[4][kFineDwords * 64];
+    __shared__ uint32_t s_rec[4][64][6];          // per lane: exit map, pixels[5]
+    __shared__ uint32_t s_res[4][64][2];          // per (group, entry phase): exit phase, pixels
+    __shared__ LdsLut s_lut;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    build_lut(s_lut, threadIdx.x, 256u);
+    const uint32_t G = p.fine_per_seg, gs = p.fine_shift;
+    const uint32_t F = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t q = F >> gs, sub = F & (G - 1u);
+    const bool have = q < p.total_segs;
+    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
+    const DecImage im = p.images[img];
+    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
+    const uint32_t cbase = (uint32_t)kHeaderBytes + j * p.seg_bytes;
+    const uint32_t cend = min(cbase + p.seg_bytes, im.chunks_end);
+    const uint32_t base = cbase + sub * kFineBytes;
+    const uint32_t end = min(base + kFineBytes, cend);
+    FineBuf R;
+    R.init(lds_addr_of(&s_buf[wave][lane]), p.streams + im.stream_off, min(base, im.chunks_end), im.chunks_end + kTrailerBytes);
+    // five chains (one per possible entry phase) until they stand on the same byte, then ONE cursor
+    ParseState s; parse_init(s, base);
+    uint32_t m = base;
+    bool merged = false;
+    bool active = have && m < end;
+    while (__ballot(active && !merged)) {
+        if (active && !merged) {
+            parse_step(s, m, R.byte(m));
+            m = parse_front(s);
+            merged = s.p0 == s.p1 && s.p1 == s.p2 && s.p2 == s.p3 && s.p3 == s.p4;
+            active = m < end;
+        }
+    }
+    uint32_t add = 0;
+    while (__ballot(active)) {
+        if (active) {
+            const uint32_t b1 = R.byte(m);
+            add += lut_pixels(s_lut.info[b1]);
+            m += len_of(b1);
+            active = m < end;
+        }
+    }
+    if (merged) {
+        s.p0 = s.p1 = s.p2 = s.p3 = s.p4 = m;
+        s.c0 += add; s.c1 += add; s.c2 += add; s.c3 += add; s.c4 += add;
+    }
+    ParseRec r; parse_finish(s, base, kFineBytes, r);
+    if (have) p.fine_exit[F] = (uint16_t)r.exit_phase;
+    // compose the G (8..64) pieces of every segment: lane `sub` = e < 5 walks the pieces for entry phase e
+    s_rec[wave][lane][0] = r.exit_phase;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s_rec[wave][lane][1 + k] = r.pixels[k];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t g0 = lane - sub;                      // first lane of this segment's group
+    if (sub < 5u) {
+        uint32_t ph = sub, tot = 0;
+        for (uint32_t k = 0; k < G; ++k) {
+            tot += s_rec[wave][g0 + k][1u + ph];
+            ph = (s_rec[wave][g0 + k][0] >> (3u * ph)) & 7u;
+        }
+        s_res[wave][lane][0] = ph; s_res[wave][lane][1] = tot;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (have && sub == 0u) {
+        ParseRec o; o.exit_phase = 0;
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            o.exit_phase |= s_res[wave][lane + e][0] << (3 * e);
+            o.pixels[e] = s_res[wave][lane + e][1];
+        }
+        p.parse[q] = o;
+    }
+}
+
+// P2 on 128-byte pieces: entry phase of a piece from the segment's entry phase and the exit maps of the
+// pieces before it (written by dec_parse_fine), then the slot transfers of the pieces are composed in order.
+__global__ __launch_bounds__(256) void dec_slot_walk_fine(DecParams p) {
+    __shared__ uint32_t s_buf[4][kFineDwords * 64];
+    __shared__ uint32_t s_x[4][64];
+    __shared__ LdsLut s_lut;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    build_lut(s_lut, threadIdx.x, 256u);
+    const uint32_t G = p.fine_per_seg, gs = p.fine_shift;
+    const uint32_t F = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t q = F >> gs, sub = F & (G - 1u);
+    bool have = q < p.total_segs;
+    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
+    const DecImage im = p.images[img];
+    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
+    have = have && j >= im.start_seg && j < im.n_active;
+    if (!__ballot(have)) return;
+    const uint32_t cbase = (uint32_t)kHeaderBytes + j * p.seg_bytes;
+    const uint32_t cend = min(cbase + p.seg_bytes, im.chunks_end);
+    const uint32_t base = cbase + sub * kFineBytes;
+    const uint32_t end = min(base + kFineBytes, cend);
+    FineBuf R;
+    R.init(lds_addr_of(&s_buf[wave][lane]), p.streams + im.stream_off, min(base, im.chunks_end), im.chunks_end + kTrailerBytes);
+    // entry phase of this piece
+    s_x[wave][lane] = have ? p.fine_exit[F] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t g0 = lane - sub;
+    uint32_t ph = have ? p.entry_phase[q] : 0u;
+    for (uint32_t k = 0; k + 1u < G; ++k) {
+        const uint32_t mp = s_x[wave][g0 + k];
+        if (k < sub) ph = (mp >> (3u * ph)) & 7u;
+    }
+    uint32_t pos = base + ph;
+    SlotFast s; slotf_init(s);
+    bool active = have && pos < end;
+    while (__ballot(active)) {
+        if (active) {
+            uint32_t w32, b5; R.peek(pos, w32, b5);
+            const uint32_t b1 = w32 & 0xFFu;
+            slotf_step(s, w32, b5, s_lut.info[b1]);
+            pos += len_of(b1);
+            active = pos < end;
+        }
+    }
+    SlotRec r; slotf_finish(s, r);
+    __builtin_amdgcn_wave_barrier();
+    s_x[wave][lane] = slot_pack(r);
+    __builtin_amdgcn_wave_barrier();
+    if (have && sub == 0u) {
+        SlotRec acc = {0, 1, 0, 0, 0};
+        for (uint32_t k = 0; k < G; ++k) acc = slot_compose(acc, slot_unpack(s_x[wave][lane + k]));
+        p.slot_rec[q] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -280,8 +516,10 @@ __global__ __launch_bounds__(64) void dec_chain_parse_l3(DecParams p) {
 // P2: speculative slot/alpha transfer (lane = segment)
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dec_slot_walk(DecParams p) {
-    __shared__ uint32_t s_ring[4][LaneReader::RD * 64];
+    __shared__ uint32_t s_ring[4][LaneReader::kSlots * 64];
+    __shared__ LdsLut s_lut;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    build_lut(s_lut, threadIdx.x, 256u);
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
     bool have = q < p.total_segs;
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
@@ -293,28 +531,20 @@ __global__ __launch_bounds__(256) void dec_slot_walk(DecParams p) {
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
     uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
     LaneReader R;
-    R.init(&s_ring[wave][lane], p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
-    SlotState s; slot_init(s);
+    R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
+    SlotFast s; slotf_init(s);
     bool active = have && pos < end;
     for (uint32_t it = 0; __ballot(active); ++it) {
-        if ((it & (LaneReader::kPeriod - 1u)) == 0u) R.refill();
+        if (R.due(it)) R.refill(pos);
         if (active) {
-            const Chunk c = crack(R.peek());
-            slot_step(s, c);
-            R.advance(c.len);
-            pos += c.len;
+            uint32_t w32, b5; R.peek(pos, w32, b5);
+            const uint32_t b1 = w32 & 0xFFu;
+            slotf_step(s, w32, b5, s_lut.info[b1]);
+            pos += len_of(b1);
             active = pos < end;
         }
     }
-    if (have) { SlotRec r; slot_finish(s, r); p.slot_rec[q] = r; }
-}
-
-__device__ __forceinline__ uint32_t slot_pack(const SlotRec& r) {
-    return r.hc | ((uint32_t)r.h_rel << 8) | ((uint32_t)r.h_alpha << 9) | ((uint32_t)r.a_abs << 10) | ((uint32_t)r.ac << 16);
-}
-__device__ __forceinline__ SlotRec slot_unpack(uint32_t w) {
-    SlotRec t; t.hc = w & 63u; t.h_rel = (w >> 8) & 1u; t.h_alpha = (w >> 9) & 1u; t.a_abs = (w >> 10) & 1u; t.ac = (w >> 16) & 0xFFu;
-    return t;
+    if (have) { SlotRec r; slotf_finish(s, r); p.slot_rec[q] = r; }
 }
 
 // S2 l1: compose the transfers of the group's segments that are still to be decoded
@@ -388,8 +618,10 @@ struct LdsSymTab {
 
 __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     __shared__ sym_t s_tab[64 * 64];
-    __shared__ uint32_t s_ring[LaneReader::RD * 64];
+    __shared__ uint32_t s_ring[LaneReader::kSlots * 64];
+    __shared__ LdsLut s_lut;
     const uint32_t lane = lane_id();
+    build_lut(s_lut, lane, 64u);
     const uint32_t q = blockIdx.x * 64u + lane;
     bool have = q < p.total_segs;
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
@@ -401,18 +633,24 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
     uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
     LaneReader R;
-    R.init(&s_ring[lane], p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
+    R.init(lds_addr_of(&s_ring[lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
     LdsSymTab tab{&s_tab[lane]};
     SymState s; sym_init(s, have ? p.slot_in[q] : 0u, have ? p.alpha_in[q] : 0u, tab);
     bool active = have && pos < end;
-    for (uint32_t it = 0; __ballot(active); ++it) {
-        if ((it & (LaneReader::kPeriod - 1u)) == 0u) R.refill();
-        if (active) {
-            const Chunk c = crack(R.peek());
-            sym_step(s, c, tab);
-            R.advance(c.len);
-            pos += c.len;
-            active = pos < end;
+    uint32_t w32, b5; R.peek(pos, w32, b5);
+    // blocks of kPeriod steps: the stream loads issued by refill() are waited for at the NEXT refill only
+    while (__ballot(active)) {
+        R.refill(pos);
+#pragma unroll
+        for (uint32_t u = 0; u < LaneReader::kPeriod; ++u) {
+            if (active) {
+                const uint32_t b1 = w32 & 0xFFu;
+                const uint32_t npos = pos + len_of(b1);
+                uint32_t nw32, nb5; R.peek(npos, nw32, nb5);      // next chunk's bytes travel while this one is executed
+                symf_step(s, w32, b5, s_lut.delta[b1], s_lut.info[b1], tab.get(b1 & 63u), tab);
+                pos = npos; w32 = nw32; b5 = nb5;
+                active = pos < end;
+            }
         }
     }
     if (have) {
@@ -514,12 +752,42 @@ struct LdsTab32 {
     __device__ __forceinline__ void set(uint32_t k, uint32_t v) { col[k * 64u] = v; }
 };
 
+// Device forms of the byte-wise pixel arithmetic: one SDWA add per channel (the result's low byte lands in
+// the selected byte of acc, the other bytes are preserved) instead of a 5-op SWAR add.
+__device__ __forceinline__ void add_byte0(uint32_t& acc, uint32_t b) {
+    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0" : "+v"(acc) : "v"(b));
+}
+__device__ __forceinline__ void add_byte1(uint32_t& acc, uint32_t b) {
+    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1" : "+v"(acc) : "v"(b));
+}
+__device__ __forceinline__ void add_byte2(uint32_t& acc, uint32_t b) {
+    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2" : "+v"(acc) : "v"(b));
+}
+__device__ __forceinline__ void add_byte2_from0(uint32_t& acc, uint32_t b) {     // acc.byte2 += b.byte0
+    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0" : "+v"(acc) : "v"(b));
+}
+// px + (dr,dg,db) of a relative chunk (qoi.h:561-572); delta0/info from the chunk table, w32 = chunk bytes 0..3
+__device__ __forceinline__ uint32_t apply_relative(uint32_t px, uint32_t w32, uint32_t delta0, uint32_t info) {
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)info, 28, 1);        // all ones for LUMA
+    const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m;                   // b2 >> 4
+    const uint32_t eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;                    // b2 & 15
+    uint32_t r = px;
+    add_byte0(r, delta0); add_byte1(r, delta0); add_byte2(r, delta0);
+    add_byte0(r, er); add_byte2_from0(r, eb);
+    return r;
+}
+
+// P4 main loop, written for few instructions per step: a wavefront of this kernel runs alone on its SIMD
+// most of the time (the 16 KiB of private colour tables per wavefront bound the residency), so its speed is
+// (instructions per step) x (~9 cycles).  The next chunk's bytes are fetched while the current one executes.
 template <int OCH>
 __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
     __shared__ uint32_t s_tab[64 * 64];
-    __shared__ uint32_t s_ring[LaneReader::RD * 64];
-    __shared__ uint32_t s_out[16 * 64];
+    __shared__ uint32_t s_ring[LaneReader::kSlots * 64];
+    __shared__ uint32_t s_out[LaneWriter<OCH>::kRing * 64];
+    __shared__ LdsLut s_lut;
     const uint32_t lane = lane_id();
+    build_lut(s_lut, lane, 64u);
     const uint32_t q = blockIdx.x * 64u + lane;
     bool have = q < p.total_segs;
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
@@ -531,28 +799,58 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
     uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
     LaneReader R;
-    R.init(&s_ring[lane], p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
+    R.init(lds_addr_of(&s_ring[lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
     LaneWriter<OCH> W;
-    W.init(&s_out[lane], p.pixels + (size_t)img * p.pixel_stride, have ? p.px_off[q] : 0u);
+    W.init(lds_addr_of(&s_out[lane]), p.pixels + (size_t)img * p.pixel_stride, have ? p.px_off[q] : 0u);
     LdsTab32 tab{&s_tab[lane]};
+    const uint32_t tab_base = lds_addr_of(&s_tab[lane]);
+    const uint32_t lut_base = lds_addr_of(&s_lut.delta[0]);
     const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
     uint32_t px = 0;
     if (have) {
-        for (uint32_t k = 0; k < 64u; ++k) tab.set(k, ent[k]);
+        for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {          // 16 loads in flight, then 16 LDS writes
+            uint32_t v[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) v[k] = ent[k0 + k];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) tab.set(k0 + k, v[k]);
+        }
         px = ent[64];
     }
     const uint32_t limit = im.npx;
     bool active = have && pos < end && W.ppos < limit;
-    for (uint32_t it = 0; __ballot(active); ++it) {
-        if ((it & (LaneReader::kPeriod - 1u)) == 0u) R.refill();
-        if (active) {
-            const Chunk c = crack(R.peek());
-            px = pixel_step(px, c, tab);
-            const uint32_t n = min(chunk_run(c), limit - W.ppos);      // over-long run clipped (Appendix B item 8)
-            for (uint32_t k = 0; k < n; ++k) W.put(px);
-            R.advance(c.len);
-            pos += c.len;
-            active = pos < end && W.ppos < limit;
+    uint32_t w32, b5; R.peek(pos, w32, b5);
+    // blocks of kPeriod steps; per block: pixel stores first, then the next stream loads (see LaneWriter)
+    while (__ballot(active)) {
+        W.drain();
+        R.refill(pos);
+#pragma unroll
+        for (uint32_t u = 0; u < LaneReader::kPeriod; ++u) {
+            if (active) {
+                const uint32_t b1 = w32 & 0xFFu;
+                // chunk table (delta, info) and the colour-table slot the tag byte may name, in flight together
+                const lds_u32* lq = (const lds_u32*)(lut_base + b1 * 4u);
+                const uint32_t delta0 = lq[0], info = lq[256];
+                const uint32_t t = *(const lds_u32*)(tab_base + ((w32 & 63u) << 8));
+                // next chunk's bytes travel while this one is executed
+                const uint32_t npos = pos + len_of(b1);
+                uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
+                // the four ways a chunk sets the pixel (qoi.h:547-575)
+                const uint32_t rel = apply_relative(px, w32, delta0, info);
+                const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);                     // r,g,b,a = chunk bytes 1..4
+                const uint32_t rgbv = (px & 0xFF000000u) | (rgba & 0x00FFFFFFu);
+                const bool hi = lut_hi(info), lo = lut_lo(info);
+                const uint32_t a = lo ? t : rel, b = lo ? rgba : rgbv;
+                px = hi ? b : a;
+                // index[QOI_COLOR_HASH(px) % 64] = px after every chunk (qoi.h:577)
+                const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
+                *(lds_u32*)(tab_base + ((h & 63u) << 8)) = px;
+                uint32_t rem = min(lut_pixels(info), limit - W.ppos);      // over-long run clipped (Appendix B item 8)
+                pos = npos; w32 = nw32; b5 = nb5;
+                W.put(px);                                                 // rem >= 1: the lane was below the pixel limit
+                if (--rem) { do { W.put(px); } while (--rem); }            // QOI_OP_RUN (qoi.h:573-575)
+                active = pos < end && W.ppos < limit;
+            }
         }
     }
     if (have) {
@@ -561,7 +859,13 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
             // exit state must equal what the next segment was started from
             const uint32_t* __restrict__ nxt = ent + 65u;
             bool same = nxt[64] == px;
-            for (uint32_t k = 0; k < 64u; ++k) same = same && (nxt[k] == tab.get(k));
+            for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {
+                uint32_t v[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) v[k] = nxt[k0 + k];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) same = same && (v[k] == tab.get(k0 + k));
+            }
             if (!same) {
                 uint32_t* fx = p.fix + (size_t)(q + 1u) * 65u;
                 for (uint32_t k = 0; k < 64u; ++k) fx[k] = tab.get(k);
@@ -623,7 +927,8 @@ __global__ __launch_bounds__(64) void dec_prepare_restart(DecParams p) {
 void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
     tm->mark(kT_begin, st);
     if (p.total_segs) {
-        hipLaunchKernelGGL(dec_parse, dim3((p.total_segs + 255u) / 256u), dim3(256), 0, st, p);
+        if (p.fine_per_seg) hipLaunchKernelGGL(dec_parse_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(dec_parse, dim3((p.total_segs + 255u) / 256u), dim3(256), 0, st, p);
         tm->mark(kT_dec_parse, st);
         hipLaunchKernelGGL(dec_chain_parse_l1, dim3(p.total_grps), dim3(64), 0, st, p);
     }
@@ -637,7 +942,8 @@ void launch_decode_round(const DecParams& p, int out_channels, hipStream_t st, K
     if (!p.total_segs) return;
     const uint32_t b256 = (p.total_segs + 255u) / 256u, b64 = (p.total_segs + 63u) / 64u;
     tm->mark(kT_begin, st);
-    hipLaunchKernelGGL(dec_slot_walk, dim3(b256), dim3(256), 0, st, p);
+    if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_walk_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(dec_slot_walk, dim3(b256), dim3(256), 0, st, p);
     tm->mark(kT_dec_slot_walk, st);
     hipLaunchKernelGGL(dec_chain_slots_l1, dim3(p.total_grps), dim3(64), 0, st, p);
     hipLaunchKernelGGL(dec_chain_slots_l2, dim3(p.n_images), dim3(64), 0, st, p);

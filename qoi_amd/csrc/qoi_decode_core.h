@@ -304,4 +304,195 @@ QOIMI_HD uint32_t decode_segment(const uint8_t* in, uint32_t pos, uint32_t seg_e
     return px;
 }
 
+
+// =====================================================================================
+// Lean per-chunk primitives used by the kernels (the functions above are the readable
+// statement of the same steps; tests/host/decode_host.cpp checks both against the oracle).
+//
+// Everything that depends on the tag byte alone comes from a 256-entry table (LDS on the
+// device): a chunk step is then a handful of selects instead of a branch-free re-derivation
+// of every field (PMC: the first version spent 92..130 VALU ops per chunk and pass).
+//   delta   packed (dr,dg,db,0): DIFF delta; LUMA base (vg-8, vg, vg-8); else 0
+//   info    bits 0..2   chunk length (1,2,4,5)                         qoi.h:547-575
+//           bits 3..8   pixels produced (1, RUN: 1..62)               qoi.h:573-575
+//           bits 9..14  slot shift of the chunk: lin_hash(delta) & 63 (LUMA: of its base)
+//           bit  28     LUMA (second byte adds (b2>>4) to r and (b2&15) to b, qoi.h:566-571)
+//           bits 30,31  op class: 0 relative (DIFF/LUMA/RUN), 1 INDEX, 2 RGB, 3 RGBA
+// =====================================================================================
+QOIMI_HD void lut_entry(uint32_t b, uint32_t& delta, uint32_t& info) {
+    const uint32_t top = b >> 6;
+    uint32_t len = 1, npx = 1, code = 0, luma = 0;
+    delta = 0;
+    if (b == 0xFEu) { len = 4; code = 2; }
+    else if (b == 0xFFu) { len = 5; code = 3; }
+    else if (top == 0u) { code = 1; }
+    else if (top == 1u) { delta = diff_delta(b); }
+    else if (top == 2u) { len = 2; luma = 1; delta = luma_delta(b, 0u); }
+    else { npx = (b & 0x3Fu) + 1u; }
+    info = len | (npx << 3) | ((lin_hash(delta) & 63u) << 9) | (luma << 28) | (code << 30);
+}
+QOIMI_HD uint32_t lut_len(uint32_t info) { return info & 7u; }
+QOIMI_HD uint32_t lut_pixels(uint32_t info) { return (info >> 3) & 63u; }
+QOIMI_HD uint32_t lut_slot_shift(uint32_t info) { return (info >> 9) & 63u; }
+QOIMI_HD bool lut_hi(uint32_t info) { return (int32_t)info < 0; }              // RGB or RGBA
+QOIMI_HD bool lut_lo(uint32_t info) { return (int32_t)(info << 1) < 0; }       // INDEX or RGBA
+// chunk length from the tag byte by arithmetic (keeps the LDS round trip of the table out of the
+// byte-cursor's dependency chain)
+QOIMI_HD uint32_t len_of(uint32_t b1) {
+    const uint32_t base = (0x1211u >> ((b1 >> 6) << 2)) & 0xFu;        // 1,1,2,1 by the two top bits
+    return b1 >= 0xFEu ? b1 - 0xFAu : base;                             // 0xFE -> 4, 0xFF -> 5
+}
+// second byte of a LUMA chunk as packed (b2>>4, 0, b2&15, 0); 0 for every other chunk.  w32 = chunk bytes 0..3
+QOIMI_HD uint32_t luma_extra(uint32_t w32, uint32_t info) {
+    const uint32_t m = (uint32_t)(((int32_t)(info << 3)) >> 31);        // all ones for LUMA
+    return (((w32 >> 12) & 0x0000000Fu) | ((w32 << 8) & 0x000F0000u)) & m;
+}
+
+// ---- P1, single chain (after the five entry-phase chains have met) --------------------
+// ---- P2: speculative slot/alpha transfer, same function as slot_step ------------------
+struct SlotFast { uint32_t hc, ac, fl; };     // fl: bit0 h_rel, bit1 h_alpha, bit2 a_abs
+QOIMI_HD void slotf_init(SlotFast& s) { s.hc = 0; s.ac = 0; s.fl = 1u; }
+QOIMI_HD void slotf_step(SlotFast& s, uint32_t w32, uint32_t b5, uint32_t info) {
+    const uint32_t b1 = w32 & 0xFFu;
+    const uint32_t rgb = w32 >> 8;                                       // r,g,b (RGB / RGBA payload)
+    const uint32_t lrgb = lin_hash(rgb);
+    const uint32_t ex = luma_extra(w32, info);
+    const uint32_t rel = s.hc + lut_slot_shift(info) + 3u * (ex & 0xFFu) + 7u * (ex >> 16);
+    const bool a_abs = (s.fl & 4u) != 0u;
+    const uint32_t hc_rgb = lrgb + (a_abs ? 11u * s.ac : 0u);
+    const uint32_t hc_rgba = lrgb + 11u * b5;
+    const bool hi = lut_hi(info), lo = lut_lo(info);                     // (hi,lo): 00 rel, 01 INDEX, 10 RGB, 11 RGBA
+    const uint32_t a = lo ? b1 : rel, b = lo ? hc_rgba : hc_rgb;
+    s.hc = (hi ? b : a) & 63u;
+    // flags: rel keeps all; INDEX: h_rel=0,h_alpha=0; RGB: h_rel=0,h_alpha=!a_abs; RGBA: h_rel=0,h_alpha=0,a_abs=1
+    const uint32_t f_index = s.fl & 4u;
+    const uint32_t f_rgb = (s.fl & 4u) | (a_abs ? 0u : 2u);
+    const uint32_t fa = lo ? f_index : s.fl, fb = lo ? 4u : f_rgb;
+    s.fl = hi ? fb : fa;
+    s.ac = (hi && lo) ? b5 : s.ac;
+}
+QOIMI_HD void slotf_finish(const SlotFast& s, SlotRec& r) {
+    r.hc = (uint8_t)s.hc; r.h_rel = (uint8_t)(s.fl & 1u); r.h_alpha = (uint8_t)((s.fl >> 1) & 1u);
+    r.a_abs = (uint8_t)((s.fl >> 2) & 1u); r.ac = (uint8_t)s.ac;
+}
+
+// ---- P3: symbolic step, same function as sym_step --------------------------------------
+// t = tab.get(b1 & 63), read by the caller (issued early on the device)
+template <class Tab>
+QOIMI_HD void symf_step(SymState& s, uint32_t w32, uint32_t b5, uint32_t delta0, uint32_t info, sym_t t, Tab& tab) {
+    const uint32_t b1 = w32 & 0xFFu;
+    const uint32_t ex = luma_extra(w32, info);
+    const uint32_t delta = add_bytes(delta0, ex);
+    const uint32_t rgba = (w32 >> 8) | (b5 << 24), rgb = rgba & 0x00FFFFFFu;
+    const bool hi = lut_hi(info), lo = lut_lo(info);
+    const uint32_t pc_rel = add_bytes(s.pc, delta);
+    const uint32_t pc_rgb = (s.pc & 0xFF000000u) | rgb;
+    const uint32_t pa = lo ? (uint32_t)t : pc_rel, pb = lo ? rgba : pc_rgb;
+    const uint32_t ha = lo ? (uint32_t)(t >> 32) : s.ph, hb = lo ? (15u << 8) : (s.ph | (7u << 8));
+    s.pc = hi ? pb : pa;
+    s.ph = hi ? hb : ha;
+    const uint32_t lrgb = lin_hash(rgb);
+    const uint32_t s_rel = s.slot + lut_slot_shift(info) + 3u * (ex & 0xFFu) + 7u * (ex >> 16);
+    const uint32_t sa = lo ? b1 : s_rel, sb = lrgb + 11u * (lo ? b5 : s.alpha);
+    s.slot = (hi ? sb : sa) & 63u;
+    s.alpha = (hi && lo) ? b5 : s.alpha;
+    tab.set(s.slot, (sym_t)s.pc | ((sym_t)s.ph << 32));          // index update after every chunk (qoi.h:577)
+}
+
+// ---- P4: concrete step, same function as pixel_step --------------------------------------
+template <class Tab32>
+QOIMI_HD uint32_t pixelf_step(uint32_t px, uint32_t w32, uint32_t b5, uint32_t delta0, uint32_t info, uint32_t t, Tab32& tab) {
+    const uint32_t delta = add_bytes(delta0, luma_extra(w32, info));
+    const uint32_t rgba = (w32 >> 8) | (b5 << 24);
+    const uint32_t rel = add_bytes(px, delta);
+    const uint32_t rgbv = (px & 0xFF000000u) | (rgba & 0x00FFFFFFu);
+    const bool hi = lut_hi(info), lo = lut_lo(info);
+    const uint32_t a = lo ? t : rel, b = lo ? rgba : rgbv;
+    px = hi ? b : a;
+    tab.set(hash_px(px), px);
+    return px;
+}
+
+// Plain-pointer reader + table accessors for the host rehearsal and for slow paths.
+struct PtrReader {
+    const uint8_t* in;
+    QOIMI_HD void peek(uint32_t pos, uint32_t& w32, uint32_t& b5) const {
+        const unsigned long long w = load8(in + pos);
+        w32 = (uint32_t)w; b5 = (uint32_t)(w >> 32) & 0xFFu;
+    }
+};
+struct ChunkLutRef {            // host: plain arrays
+    uint32_t delta[256], info[256];
+    void build() { for (uint32_t b = 0; b < 256; ++b) lut_entry(b, delta[b], info[b]); }
+};
+
+// segment walkers on the lean primitives (host rehearsal; the kernels inline the same loops around their LDS reader)
+template <class Lut>
+QOIMI_HD void slot_walk_segment_fast(const uint8_t* in, uint32_t pos, uint32_t seg_end, const Lut& lut, SlotRec& r) {
+    PtrReader R{in};
+    SlotFast s; slotf_init(s);
+    while (pos < seg_end) {
+        uint32_t w32, b5; R.peek(pos, w32, b5);
+        slotf_step(s, w32, b5, lut.info[w32 & 0xFFu]);
+        pos += len_of(w32 & 0xFFu);
+    }
+    slotf_finish(s, r);
+}
+template <class Lut, class Tab>
+QOIMI_HD sym_t summarize_segment_fast(const uint8_t* in, uint32_t pos, uint32_t seg_end, uint32_t slot, uint32_t alpha,
+                                      const Lut& lut, Tab& tab) {
+    PtrReader R{in};
+    SymState s; sym_init(s, slot, alpha, tab);
+    while (pos < seg_end) {
+        uint32_t w32, b5; R.peek(pos, w32, b5);
+        const uint32_t b1 = w32 & 0xFFu;
+        symf_step(s, w32, b5, lut.delta[b1], lut.info[b1], tab.get(b1 & 63u), tab);
+        pos += len_of(b1);
+    }
+    return sym_pixel(s);
+}
+template <int OCH, class Lut, class Tab32>
+QOIMI_HD uint32_t decode_segment_fast(const uint8_t* in, uint32_t pos, uint32_t seg_end, uint32_t px, const Lut& lut, Tab32& tab,
+                                      uint8_t* out, uint32_t px_pos, uint32_t px_limit) {
+    PtrReader R{in};
+    while (pos < seg_end && px_pos < px_limit) {
+        uint32_t w32, b5; R.peek(pos, w32, b5);
+        const uint32_t b1 = w32 & 0xFFu, info = lut.info[b1];
+        px = pixelf_step(px, w32, b5, lut.delta[b1], info, tab.get(b1 & 63u), tab);
+        pos += len_of(b1);
+        uint32_t stop = px_pos + lut_pixels(info);
+        if (stop > px_limit) stop = px_limit;            // over-long run clipped (Appendix B item 8)
+        for (; px_pos < stop; ++px_pos) {
+            if (OCH == 4) {
+                reinterpret_cast<uint32_t*>(out)[px_pos] = px;
+            } else {
+                uint8_t* d = out + (size_t)px_pos * 3u;
+                d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16);
+            }
+        }
+    }
+    return px;
+}
+// P1 with the single-chain fast path: five chains until they have met, then one cursor
+template <class Lut>
+QOIMI_HD void parse_segment_fast(const uint8_t* in, uint32_t base, uint32_t seg_end, uint32_t B, const Lut& lut, ParseRec& r) {
+    ParseState s; parse_init(s, base);
+    uint32_t m = base;
+    while (m < seg_end && !(s.p0 == s.p1 && s.p1 == s.p2 && s.p2 == s.p3 && s.p3 == s.p4)) {
+        parse_step(s, m, in[m]);
+        m = parse_front(s);
+    }
+    uint32_t add = 0;
+    while (m < seg_end) {                                   // all five cursors stand on m
+        const uint32_t b1 = in[m];
+        add += lut_pixels(lut.info[b1]);
+        m += len_of(b1);
+    }
+    if (s.p0 == s.p1 && s.p1 == s.p2 && s.p2 == s.p3 && s.p3 == s.p4) {
+        s.p0 = s.p1 = s.p2 = s.p3 = s.p4 = m;
+        s.c0 += add; s.c1 += add; s.c2 += add; s.c3 += add; s.c4 += add;
+    }
+    parse_finish(s, base, B, r);
+}
+
 }  // namespace qoimi

@@ -77,6 +77,7 @@ struct qoimi_ctx {
     bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
     int enc_ablate = 0, enc_ticket = 1, enc_quads = 0, enc_prefetch = 0;   // tuning / profiling knobs (env QOIMI_ENC_*)
     int enc_lookback = 0;               // 1: single-pass decoupled look-back instead of scratch + compaction
+    int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
     KernelTimer timer;                  // optional per-kernel HIP-event timing
     double prof_ms[kT_count] = {0};     // accumulated kernel milliseconds since profiling was (re)enabled
     long long prof_calls[kT_count] = {0};
@@ -116,6 +117,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_QUADS")) c->enc_quads = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_PREFETCH")) c->enc_prefetch = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
     if (const char* e = getenv("QOIMI_SEG_BYTES")) {
         long v = atol(e);
         if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v;
@@ -294,11 +296,20 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
     const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
+    {   // P1/P2 on 128-byte pieces when a segment is 8, 16, 32 or 64 of them
+        const uint32_t g = B / 128u;
+        const bool ok = B % 128u == 0u && g >= 8u && g <= 64u && (g & (g - 1u)) == 0u && c->dec_fine;
+        p.fine_per_seg = ok ? g : 0u;
+        p.fine_shift = 0;
+        while (ok && (1u << p.fine_shift) < g) ++p.fine_shift;
+        if ((uint64_t)total * (p.fine_per_seg ? p.fine_per_seg : 1u) > 0xFFFFFF00ull) return fail(QOIMI_E_ARG, "batch too large (piece index overflows 32 bits)");
+    }
     for (int pass = 0; pass < 2; ++pass) {
         Carver w(pass ? c->dec_ws.base : nullptr);
         p.pending = w.take<uint32_t>(2); p.redo_segs = p.pending ? p.pending + 1 : nullptr;
         p.images = w.take<DecImage>((size_t)n_images);
         p.first_bad = w.take<uint32_t>((size_t)n_images);
+        p.fine_exit = w.take<uint16_t>(p.fine_per_seg ? Q * p.fine_per_seg : 1);
         p.parse = w.take<ParseRec>(Q); p.entry_phase = w.take<uint8_t>(Q); p.px_off = w.take<uint32_t>(Q);
         p.slot_rec = w.take<SlotRec>(Q); p.slot_in = w.take<uint8_t>(Q); p.alpha_in = w.take<uint8_t>(Q);
         p.summary = w.take<u64>(Q * 65); p.entry = w.take<uint32_t>(Q * 65); p.fix = w.take<uint32_t>(Q * 65);

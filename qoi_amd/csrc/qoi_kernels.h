@@ -85,6 +85,8 @@ struct DecParams {
     const uint8_t* streams;
     DecImage* images;      // device array [n_images]
     uint32_t n_images, total_segs, total_grps, seg_bytes;
+    uint32_t fine_per_seg, fine_shift;   // 128-byte pieces per segment for P1/P2 (8..64, power of two), 0: lane per segment
+    uint16_t* fine_exit;       // P1 fine: exit-phase map of every piece [total_segs * fine_per_seg]
     uint8_t* pixels; size_t pixel_stride;
     // workspace, per global segment q
     ParseRec* parse;           // P1

@@ -25,15 +25,34 @@ struct Tab32 { uint32_t v[64]; uint32_t get(uint32_t k) const { return v[k]; } v
 
 // returns 0; stats[0] = rounds, stats[1] = segments re-decoded, stats[2] = segments
 // GRP: segments per group of the two-level chains (the kernels use 64)
+static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
+                    uint8_t* out, long long* stats, bool fast);
 extern "C" int host_decode_pipeline_g(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
-                                      uint8_t* out, long long* stats);
+                                      uint8_t* out, long long* stats) {
+    return pipeline(in, size, npx, och, B, GRP, out, stats, false);
+}
+// same pipeline on the lean LUT-driven primitives the kernels use
+extern "C" int host_decode_pipeline_fast(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
+                                         uint8_t* out, long long* stats) {
+    return pipeline(in, size, npx, och, B, GRP, out, stats, true);
+}
 extern "C" int host_decode_pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B,
                                     uint8_t* out, long long* stats) {
     return host_decode_pipeline_g(in, size, npx, och, B, 64, out, stats);
 }
+// len_of / lut_entry against chunk_len / chunk_pixels for all 256 tag bytes; returns mismatches
+extern "C" int host_check_lut(void) {
+    ChunkLutRef lut; lut.build();
+    int bad = 0;
+    for (uint32_t b = 0; b < 256; ++b) {
+        if (len_of(b) != chunk_len(b) || lut_len(lut.info[b]) != chunk_len(b) || lut_pixels(lut.info[b]) != chunk_pixels(b)) ++bad;
+    }
+    return bad;
+}
 
-extern "C" int host_decode_pipeline_g(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
-                                      uint8_t* out, long long* stats) {
+static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
+                    uint8_t* out, long long* stats, bool fast) {
+    ChunkLutRef lut; lut.build();
     const uint32_t chunks_end = (uint32_t)size - 8u;
     const uint32_t nseg = (chunks_end - 14u + B - 1u) / B;
     std::vector<ParseRec> parse(nseg);
@@ -41,7 +60,7 @@ extern "C" int host_decode_pipeline_g(const uint8_t* in, int size, uint32_t npx,
     // P1
     for (uint32_t j = 0; j < nseg; ++j) {
         const uint32_t base = 14u + j * B, end = base + B < chunks_end ? base + B : chunks_end;
-        parse_segment(in, base, end, B, parse[j]);
+        if (fast) parse_segment_fast(in, base, end, B, lut, parse[j]); else parse_segment(in, base, end, B, parse[j]);
     }
     // S1, two-level like the kernels: (1) per group and entry phase: exit phase + pixels,
     // (2) chain the groups, (3) chain inside every group from its entry
@@ -87,7 +106,7 @@ extern "C" int host_decode_pipeline_g(const uint8_t* in, int size, uint32_t npx,
         // P2 + S2
         for (uint32_t j = start; j < n_active; ++j) {
             const uint32_t base = 14u + j * B, end = base + B < chunks_end ? base + B : chunks_end;
-            slot_walk_segment(in, base + phase[j], end, srec[j]);
+            if (fast) slot_walk_segment_fast(in, base + phase[j], end, lut, srec[j]); else slot_walk_segment(in, base + phase[j], end, srec[j]);
         }
         {   // S2, two-level: compose the transfers of each group, chain groups, apply inside groups
             const uint32_t g0 = start / GRP, g1 = (n_active + GRP - 1) / GRP;
@@ -111,7 +130,8 @@ extern "C" int host_decode_pipeline_g(const uint8_t* in, int size, uint32_t npx,
         for (uint32_t j = start; j < n_active; ++j) {
             const uint32_t base = 14u + j * B, end = base + B < chunks_end ? base + B : chunks_end;
             SymTab t;
-            const sym_t px = summarize_segment(in, base + phase[j], end, slot_in[j], alpha_in[j], t);
+            const sym_t px = fast ? summarize_segment_fast(in, base + phase[j], end, slot_in[j], alpha_in[j], lut, t)
+                                  : summarize_segment(in, base + phase[j], end, slot_in[j], alpha_in[j], t);
             for (int k = 0; k < 64; ++k) summary[(size_t)j * 65u + k] = t.v[k];
             summary[(size_t)j * 65u + 64u] = px;
         }
@@ -153,8 +173,10 @@ extern "C" int host_decode_pipeline_g(const uint8_t* in, int size, uint32_t npx,
             Tab32 t;
             memcpy(t.v, &entry[(size_t)j * 65u], 256);
             uint32_t px = entry[(size_t)j * 65u + 64u];
-            px = och == 4 ? decode_segment<4>(in, base + phase[j], end, px, t, out, px_off[j], npx)
-                          : decode_segment<3>(in, base + phase[j], end, px, t, out, px_off[j], npx);
+            if (fast) px = och == 4 ? decode_segment_fast<4>(in, base + phase[j], end, px, lut, t, out, px_off[j], npx)
+                                    : decode_segment_fast<3>(in, base + phase[j], end, px, lut, t, out, px_off[j], npx);
+            else px = och == 4 ? decode_segment<4>(in, base + phase[j], end, px, t, out, px_off[j], npx)
+                               : decode_segment<3>(in, base + phase[j], end, px, t, out, px_off[j], npx);
             if (j + 1 < n_active) {
                 const uint32_t* nxt = &entry[(size_t)(j + 1) * 65u];
                 if (nxt[64] != px || memcmp(nxt, t.v, 256) != 0) {

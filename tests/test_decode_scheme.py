@@ -25,19 +25,21 @@ def host_lib(tmp_path_factory):
     src = os.path.join(ROOT, "tests", "host", "decode_host.cpp")
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src], check=True)
     lib = ctypes.CDLL(out)
-    lib.host_decode_pipeline_g.restype = ctypes.c_int
-    lib.host_decode_pipeline_g.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32,
-                                           ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
+    for fn in (lib.host_decode_pipeline_g, lib.host_decode_pipeline_fast):
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32,
+                       ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
     return lib
 
 
-def run(lib, stream: bytes, och: int, B: int, grp: int = 64):
+def run(lib, stream: bytes, och: int, B: int, grp: int = 64, fast: bool = False):
     w, h = struct.unpack(">II", stream[4:12])
     npx = w * h
     buf = np.frombuffer(stream + b"\0" * 8, dtype=np.uint8).copy()
     out = np.full(npx * och + 8, 0xAB, dtype=np.uint8)
     stats = (ctypes.c_longlong * 4)()
-    lib.host_decode_pipeline_g(buf.ctypes.data, len(stream), npx, och, B, grp, out.ctypes.data, stats)
+    fn = lib.host_decode_pipeline_fast if fast else lib.host_decode_pipeline_g
+    fn(buf.ctypes.data, len(stream), npx, och, B, grp, out.ctypes.data, stats)
     return out[:npx * och], list(stats)
 
 
@@ -50,10 +52,16 @@ def test_scheme_matches_golden(host_lib, golden, encoded_streams):
         och = c["channels"] if c["channels"] else int(desc[2])
         want = golden[f"dec/{c['name']}/pixels"]
         for B, grp in ((5, 3), (7, 64), (16, 2), (64, 5), (333, 64), (2048, 64)):
-            got, stats = run(host_lib, c["stream"], och, B, grp)
-            assert np.array_equal(got, want), (c["name"], B, grp, stats)
+            for fast in (False, True):            # readable primitives and the lean LUT-driven ones the kernels use
+                got, stats = run(host_lib, c["stream"], och, B, grp, fast)
+                assert np.array_equal(got, want), (c["name"], B, grp, fast, stats)
         n += 1
     assert n > 100
+
+
+def test_chunk_lut_matches_grammar(host_lib):
+    """len_of / the 256-entry chunk table agree with chunk_len / chunk_pixels (qoi.h:547-575) for every tag byte."""
+    assert host_lib.host_check_lut() == 0
 
 
 def test_speculation_holds_on_encoder_streams(host_lib, port):
@@ -62,9 +70,10 @@ def test_speculation_holds_on_encoder_streams(host_lib, port):
         w, h = 256, 192
         px = synth.frame_rgba(kind, w, h, 2)
         s = port.encode(px, w, h, 4)
-        got, stats = run(host_lib, s, 4, 256)
-        assert np.array_equal(got, px.reshape(-1))
-        assert stats[0] == 1 and stats[1] == 0, (kind, stats)
+        for fast in (False, True):
+            got, stats = run(host_lib, s, 4, 256, 64, fast)
+            assert np.array_equal(got, px.reshape(-1))
+            assert stats[0] == 1 and stats[1] == 0, (kind, fast, stats)
 
 
 def test_uiflat_exact_even_if_restarts(host_lib, port):

@@ -25,5 +25,10 @@ with open(out+'/pmc_summary.txt','w') as fo:
         fo.write(k+'\n')
         for c in sorted(agg[k]):
             v=agg[k][c]; fo.write(f'   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.4g}\n')
-print(open(out+'/pmc_summary.txt').read()[:8000])
+keys=['SQ_WAVES','SQ_WAVE_CYCLES','SQ_INSTS_VALU','SQ_INSTS_SALU','SQ_INSTS_LDS','SQ_INSTS_VMEM_RD','SQ_INSTS_VMEM_WR','SQ_WAIT_ANY','SQ_WAIT_INST_ANY','SQ_ACTIVE_INST_VALU','SQ_ACTIVE_INST_LDS','SQ_LDS_BANK_CONFLICT','SQ_LDS_IDX_ACTIVE','GRBM_GUI_ACTIVE','FETCH_SIZE','WRITE_SIZE','TCC_HIT_sum','TCC_MISS_sum']
+import os
+flt=os.environ.get('PMC_FILTER','')
+for k in sorted(agg):
+    if flt and flt not in k: continue
+    print(k[:60]); print('   '+'  '.join(f"{c.replace('SQ_','')}={sum(agg[k][c])/len(agg[k][c]):.3g}" for c in keys if c in agg[k]))
 PY
