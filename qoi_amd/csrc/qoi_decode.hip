@@ -136,6 +136,31 @@ __device__ __forceinline__ void build_lut(LdsLut& L, uint32_t tid, uint32_t nthr
     __syncthreads();
 }
 
+// Device forms of the byte-wise pixel arithmetic: one SDWA add per channel (the result's low byte lands in
+// the selected byte of acc, the other bytes are preserved) instead of a 5-op SWAR add.
+__device__ __forceinline__ void add_byte0(uint32_t& acc, uint32_t b) {
+    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0" : "+v"(acc) : "v"(b));
+}
+__device__ __forceinline__ void add_byte1(uint32_t& acc, uint32_t b) {
+    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1" : "+v"(acc) : "v"(b));
+}
+__device__ __forceinline__ void add_byte2(uint32_t& acc, uint32_t b) {
+    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2" : "+v"(acc) : "v"(b));
+}
+__device__ __forceinline__ void add_byte2_from0(uint32_t& acc, uint32_t b) {     // acc.byte2 += b.byte0
+    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0" : "+v"(acc) : "v"(b));
+}
+// px + (dr,dg,db) of a relative chunk (qoi.h:561-572); delta0/info from the chunk table, w32 = chunk bytes 0..3
+__device__ __forceinline__ uint32_t apply_relative(uint32_t px, uint32_t w32, uint32_t delta0, uint32_t info) {
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)info, 28, 1);        // all ones for LUMA
+    const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m;                   // b2 >> 4
+    const uint32_t eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;                    // b2 & 15
+    uint32_t r = px;
+    add_byte0(r, delta0); add_byte1(r, delta0); add_byte2(r, delta0);
+    add_byte0(r, er); add_byte2_from0(r, eb);
+    return r;
+}
+
 // ---------------------------------------------------------------------------------
 // LaneWriter: pixel sink of one lane.  A lane produces its segment's pixels in order into a 16-pixel
 // ring in LDS ([k][lane] layout, 4 KiB per wavefront); drain() writes every complete, 4-pixel aligned
@@ -616,8 +641,13 @@ struct LdsSymTab {
     __device__ __forceinline__ void set(uint32_t k, sym_t v) { col[k * 64u] = v; }
 };
 
+// The symbolic table is kept as two LDS arrays, constants (u32) and source|absmask (u16): 24 KiB per
+// wavefront instead of 32, which lets a fifth wavefront onto the CU (this kernel is bound by how many
+// lanes are resident, see dec_segments).  Same step as symf_step (qoi_decode_core.h), with the SDWA byte
+// adds and with the LDS round trips of a step in flight together.
 __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
-    __shared__ sym_t s_tab[64 * 64];
+    __shared__ uint32_t s_tabc[64 * 64];
+    __shared__ uint16_t s_tabm[64 * 64];
     __shared__ uint32_t s_ring[LaneReader::kSlots * 64];
     __shared__ LdsLut s_lut;
     const uint32_t lane = lane_id();
@@ -634,10 +664,18 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
     LaneReader R;
     R.init(lds_addr_of(&s_ring[lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
-    LdsSymTab tab{&s_tab[lane]};
-    SymState s; sym_init(s, have ? p.slot_in[q] : 0u, have ? p.alpha_in[q] : 0u, tab);
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    const uint32_t tc_base = lds_addr_of(&s_tabc[lane]);             // slot k at + k*256
+    const uint32_t tm_base = lds_addr_of(&s_tabm[lane]);             // slot k at + k*128
+    const uint32_t lut_base = lds_addr_of(&s_lut.delta[0]);
+    // identity: slot k = entry slot k + 0, pixel = entry pixel + 0 (sym_init)
+    for (uint32_t k = 0; k < 64u; ++k) { *(lds_u32*)(tc_base + k * 256u) = 0u; *(lds_u16*)(tm_base + k * 128u) = (uint16_t)k; }
+    uint32_t pc = 0u, ph = 64u;
+    uint32_t slot = have ? p.slot_in[q] : 0u, alpha = have ? p.alpha_in[q] : 0u;
     bool active = have && pos < end;
     uint32_t w32, b5; R.peek(pos, w32, b5);
+    uint32_t delta0, info;
+    {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); delta0 = lq[0]; info = lq[256]; }
     // blocks of kPeriod steps: the stream loads issued by refill() are waited for at the NEXT refill only
     while (__ballot(active)) {
         R.refill(pos);
@@ -645,18 +683,41 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
         for (uint32_t u = 0; u < LaneReader::kPeriod; ++u) {
             if (active) {
                 const uint32_t b1 = w32 & 0xFFu;
+                const uint32_t t_c = *(const lds_u32*)(tc_base + ((w32 & 63u) << 8));
+                const uint32_t t_m = *(const lds_u16*)(tm_base + ((w32 & 63u) << 7));
                 const uint32_t npos = pos + len_of(b1);
                 uint32_t nw32, nb5; R.peek(npos, nw32, nb5);      // next chunk's bytes travel while this one is executed
-                symf_step(s, w32, b5, s_lut.delta[b1], s_lut.info[b1], tab.get(b1 & 63u), tab);
-                pos = npos; w32 = nw32; b5 = nb5;
+                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)info, 28, 1);        // all ones for LUMA
+                const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
+                uint32_t pc_rel = pc;
+                add_byte0(pc_rel, delta0); add_byte1(pc_rel, delta0); add_byte2(pc_rel, delta0);
+                add_byte0(pc_rel, er); add_byte2_from0(pc_rel, eb);
+                const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);
+                const uint32_t pc_rgb = (pc & 0xFF000000u) | (rgba & 0x00FFFFFFu);
+                const bool hi = lut_hi(info), lo = lut_lo(info);
+                const uint32_t lrgb = __builtin_amdgcn_udot4(rgba, 0x00070503u, 0u, false);
+                const uint32_t s_rel = slot + lut_slot_shift(info) + 3u * er + 7u * eb;
+                const uint32_t sb = lrgb + 11u * (lo ? b5 : alpha);
+                const uint32_t pb = lo ? rgba : pc_rgb, hb = lo ? (15u << 8) : (ph | (7u << 8));
+                const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
+                const uint32_t ndelta0 = lq[0], ninfo = lq[256];
+                const uint32_t pa = lo ? t_c : pc_rel, ha = lo ? t_m : ph, sa = lo ? b1 : s_rel;
+                pc = hi ? pb : pa;
+                ph = hi ? hb : ha;
+                slot = (hi ? sb : sa) & 63u;
+                alpha = (hi && lo) ? b5 : alpha;
+                *(lds_u32*)(tc_base + (slot << 8)) = pc;          // index update after every chunk (qoi.h:577)
+                *(lds_u16*)(tm_base + (slot << 7)) = (uint16_t)ph;
+                pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
                 active = pos < end;
             }
         }
     }
     if (have) {
         sym_t* dst = p.summary + (size_t)q * 65u;
-        for (uint32_t k = 0; k < 64u; ++k) dst[k] = tab.get(k);
-        dst[64] = sym_pixel(s);
+        for (uint32_t k = 0; k < 64u; ++k)
+            dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)*(const lds_u16*)(tm_base + k * 128u) << 32);
+        dst[64] = (sym_t)pc | ((sym_t)ph << 32);
     }
 }
 
@@ -752,31 +813,6 @@ struct LdsTab32 {
     __device__ __forceinline__ void set(uint32_t k, uint32_t v) { col[k * 64u] = v; }
 };
 
-// Device forms of the byte-wise pixel arithmetic: one SDWA add per channel (the result's low byte lands in
-// the selected byte of acc, the other bytes are preserved) instead of a 5-op SWAR add.
-__device__ __forceinline__ void add_byte0(uint32_t& acc, uint32_t b) {
-    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0" : "+v"(acc) : "v"(b));
-}
-__device__ __forceinline__ void add_byte1(uint32_t& acc, uint32_t b) {
-    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1" : "+v"(acc) : "v"(b));
-}
-__device__ __forceinline__ void add_byte2(uint32_t& acc, uint32_t b) {
-    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2" : "+v"(acc) : "v"(b));
-}
-__device__ __forceinline__ void add_byte2_from0(uint32_t& acc, uint32_t b) {     // acc.byte2 += b.byte0
-    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0" : "+v"(acc) : "v"(b));
-}
-// px + (dr,dg,db) of a relative chunk (qoi.h:561-572); delta0/info from the chunk table, w32 = chunk bytes 0..3
-__device__ __forceinline__ uint32_t apply_relative(uint32_t px, uint32_t w32, uint32_t delta0, uint32_t info) {
-    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)info, 28, 1);        // all ones for LUMA
-    const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m;                   // b2 >> 4
-    const uint32_t eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;                    // b2 & 15
-    uint32_t r = px;
-    add_byte0(r, delta0); add_byte1(r, delta0); add_byte2(r, delta0);
-    add_byte0(r, er); add_byte2_from0(r, eb);
-    return r;
-}
-
 // P4 main loop, written for few instructions per step: a wavefront of this kernel runs alone on its SIMD
 // most of the time (the 16 KiB of private colour tables per wavefront bound the residency), so its speed is
 // (instructions per step) x (~9 cycles).  The next chunk's bytes are fetched while the current one executes.
@@ -820,33 +856,39 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
     const uint32_t limit = im.npx;
     bool active = have && pos < end && W.ppos < limit;
     uint32_t w32, b5; R.peek(pos, w32, b5);
-    // blocks of kPeriod steps; per block: pixel stores first, then the next stream loads (see LaneWriter)
+    uint32_t delta0, info;
+    {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); delta0 = lq[0]; info = lq[256]; }
+    // Blocks of kPeriod steps; per block: pixel stores first, then the next stream loads (see LaneWriter).
+    // Inside a step the LDS round trips are software-pipelined: the colour-table read of this chunk, the bytes
+    // of the next chunk and the next chunk's table entry are all in flight while this chunk's arithmetic runs
+    // (a wavefront is mostly alone on its SIMD here, nothing else hides the ~100-cycle LDS latency).
     while (__ballot(active)) {
         W.drain();
         R.refill(pos);
 #pragma unroll
         for (uint32_t u = 0; u < LaneReader::kPeriod; ++u) {
             if (active) {
-                const uint32_t b1 = w32 & 0xFFu;
-                // chunk table (delta, info) and the colour-table slot the tag byte may name, in flight together
-                const lds_u32* lq = (const lds_u32*)(lut_base + b1 * 4u);
-                const uint32_t delta0 = lq[0], info = lq[256];
+                // colour-table slot the tag byte may name (issued after the previous step's table write)
                 const uint32_t t = *(const lds_u32*)(tab_base + ((w32 & 63u) << 8));
-                // next chunk's bytes travel while this one is executed
-                const uint32_t npos = pos + len_of(b1);
+                const uint32_t npos = pos + len_of(w32 & 0xFFu);
                 uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
-                // the four ways a chunk sets the pixel (qoi.h:547-575)
+                // the ways a chunk sets the pixel that need no table (qoi.h:547-575)
                 const uint32_t rel = apply_relative(px, w32, delta0, info);
                 const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);                     // r,g,b,a = chunk bytes 1..4
                 const uint32_t rgbv = (px & 0xFF000000u) | (rgba & 0x00FFFFFFu);
                 const bool hi = lut_hi(info), lo = lut_lo(info);
-                const uint32_t a = lo ? t : rel, b = lo ? rgba : rgbv;
+                const uint32_t b = lo ? rgba : rgbv;
+                const uint32_t npx = lut_pixels(info);
+                // next chunk's table entry
+                const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
+                const uint32_t ndelta0 = lq[0], ninfo = lq[256];
+                const uint32_t a = lo ? t : rel;
                 px = hi ? b : a;
                 // index[QOI_COLOR_HASH(px) % 64] = px after every chunk (qoi.h:577)
                 const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
                 *(lds_u32*)(tab_base + ((h & 63u) << 8)) = px;
-                uint32_t rem = min(lut_pixels(info), limit - W.ppos);      // over-long run clipped (Appendix B item 8)
-                pos = npos; w32 = nw32; b5 = nb5;
+                uint32_t rem = min(npx, limit - W.ppos);                   // over-long run clipped (Appendix B item 8)
+                pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
                 W.put(px);                                                 // rem >= 1: the lane was below the pixel limit
                 if (--rem) { do { W.put(px); } while (--rem); }            // QOI_OP_RUN (qoi.h:573-575)
                 active = pos < end && W.ppos < limit;
