@@ -145,6 +145,25 @@ def main() -> None:
     ctx.set_profiling(False)
     ctx.encode_status(stream)
 
+    # BASELINE configs[1]: ONE 4K frame, encode + decode, device-resident (33 MB: served by the 256 MiB Infinity
+    # Cache on repeat runs and bound by launch latency, not by HBM - reported next to the batch figure, never as it)
+    single = None
+    if not args.encode_only and rank == 0:
+        one = [sizes[0]]
+        for _ in range(3):
+            ctx.encode_batch(pixels.data_ptr(), pstride, desc, 1, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+            ctx.decode_batch(streams.data_ptr(), sstride, one, [desc], 4, decoded.data_ptr(), pstride, stream)
+        torch.cuda.synchronize()
+        reps = 20
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ctx.encode_batch(pixels.data_ptr(), pstride, desc, 1, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+            ctx.decode_batch(streams.data_ptr(), sstride, one, [desc], 4, decoded.data_ptr(), pstride, stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        single = {"workload": f"1 x {w}x{h} RGBA frame, encode + decode, device-resident, wall clock incl. launches",
+                  "ms": round(dt * 1e3, 4), "mpixels_per_s": round(npx / dt / 1e6, 1)}
+
     # bit-exact round trip (qoibench.c:408-417) checked outside the timed region
     ok = args.encode_only or bool(torch.equal(decoded.view(F, -1)[:, :npx * 4], pixels.view(F, -1)[:, :npx * 4]))
     dstats = ctx.decode_stats()
@@ -181,6 +200,8 @@ def main() -> None:
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": round(per_launch_ms, 4)},
         }
+        if single:
+            out["single_frame"] = single
         if args.encode_only:
             out["config"]["workload"] += " [ENCODE ONLY - diagnostic run, not the benchmark]"
         if world == 1 and not args.no_cpu:

@@ -113,16 +113,23 @@ struct LaneReaderT {
         w32 = __builtin_amdgcn_alignbit(d1, d0, sh);
         b5 = (d1 >> sh) & 0xFFu;
     }
-    // wave-uniform call; pos = the lane's current stream position
-    __device__ __forceinline__ void refill(uint32_t pos) {
+    // wave-uniform calls; pos = the lane's current stream position.  land(): the loads issued one period ago
+    // go into the ring (the only place that waits for memory).  issue(): next loads.  Callers that STORE to
+    // global memory do so right AFTER issue(): the vector-memory counter retires in order, so a store issued
+    // shortly before land() would make that wait a wait for the store's acknowledgement; issued a whole
+    // period earlier it has long completed.
+    __device__ __forceinline__ void land() {
 #pragma unroll
         for (int i = 0; i < NP_; ++i) if ((uint32_t)i < npend) put4(wr + 4u * i, pend[i]);
         wr += 4u * npend;
+    }
+    __device__ __forceinline__ void issue(uint32_t pos) {
         const uint32_t space = RD - (wr - ((pos - aoff) >> 2));
         npend = min((uint32_t)NP_, space >> 2);
 #pragma unroll
         for (int i = 0; i < NP_; ++i) if ((uint32_t)i < npend) pend[i] = load16(abase + (size_t)wr * 4u + 16u * i);
     }
+    __device__ __forceinline__ void refill(uint32_t pos) { land(); issue(pos); }
     __device__ __forceinline__ bool due(uint32_t it) const { return (it % kPeriod) == 0u; }
 };
 typedef LaneReaderT<16, 2, 4> LaneReader;
@@ -863,8 +870,9 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
     // of the next chunk and the next chunk's table entry are all in flight while this chunk's arithmetic runs
     // (a wavefront is mostly alone on its SIMD here, nothing else hides the ~100-cycle LDS latency).
     while (__ballot(active)) {
+        R.land();
+        R.issue(pos);
         W.drain();
-        R.refill(pos);
 #pragma unroll
         for (uint32_t u = 0; u < LaneReader::kPeriod; ++u) {
             if (active) {

@@ -72,7 +72,7 @@ struct qoimi_ctx {
     Arena io_a, io_b, io_c;     // staging for the host-pointer (drop-in) path
     uint32_t* host_word = nullptr;   // pinned word for read-backs
     long long dec_stats[4] = {0, 0, 0, 0};
-    uint32_t seg_bytes = 2048;  // decode segment size
+    uint32_t seg_bytes = 0;     // decode segment size; 0: chosen per call from the batch's stream bytes
     uint32_t* last_enc_err = nullptr;   // device flag of the most recent encode launch
     bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
     int enc_ablate = 0, enc_ticket = 1, enc_quads = 0, enc_prefetch = 0;   // tuning / profiling knobs (env QOIMI_ENC_*)
@@ -263,7 +263,17 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     if (channels != 0 && channels != 3 && channels != 4) return fail(QOIMI_E_ARG, "channels must be 0, 3 or 4 (qoi.h:499)");
     int och = 0;
     std::vector<DecImage> imgs((size_t)n_images);
-    const uint32_t B = c->seg_bytes;
+    uint32_t B = c->seg_bytes;
+    if (B == 0) {
+        // One lane decodes one segment.  Small batches get small segments so that the lanes still fill the
+        // resident wavefronts of the two table-bound passes (~98 K lanes); large batches cap at 2 KiB (the
+        // 520-byte symbolic summary per segment then costs a quarter of the stream traffic).
+        uint64_t bytes = 0;
+        for (int i = 0; i < n_images; ++i) bytes += (uint64_t)(sizes[i] > 0 ? sizes[i] : 0);
+        uint64_t want = bytes / 98304u;
+        B = 128;
+        while (B < 2048u && B < want) B <<= 1;
+    }
     uint64_t total = 0, total_g = 0;
     for (int i = 0; i < n_images; ++i) {
         if (sizes[i] < kHeaderBytes + kTrailerBytes) return fail(QOIMI_E_ARG, "stream shorter than 22 bytes (qoi.h:500)");

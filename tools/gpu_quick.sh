@@ -10,7 +10,7 @@ for kind in ${KINDS:-photo}; do
 import json,sys
 for l in open(sys.argv[1]):
     if l.startswith('{'):
-        d=json.loads(l); print(d['config']['content'], 'value', d['value'], 'exact', d['verified_bit_exact'], 'enc', d['encode_mpps_kernels'], 'dec', d['decode_mpps_kernels'], 'frac', d['roofline']['frac']); print(d['kernel_ms_per_step'])
+        d=json.loads(l); print(d['config']['content'], 'value', d['value'], 'exact', d['verified_bit_exact'], 'enc', d['encode_mpps_kernels'], 'dec', d['decode_mpps_kernels'], 'frac', d['roofline']['frac']); print(d['kernel_ms_per_step']); print(d.get('single_frame'))
     elif 'rror' in l or 'rc=' in l: print(l.strip())
 PY
 done
