@@ -214,6 +214,22 @@ struct LaneWriter {
         *(lds_u32*)(row + (ppos & (kRing - 1u)) * 256u) = px;
         ++ppos;
     }
+    // n copies of px from ppos on, not through the ring; n is reduced to the < 4 copies that remain for put()
+    __device__ __forceinline__ void splat(uint32_t px, uint32_t& n) {
+        finish();                                                         // ring out first: [fpos, ppos) stays contiguous
+        while ((ppos & 3u) != 0u && n) { store_one(ppos, px); ++ppos; --n; }
+        while (n >= 4u) {
+            if (OCH == 4) {
+                *reinterpret_cast<uint4*>(out + (size_t)ppos * 4u) = make_uint4(px, px, px, px);
+            } else {
+                const uint32_t a = px & 0xFFFFFFu;
+                uint32_t* d = reinterpret_cast<uint32_t*>(out + (size_t)ppos * 3u);
+                d[0] = a | (a << 24); d[1] = (a >> 8) | (a << 16); d[2] = (a >> 16) | (a << 8);
+            }
+            ppos += 4u; n -= 4u;
+        }
+        fpos = ppos;
+    }
     __device__ __forceinline__ void finish() {                            // everything left, tail group pixel by pixel
         drain();
         while (fpos < ppos) { store_one(fpos, at(fpos)); ++fpos; }
@@ -652,10 +668,19 @@ struct LdsSymTab {
 // wavefront instead of 32, which lets a fifth wavefront onto the CU (this kernel is bound by how many
 // lanes are resident, see dec_segments).  Same step as symf_step (qoi_decode_core.h), with the SDWA byte
 // adds and with the LDS round trips of a step in flight together.
+//
+// REFINE (rounds after a failed exit-state check): the entry states the previous round computed serve as
+// hints - slot and alpha at segment entry come from the hinted entry pixel (no P2/S2 in these rounds), and
+// an INDEX chunk that names a table entry whose alpha still refers to the entry state takes the hinted
+// alpha of that entry word.  Streams whose alpha changes through the colour table (UI content with
+// several alpha levels) mis-speculate the slot of a later QOI_OP_RGB in almost every segment in round 1 and
+// verify in 2-5 rounds with the hints (one segment per round without them).
+template <bool REFINE>
 __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     __shared__ uint32_t s_tabc[64 * 64];
     __shared__ uint16_t s_tabm[64 * 64];
     __shared__ uint32_t s_ring[LaneReader::kSlots * 64];
+    __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 64];
     __shared__ LdsLut s_lut;
     const uint32_t lane = lane_id();
     build_lut(s_lut, lane, 64u);
@@ -678,7 +703,26 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     // identity: slot k = entry slot k + 0, pixel = entry pixel + 0 (sym_init)
     for (uint32_t k = 0; k < 64u; ++k) { *(lds_u32*)(tc_base + k * 256u) = 0u; *(lds_u16*)(tm_base + k * 128u) = (uint16_t)k; }
     uint32_t pc = 0u, ph = 64u;
-    uint32_t slot = have ? p.slot_in[q] : 0u, alpha = have ? p.alpha_in[q] : 0u;
+    uint32_t slot, alpha;
+    if (REFINE) {
+        const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
+        uint32_t epx = 0;
+        if (have) {
+            for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {
+                uint32_t v[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) v[k] = ent[k0 + k];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) s_hint[(k0 + k) * 64u + lane] = (uint8_t)(v[k] >> 24);
+            }
+            epx = ent[64];
+            s_hint[64u * 64u + lane] = (uint8_t)(epx >> 24);
+        }
+        slot = hash_px(epx); alpha = epx >> 24;
+    } else {
+        slot = have ? p.slot_in[q] : 0u; alpha = have ? p.alpha_in[q] : 0u;
+    }
+    const uint32_t alpha_in0 = alpha;
     bool active = have && pos < end;
     uint32_t w32, b5; R.peek(pos, w32, b5);
     uint32_t delta0, info;
@@ -712,7 +756,10 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
                 pc = hi ? pb : pa;
                 ph = hi ? hb : ha;
                 slot = (hi ? sb : sa) & 63u;
-                alpha = (hi && lo) ? b5 : alpha;
+                // alpha after the chunk: RGBA sets it, INDEX takes the named entry's (hinted where it is still symbolic)
+                const uint32_t th = REFINE ? (uint32_t)s_hint[(t_m & 0x7Fu) * 64u + lane] : alpha_in0;
+                const uint32_t ta = (t_m & 0x800u) ? (t_c >> 24) : th;
+                alpha = hi ? (lo ? b5 : alpha) : (lo ? ta : alpha);
                 *(lds_u32*)(tc_base + (slot << 8)) = pc;          // index update after every chunk (qoi.h:577)
                 *(lds_u16*)(tm_base + (slot << 7)) = (uint16_t)ph;
                 pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
@@ -862,6 +909,7 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
     }
     const uint32_t limit = im.npx;
     bool active = have && pos < end && W.ppos < limit;
+    constexpr uint32_t kLongRun = 12;
     uint32_t w32, b5; R.peek(pos, w32, b5);
     uint32_t delta0, info;
     {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); delta0 = lq[0]; info = lq[256]; }
@@ -898,7 +946,12 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
                 uint32_t rem = min(npx, limit - W.ppos);                   // over-long run clipped (Appendix B item 8)
                 pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
                 W.put(px);                                                 // rem >= 1: the lane was below the pixel limit
-                if (--rem) { do { W.put(px); } while (--rem); }            // QOI_OP_RUN (qoi.h:573-575)
+                if (--rem) {                                               // QOI_OP_RUN (qoi.h:573-575)
+                    // a long run bypasses the ring (ring out, then aligned 4-pixel stores of the repeated pixel):
+                    // flat content is all runs
+                    if (rem >= kLongRun) W.splat(px, rem);
+                    while (rem) { W.put(px); --rem; }
+                }
                 active = pos < end && W.ppos < limit;
             }
         }
@@ -988,10 +1041,14 @@ void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
     tm->mark(kT_dec_chain_parse, st);
 }
 
-void launch_decode_round(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm) {
+void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipStream_t st, KernelTimer* tm) {
     if (!p.total_segs) return;
     const uint32_t b256 = (p.total_segs + 255u) / 256u, b64 = (p.total_segs + 63u) / 64u;
     tm->mark(kT_begin, st);
+    if (refine) {
+        hipLaunchKernelGGL(dec_summarize<true>, dim3(b64), dim3(64), 0, st, p);
+        tm->mark(kT_dec_summarize, st);
+    } else {
     if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_walk_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(dec_slot_walk, dim3(b256), dim3(256), 0, st, p);
     tm->mark(kT_dec_slot_walk, st);
@@ -999,8 +1056,9 @@ void launch_decode_round(const DecParams& p, int out_channels, hipStream_t st, K
     hipLaunchKernelGGL(dec_chain_slots_l2, dim3(p.n_images), dim3(64), 0, st, p);
     hipLaunchKernelGGL(dec_chain_slots_l3, dim3(p.total_grps), dim3(64), 0, st, p);
     tm->mark(kT_dec_chain_slots, st);
-    hipLaunchKernelGGL(dec_summarize, dim3(b64), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(dec_summarize<false>, dim3(b64), dim3(64), 0, st, p);
     tm->mark(kT_dec_summarize, st);
+    }
     hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
     hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64), 0, st, p);
     hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);

@@ -376,10 +376,14 @@ QOIMI_HD void slotf_finish(const SlotFast& s, SlotRec& r) {
     r.a_abs = (uint8_t)((s.fl >> 2) & 1u); r.ac = (uint8_t)s.ac;
 }
 
-// ---- P3: symbolic step, same function as sym_step --------------------------------------
-// t = tab.get(b1 & 63), read by the caller (issued early on the device)
-template <class Tab>
-QOIMI_HD void symf_step(SymState& s, uint32_t w32, uint32_t b5, uint32_t delta0, uint32_t info, sym_t t, Tab& tab) {
+// ---- P3: symbolic step, same function as sym_step except for the alpha an INDEX chunk leaves --------
+// t = tab.get(b1 & 63), read by the caller (issued early on the device).
+// An INDEX chunk takes the alpha of the table entry it names (qoi.h:558-560).  Where that entry's alpha is
+// absolute the value is known; where it still refers to the segment's entry state, `hint(src)` supplies a
+// guess: the entry alpha of the segment (first round) or the alpha the previous round computed for that
+// entry word (refinement rounds).  Only the SPECULATED slot of a later QOI_OP_RGB depends on it.
+template <class Tab, class Hint>
+QOIMI_HD void symf_step(SymState& s, uint32_t w32, uint32_t b5, uint32_t delta0, uint32_t info, sym_t t, Tab& tab, const Hint& hint) {
     const uint32_t b1 = w32 & 0xFFu;
     const uint32_t ex = luma_extra(w32, info);
     const uint32_t delta = add_bytes(delta0, ex);
@@ -395,7 +399,8 @@ QOIMI_HD void symf_step(SymState& s, uint32_t w32, uint32_t b5, uint32_t delta0,
     const uint32_t s_rel = s.slot + lut_slot_shift(info) + 3u * (ex & 0xFFu) + 7u * (ex >> 16);
     const uint32_t sa = lo ? b1 : s_rel, sb = lrgb + 11u * (lo ? b5 : s.alpha);
     s.slot = (hi ? sb : sa) & 63u;
-    s.alpha = (hi && lo) ? b5 : s.alpha;
+    if (hi && lo) s.alpha = b5;                                           // QOI_OP_RGBA
+    else if (lo) s.alpha = (sym_abs(t) & 8u) ? (uint32_t)t >> 24 : hint(sym_src(t));   // QOI_OP_INDEX
     tab.set(s.slot, (sym_t)s.pc | ((sym_t)s.ph << 32));          // index update after every chunk (qoi.h:577)
 }
 
@@ -438,15 +443,15 @@ QOIMI_HD void slot_walk_segment_fast(const uint8_t* in, uint32_t pos, uint32_t s
     }
     slotf_finish(s, r);
 }
-template <class Lut, class Tab>
+template <class Lut, class Tab, class Hint>
 QOIMI_HD sym_t summarize_segment_fast(const uint8_t* in, uint32_t pos, uint32_t seg_end, uint32_t slot, uint32_t alpha,
-                                      const Lut& lut, Tab& tab) {
+                                      const Lut& lut, Tab& tab, const Hint& hint) {
     PtrReader R{in};
     SymState s; sym_init(s, slot, alpha, tab);
     while (pos < seg_end) {
         uint32_t w32, b5; R.peek(pos, w32, b5);
         const uint32_t b1 = w32 & 0xFFu;
-        symf_step(s, w32, b5, lut.delta[b1], lut.info[b1], tab.get(b1 & 63u), tab);
+        symf_step(s, w32, b5, lut.delta[b1], lut.info[b1], tab.get(b1 & 63u), tab, hint);
         pos += len_of(b1);
     }
     return sym_pixel(s);

@@ -77,6 +77,7 @@ struct qoimi_ctx {
     bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
     int enc_ablate = 0, enc_ticket = 1, enc_quads = 0, enc_prefetch = 0;   // tuning / profiling knobs (env QOIMI_ENC_*)
     int enc_lookback = 0;               // 1: single-pass decoupled look-back instead of scratch + compaction
+    int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
     KernelTimer timer;                  // optional per-kernel HIP-event timing
     double prof_ms[kT_count] = {0};     // accumulated kernel milliseconds since profiling was (re)enabled
@@ -118,6 +119,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_PREFETCH")) c->enc_prefetch = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
     if (const char* e = getenv("QOIMI_SEG_BYTES")) {
         long v = atol(e);
         if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v;
@@ -337,7 +339,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     long long rounds = 0;
     for (;;) {
         HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
-        launch_decode_round(p, och, st, &c->timer);
+        launch_decode_round(p, och, rounds > 0 && c->dec_refine, st, &c->timer);
         ++rounds;
         if (!p.total_segs) break;
         HIP_TRY(hipMemcpyAsync(c->host_word, p.pending, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

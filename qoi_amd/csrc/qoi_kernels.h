@@ -113,7 +113,7 @@ struct DecParams {
 };
 
 void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm);
-void launch_decode_round(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);
+void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipStream_t st, KernelTimer* tm);
 void launch_decode_fill(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);
 
 // ---- synthetic frames --------------------------------------------------------------
