@@ -56,10 +56,14 @@ template <int CH, int K>
 __global__ __launch_bounds__(256) void enc_slab_summary(EncParams p) {
     __shared__ u64 s_key[4][64];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t g = blockIdx.x * 4u + wave;
+    if (p.only_flagged && *p.any_generic == 0u) return;
     const uint32_t total = p.n_images * p.spi;
-    if (g >= total) return;
+#pragma unroll 1
+    for (uint32_t blk = blockIdx.x; blk * 4u < total; blk += gridDim.x) {
+    const uint32_t g = blk * 4u + wave;
+    if (g >= total) continue;
     const uint32_t img = g / p.spi, s = g - img * p.spi;
+    if (p.only_flagged && p.need_generic[img] == 0u) continue;
     const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
     const uint32_t n = p.npx, lo = s * (64u * K);
 
@@ -95,6 +99,8 @@ __global__ __launch_bounds__(256) void enc_slab_summary(EncParams p) {
     const u64 vmask = __ballot(k != 0);
     p.sum_tab[(size_t)g * 64u + lane] = (uint32_t)k;
     if (lane == 0) { p.sum_valid[g] = vmask; p.sum_le[g] = le; }
+    __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -105,6 +111,7 @@ __global__ __launch_bounds__(64) void enc_scan_groups(EncParams p) {
     const uint32_t lane = lane_id();
     const uint32_t G = blockIdx.x;                       // img * gpi + grp
     const uint32_t img = G / p.gpi, grp = G - img * p.gpi;
+    if (p.only_flagged && p.need_generic[img] == 0u) return;
     const uint32_t s0 = grp * 64u;
     const uint32_t s1 = min(p.spi, s0 + 64u);
     uint32_t cur = 0; bool curv = false; int curle = -1;
@@ -128,6 +135,7 @@ __global__ __launch_bounds__(64) void enc_scan_groups(EncParams p) {
 __global__ __launch_bounds__(64) void enc_scan_images(EncParams p) {
     const uint32_t lane = lane_id();
     const uint32_t img = blockIdx.x;
+    if (p.only_flagged && p.need_generic[img] == 0u) return;
     uint32_t cur = 0; int curle = -1;          // table starts zeroed (qoi.h:393), no edge yet
     for (uint32_t gr = 0; gr < p.gpi; ++gr) {
         const size_t G = (size_t)img * p.gpi + gr;
@@ -275,6 +283,8 @@ constexpr uint32_t kLenOne = 0u, kLenTwo = 1u << 17, kLenLong = 1u << 18;   // 1
 // bound by HBM latency: ~3 TB/s whatever the content).
 template <int K>
 struct SlabIn {
+    uint32_t warm[8];            // ENTRY 1: the 512 pixels before the slab (step k: pixels lo-64(k+1) .. +63), and the one before them
+    uint32_t warm_carry;
     uint32_t px[K];              // pixel t*64 + lane of the slab
     uint32_t carry0;             // pixel before the slab (qoi.h:396-399 start value for slab 0)
     uint32_t next_first;         // first pixel of the next slab
@@ -283,11 +293,20 @@ struct SlabIn {
     int le_loc, le_far;          // last edge before the slab: group-local / image-level
 };
 
-template <int CH, int K>
+template <int CH, int K, int ENTRY>
 __device__ __forceinline__ void load_slab(const EncParams& p, uint32_t g, uint32_t lane, SlabIn<K>& in) {
     const uint32_t img = g / p.spi, s = g - img * p.spi;
     const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
     const uint32_t n = p.npx, lo = s * (64u * K);
+    if (ENTRY == 1) {                                        // issued first: they are needed first
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = (int)lo - 64 * (k + 1) + (int)lane;
+            in.warm[k] = i >= 0 ? load_px<CH>(pix, (uint32_t)i) : kInitPx;
+        }
+        const int ci = (int)lo - 64 * 8 - 1;
+        in.warm_carry = ci >= 0 ? load_px<CH>(pix, (uint32_t)ci) : kInitPx;
+    }
     if (lo + 64u * K < n) {                                  // interior slab: no bounds checks
 #pragma unroll
         for (int t = 0; t < K; ++t) in.px[t] = load_px<CH>(pix, lo + t * 64u + lane);
@@ -298,15 +317,96 @@ __device__ __forceinline__ void load_slab(const EncParams& p, uint32_t g, uint32
         in.next_first = 0;
     }
     in.carry0 = (lo > 0) ? load_px<CH>(pix, lo - 1) : kInitPx;
-    const uint32_t G = img * p.gpi + (s >> 6);
-    in.tab_loc = p.ent_tab[(size_t)g * 64u + lane];
-    in.tab_far = p.gent_tab[(size_t)G * 64u + lane];
-    in.tab_valid = p.ent_valid[g];
-    in.le_loc = p.ent_le[g];
-    in.le_far = p.gent_le[G];
+    if (ENTRY == 0) {
+        const uint32_t G = img * p.gpi + (s >> 6);
+        in.tab_loc = p.ent_tab[(size_t)g * 64u + lane];
+        in.tab_far = p.gent_tab[(size_t)G * 64u + lane];
+        in.tab_valid = p.ent_valid[g];
+        in.le_loc = p.ent_le[g];
+        in.le_far = p.gent_le[G];
+    }
 }
 
-template <int CH, int K, int PROBE, bool LAST, int ABL>
+// ENTRY 1: a slab finds its entry state itself.  The colour table before pixel `lo` is "the last edge pixel
+// per hash slot" (qoi.h:430-436), so the wavefront walks BACKWARDS over the pixels before its slab, 64 at a
+// time, and fills every slot that is still empty with the latest edge pixel that hashes there, until all 64
+// slots are known or the image start is reached (untouched slots are then the zeroes of qoi.h:393).  Natural
+// images and noise need 5-8 steps (SURVEY: all 64 slots are rewritten within ~700 pixels); flat content does
+// not finish within the window - the slab then flags its image and the generic passes (per-slab summaries +
+// scans, ENTRY 0) redo that image.  Unfilled slots hold slot+1, a value that cannot hash to its own slot
+// (3(s+1) != s mod 64).  Returns false if the window did not suffice.
+constexpr int kWarmSteps = 128;      // look-back window: 8192 pixels (natural content is done after 5-11 steps)
+constexpr int kWarmBatch = 8;        // 64-pixel steps loaded together
+constexpr int kWarmMinFilled = 48;   // slots that must be known after the first batch (512 pixels), else the content is flat: give up
+
+template <int CH, int K>
+__device__ __forceinline__ bool warm_entry_state(const EncParams& p, uint32_t img, uint32_t lo, uint32_t lane,
+                                                 EncLds<K>& L, uint32_t tbase, const SlabIn<K>& in, int& last_edge) {
+    last_edge = -1;
+    if (lo == 0u) { L.table[lane] = 0u; return true; }       // qoi.h:393: zeroed table, no edge yet
+    const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
+    const uint32_t sent = lane + 1u;
+    L.table[lane] = sent;
+    __builtin_amdgcn_wave_barrier();
+    // ---- the 512 pixels right before the slab, oldest first: later edge pixels simply overwrite earlier ones
+    //      (these loads were issued ahead of the slab's own pixels) ------------------------------------------
+    {
+        const uint32_t carry = __builtin_amdgcn_readfirstlane(in.warm_carry);
+#pragma unroll
+        for (int k = kWarmBatch - 1; k >= 0; --k) {
+            const int base = (int)lo - 64 * (k + 1);
+            const uint32_t px = in.warm[k];
+            const uint32_t prev = k + 1 < kWarmBatch ? prev_pixels(px, in.warm[k + 1 < kWarmBatch ? k + 1 : k]) : from_lane_below(px, carry);
+            const u64 E = __ballot(px != prev);               // lanes before the image start hold the start pixel: no edge
+            if (E) {
+                last_edge = base + msb64(E);
+                (void)probe_swap(tbase | slot_byte_offset(px), px, E);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    u64 filled = __ballot(L.table[lane] != sent);
+    bool full = filled == ~0ull, at_start = (int)lo - 64 * kWarmBatch <= 0;
+    if (!full && !at_start && __builtin_popcountll(filled) < kWarmMinFilled) return false;   // flat content: generic path
+    // ---- rarely: further back, 64 pixels at a time, filling only slots that are still empty -------------------
+#pragma unroll 1
+    for (int t0 = kWarmBatch + 1; t0 <= kWarmSteps && !full && !at_start; t0 += kWarmBatch) {
+        uint32_t wp[kWarmBatch];
+#pragma unroll
+        for (int k = 0; k < kWarmBatch; ++k) {
+            const int i = (int)lo - 64 * (t0 + k) + (int)lane;
+            wp[k] = i >= 0 ? load_px<CH>(pix, (uint32_t)i) : kInitPx;
+        }
+        const int ci = (int)lo - 64 * (t0 + kWarmBatch - 1) - 1;
+        const uint32_t carry = __builtin_amdgcn_readfirstlane(ci >= 0 ? load_px<CH>(pix, (uint32_t)ci) : kInitPx);
+#pragma unroll
+        for (int k = 0; k < kWarmBatch; ++k) {
+            if (full || at_start) break;
+            const int base = (int)lo - 64 * (t0 + k);
+            const uint32_t px = wp[k];
+            const uint32_t prev = k + 1 < kWarmBatch ? prev_pixels(px, wp[k + 1 < kWarmBatch ? k + 1 : k]) : from_lane_below(px, carry);
+            const bool edge = px != prev;
+            const u64 E = __ballot(edge);
+            if (last_edge < 0 && E) last_edge = base + msb64(E);
+            const uint32_t so = slot_byte_offset(px);
+            const uint32_t cur = *(const lds_u32*)(tbase | so);
+            const u64 want = __ballot(edge && cur == (so >> 2) + 1u);
+            if (want) (void)probe_swap(tbase | so, px, want);            // same slot twice in a step: the later pixel wins
+            __builtin_amdgcn_wave_barrier();
+            filled = __ballot(L.table[lane] != sent);
+            full = filled == ~0ull;
+            at_start = base <= 0;
+        }
+    }
+    if (at_start && !full) {                                  // image start reached: what is left is the zeroed table
+        const uint32_t v = L.table[lane];
+        if (v == sent) L.table[lane] = 0u;
+        full = true;
+    }
+    return full && (last_edge >= 0 || at_start);
+}
+
+template <int CH, int K, int PROBE, bool LAST, int ABL, int ENTRY>
 __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, uint32_t lane, EncLds<K>& L, const SlabIn<K>& in) {
     const uint32_t img = g / p.spi, s = g - img * p.spi;
     const uint32_t n = p.npx, lo = s * (64u * K);
@@ -317,12 +417,20 @@ __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, 
     const uint32_t next_first = __builtin_amdgcn_readfirstlane(in.next_first);
 
     // ---- entry state: colour table + distance to the last edge ---------------------------
-    {
+    int last_edge;
+    if (ENTRY == 1) {
+        uint32_t tb = lds_addr(L.table);
+        asm volatile("" : "+v"(tb));
+        if (!warm_entry_state<CH, K>(p, img, lo, lane, L, tb, in, last_edge)) {
+            if (lane == 0) { atomicOr(&p.need_generic[img], 1u); atomicOr(p.any_generic, 1u); }
+            return;
+        }
+    } else {
         const u64 lv = uniform64(in.tab_valid);
         L.table[lane] = ((lv >> lane) & 1ull) ? in.tab_loc : in.tab_far;
-        if (PROBE == 0) L.mask[lane] = 0;
+        last_edge = max(__builtin_amdgcn_readfirstlane(in.le_loc), __builtin_amdgcn_readfirstlane(in.le_far));   // max edge position < lo, or -1
     }
-    const int last_edge = max(__builtin_amdgcn_readfirstlane(in.le_loc), __builtin_amdgcn_readfirstlane(in.le_far));   // max edge position < lo, or -1
+    if (PROBE == 0) L.mask[lane] = 0;
     // ccp = 63 + (first pixel of the step - last edge before the step): stands in for clz(edges below the lane)
     uint32_t ccp = 63u + (uint32_t)((int)lo - last_edge);
     __builtin_amdgcn_wave_barrier();
@@ -533,46 +641,41 @@ __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, 
     }
 }
 
-// PREFETCH: a wavefront walks through quads_per_wg slabs and loads the next one while it encodes the
-// current one (costs 26 VGPRs = one wavefront per SIMD; measured slower on MI355X because the kernel is
-// VALU-bound, not latency-bound - kept selectable with QOIMI_ENC_PREFETCH=1).
-template <int CH, int K, int PROBE, int ABL, bool PREFETCH>
+// ENTRY 0: entry state from the per-slab summaries + scans (E1/E2).  ENTRY 1: each slab finds it itself
+// (warm_entry_state); slabs whose look-back window does not suffice flag their image, and the launcher runs
+// the ENTRY 0 passes with only_flagged set: small grid-stride grids that return at once when nothing was
+// flagged.  A workgroup serves unit u = (image u % n_images, group u / n_images) so that the slabs in flight
+// spread over all images.
+template <int CH, int K, int PROBE, int ABL, int ENTRY>
 __global__ __launch_bounds__(256) void enc_slabs(EncParams p) {
     __shared__ EncLds<K> s_lds[4];
     __shared__ uint32_t s_ticket;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    // A workgroup serves image (blockIdx % n_images): the slabs in flight spread over all images, so
-    // every per-image look-back chain has few unfinished predecessors.  Within its image the
-    // workgroup takes the next `quads_per_wg` groups of 4 slabs (one slab per wavefront and group);
-    // in look-back mode the groups are handed out by the image's ticket counter, i.e. in START
-    // order, hence every predecessor a look-back can wait on is already running or finished (no
-    // reliance on dispatch order; guide G16).  One counter per image keeps the atomics off a
-    // single hot word.
-    const uint32_t img = blockIdx.x % p.n_images;
-    uint32_t quad = blockIdx.x / p.n_images;              // order-free (scratch) mode: any order will do
-    if (p.use_ticket && !p.scratch) {
-        if (threadIdx.x == 0) s_ticket = atomicAdd(&p.ticket[img], 1u);
-        __syncthreads();
-        quad = __builtin_amdgcn_readfirstlane(s_ticket);
-    }
-    const uint32_t first_quad = quad * p.quads_per_wg;
-    uint32_t s_pos = first_quad * 4u + wave;
-    if (s_pos >= p.spi) return;
-    SlabIn<K> in;
-    load_slab<CH, K>(p, img * p.spi + s_pos, lane, in);
+    if (p.only_flagged && *p.any_generic == 0u) return;
 #pragma unroll 1
-    for (uint32_t r = 0; r < p.quads_per_wg; ++r) {
-        const uint32_t g = img * p.spi + s_pos;
-        const uint32_t s_next = s_pos + 4u;
-        const bool more = r + 1u < p.quads_per_wg && s_next < p.spi;
-        SlabIn<K> nxt;
-        if (PREFETCH && more) load_slab<CH, K>(p, g + 4u, lane, nxt);  // next slab's loads fly while this one is encoded
-        if (s_pos == p.spi - 1u) encode_one_slab<CH, K, PROBE, true, ABL>(p, g, lane, s_lds[wave], in);
-        else encode_one_slab<CH, K, PROBE, false, ABL>(p, g, lane, s_lds[wave], in);
-        if (!more) return;
-        __builtin_amdgcn_wave_barrier();
-        if (PREFETCH) in = nxt; else load_slab<CH, K>(p, g + 4u, lane, in);
-        s_pos = s_next;
+    for (uint32_t unit = blockIdx.x; unit < p.n_units; unit += gridDim.x) {
+        const uint32_t img = unit % p.n_images;
+        uint32_t quad = unit / p.n_images;                 // order-free (scratch) mode: any order will do
+        if (p.only_flagged && p.need_generic[img] == 0u) continue;
+        if (p.use_ticket && !p.scratch) {
+            // look-back mode (one unit per workgroup): groups are handed out by the image's ticket counter, i.e. in
+            // START order, hence every predecessor a look-back can wait on is already running or finished (no
+            // reliance on dispatch order; guide G16).  One counter per image keeps the atomics off a single hot word.
+            if (threadIdx.x == 0) s_ticket = atomicAdd(&p.ticket[img], 1u);
+            __syncthreads();
+            quad = __builtin_amdgcn_readfirstlane(s_ticket);
+        }
+        uint32_t s_pos = quad * p.quads_per_wg * 4u + wave;
+#pragma unroll 1
+        for (uint32_t r = 0; r < p.quads_per_wg && s_pos < p.spi; ++r, s_pos += 4u) {
+            const uint32_t g = img * p.spi + s_pos;
+            if (ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // image already sent to the generic path
+            SlabIn<K> in;
+            load_slab<CH, K, ENTRY>(p, g, lane, in);
+            if (s_pos == p.spi - 1u) encode_one_slab<CH, K, PROBE, true, ABL, ENTRY>(p, g, lane, s_lds[wave], in);
+            else encode_one_slab<CH, K, PROBE, false, ABL, ENTRY>(p, g, lane, s_lds[wave], in);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -688,21 +791,33 @@ __global__ __launch_bounds__(64) void lds_order_selftest(uint32_t* out) {
 // ---------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------
-template <int CH, int K, int PROBE, int ABL, bool PREFETCH>
-static void launch_encode_t(const EncParams& p, hipStream_t st, KernelTimer* tm) {
+template <int CH, int K, int PROBE, int ABL>
+static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm) {
     const uint32_t total = p.n_images * p.spi;
     const uint32_t blocks = (total + 3u) / 4u;
+    const uint32_t quads_per_image = (p.spi + 3u) / 4u;
+    const uint32_t wgs_per_image = (quads_per_image + p.quads_per_wg - 1u) / p.quads_per_wg;
+    p.n_units = wgs_per_image * p.n_images;
+    const bool warm = p.warm && PROBE == 1 && p.scratch;
+    uint32_t small = 2048u;                                  // grid of the passes that usually have nothing to do
     tm->mark(kT_begin, st);
-    hipLaunchKernelGGL((enc_slab_summary<CH, K>), dim3(blocks), dim3(256), 0, st, p);
+    if (warm) {
+        p.only_flagged = 0;
+        hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL, 1>), dim3(p.n_units), dim3(256), 0, st, p);
+        tm->mark(kT_enc_slabs, st);
+        p.only_flagged = 1;
+    } else {
+        p.only_flagged = 0;
+        small = 0xFFFFFFFFu;
+    }
+    hipLaunchKernelGGL((enc_slab_summary<CH, K>), dim3(blocks < small ? blocks : small), dim3(256), 0, st, p);
     tm->mark(kT_enc_summary, st);
     hipLaunchKernelGGL(enc_scan_groups, dim3(p.n_images * p.gpi), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_groups, st);
     hipLaunchKernelGGL(enc_scan_images, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_images, st);
-    const uint32_t quads_per_image = (p.spi + 3u) / 4u;
-    const uint32_t wgs_per_image = (quads_per_image + p.quads_per_wg - 1u) / p.quads_per_wg;
-    hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL, PREFETCH>), dim3(wgs_per_image * p.n_images), dim3(256), 0, st, p);
-    tm->mark(kT_enc_slabs, st);
+    hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL, 0>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
+    tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
     if (p.scratch) {
         hipLaunchKernelGGL(enc_offsets, dim3(p.n_images), dim3(256), 0, st, p);
         tm->mark(kT_enc_offsets, st);
@@ -713,16 +828,11 @@ static void launch_encode_t(const EncParams& p, hipStream_t st, KernelTimer* tm)
 
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm) {
     if (p.channels == 3) {
-        if (p.probe_xchg) launch_encode_t<3, kEncSteps, 1, 0, false>(p, st, tm); else launch_encode_t<3, kEncSteps, 0, 0, false>(p, st, tm);
+        if (p.probe_xchg) launch_encode_t<3, kEncSteps, 1, 0>(p, st, tm); else launch_encode_t<3, kEncSteps, 0, 0>(p, st, tm);
         return;
     }
-    if (!p.probe_xchg) { launch_encode_t<4, kEncSteps, 0, 0, false>(p, st, tm); return; }
-    if (p.prefetch) { launch_encode_t<4, kEncSteps, 1, 0, true>(p, st, tm); return; }
-    switch (p.ablate) {   // ablation variants exist for profiling only (QOIMI_ENC_ABLATE); outputs are then invalid
-        case 1: launch_encode_t<4, kEncSteps, 1, 1, false>(p, st, tm); break;
-        case 4: launch_encode_t<4, kEncSteps, 1, 4, false>(p, st, tm); break;
-        default: launch_encode_t<4, kEncSteps, 1, 0, false>(p, st, tm); break;
-    }
+    if (!p.probe_xchg) { launch_encode_t<4, kEncSteps, 0, 0>(p, st, tm); return; }
+    launch_encode_t<4, kEncSteps, 1, 0>(p, st, tm);
 }
 
 // returns the number of mismatching patterns of the LDS exchange-order self-test (0 = ordered)

@@ -71,11 +71,12 @@ struct qoimi_ctx {
     Arena enc_ws, dec_ws;       // kernel workspaces
     Arena io_a, io_b, io_c;     // staging for the host-pointer (drop-in) path
     uint32_t* host_word = nullptr;   // pinned word for read-backs
+    void* pin_buf = nullptr; size_t pin_cap = 0;   // pinned staging for small host->device tables
     long long dec_stats[4] = {0, 0, 0, 0};
     uint32_t seg_bytes = 0;     // decode segment size; 0: chosen per call from the batch's stream bytes
     uint32_t* last_enc_err = nullptr;   // device flag of the most recent encode launch
     bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
-    int enc_ablate = 0, enc_ticket = 1, enc_quads = 0, enc_prefetch = 0;   // tuning / profiling knobs (env QOIMI_ENC_*)
+    int enc_ablate = 0, enc_ticket = 1, enc_quads = 0, enc_warm = 1;   // tuning / profiling knobs (env QOIMI_ENC_*)
     int enc_lookback = 0;               // 1: single-pass decoupled look-back instead of scratch + compaction
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
@@ -116,7 +117,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_ABLATE")) c->enc_ablate = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_TICKET")) c->enc_ticket = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_QUADS")) c->enc_quads = atoi(e);
-    if (const char* e = getenv("QOIMI_ENC_PREFETCH")) c->enc_prefetch = atoi(e);
+    if (const char* e = getenv("QOIMI_ENC_WARM")) c->enc_warm = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
@@ -133,6 +134,7 @@ extern "C" void qoimi_ctx_destroy(qoimi_ctx* c) {
     (void)hipSetDevice(c->device);
     c->enc_ws.release(); c->dec_ws.release(); c->io_a.release(); c->io_b.release(); c->io_c.release();
     if (c->host_word) (void)hipHostFree(c->host_word);
+    if (c->pin_buf) (void)hipHostFree(c->pin_buf);
     delete c;
 }
 
@@ -173,7 +175,7 @@ extern "C" int qoimi_get_profile(qoimi_ctx* c, void* stream, double* ms, long lo
 }
 
 extern "C" const char* qoimi_kernel_name(int i) {
-    static const char* names[kT_count] = {"", "enc_slab_summary", "enc_scan_groups", "enc_scan_images", "enc_slabs", "enc_offsets", "enc_compact",
+    static const char* names[kT_count] = {"", "enc_slab_summary", "enc_scan_groups", "enc_scan_images", "enc_slabs", "enc_slabs_generic", "enc_offsets", "enc_compact",
         "dec_parse", "dec_chain_parse", "dec_slot_walk", "dec_chain_slots", "dec_summarize", "dec_chain_state",
         "dec_segments", "dec_prepare_restart", "dec_fill"};
     return (i >= 0 && i < kT_count) ? names[i] : "";
@@ -212,8 +214,9 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     {   // slabs one wavefront walks through (it prefetches the next while it encodes one): enough of them that
         // the load latency is hidden, few enough that the grid still fills 256 CUs x 6 workgroups several times
         const size_t total_quads = (size_t)n_images * ((p.spi + 3u) / 4u);
-        size_t r = c->enc_prefetch ? total_quads / 6144u : 1u;
-        p.prefetch = c->enc_prefetch ? 1 : 0;
+        size_t r = 1u;
+        (void)total_quads;
+        p.warm = c->enc_warm ? 1 : 0;
         p.quads_per_wg = c->enc_quads > 0 ? (uint32_t)c->enc_quads : (uint32_t)(r < 1 ? 1 : (r > 16 ? 16 : r));
     }
     if (T > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (slab index overflows 32 bits)");
@@ -221,6 +224,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     for (int pass = 0; pass < 2; ++pass) {      // pass 0 measures, pass 1 carves
         Carver w(pass ? c->enc_ws.base : nullptr);
         p.status = w.take<u64>(T); p.ticket = w.take<uint32_t>((size_t)n_images); p.err = w.take<uint32_t>(1);
+        p.need_generic = w.take<uint32_t>((size_t)n_images); p.any_generic = w.take<uint32_t>(1);
         const size_t zero_bytes = w.off;
         p.sum_tab = w.take<uint32_t>(T * 64); p.sum_valid = w.take<u64>(T); p.sum_le = w.take<int>(T);
         p.ent_tab = w.take<uint32_t>(T * 64); p.ent_valid = w.take<u64>(T); p.ent_le = w.take<int>(T);
@@ -331,8 +335,18 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
         p.grp_summary = w.take<u64>(NG * 65); p.grp_entry = w.take<uint32_t>(NG * 65);
         if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }
     }
-    HIP_TRY(hipMemcpyAsync(p.images, imgs.data(), imgs.size() * sizeof(DecImage), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));       // imgs is pageable host memory
+    {   // image table through pinned staging: no synchronisation (every decode call ends with one, so the
+        // staging buffer is free again when the next call fills it)
+        const size_t bytes = imgs.size() * sizeof(DecImage);
+        if (bytes > c->pin_cap) {
+            if (c->pin_buf) (void)hipHostFree(c->pin_buf);
+            c->pin_buf = nullptr; c->pin_cap = 0;
+            HIP_TRY(hipHostMalloc(&c->pin_buf, bytes + 4096));
+            c->pin_cap = bytes + 4096;
+        }
+        memcpy(c->pin_buf, imgs.data(), bytes);
+        HIP_TRY(hipMemcpyAsync(p.images, c->pin_buf, bytes, hipMemcpyHostToDevice, st));
+    }
     HIP_TRY(hipMemsetAsync(p.redo_segs, 0, sizeof(uint32_t), st));
 
     launch_decode_parse(p, st, &c->timer);
@@ -341,16 +355,17 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
         HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
         launch_decode_round(p, och, rounds > 0 && c->dec_refine, st, &c->timer);
         ++rounds;
-        if (!p.total_segs) break;
+        // pixels the chunks never reach (cheap; redone if the round has to be repeated) - before the read-back,
+        // so that the one synchronisation per round also ends the call
+        launch_decode_fill(p, och, st, &c->timer);
+        if (!p.total_segs) { HIP_TRY(hipStreamSynchronize(st)); break; }
         HIP_TRY(hipMemcpyAsync(c->host_word, p.pending, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         timer_collect(c);
         if (c->host_word[0] == 0) break;
         if (rounds > (long long)total + 2) return fail(QOIMI_E_INTERNAL, "decode repair loop did not converge");
     }
-    launch_decode_fill(p, och, st, &c->timer);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
     timer_collect(c);
     c->dec_stats[0] = rounds;
     c->dec_stats[1] = p.total_segs ? c->host_word[1] : 0;

@@ -13,7 +13,7 @@ constexpr int kHeaderBytes = 14, kTrailerBytes = 8;   // qoi.h:326, qoi.h:339
 // Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's
 // roofline figure).  mark(tag) closes the interval of the kernel launched just before it.
 enum KernelTag { kT_begin = 0,
-                 kT_enc_summary, kT_enc_scan_groups, kT_enc_scan_images, kT_enc_slabs, kT_enc_offsets, kT_enc_compact,
+                 kT_enc_summary, kT_enc_scan_groups, kT_enc_scan_images, kT_enc_slabs, kT_enc_slabs_generic, kT_enc_offsets, kT_enc_compact,
                  kT_dec_parse, kT_dec_chain_parse, kT_dec_slot_walk, kT_dec_chain_slots, kT_dec_summarize,
                  kT_dec_chain_state, kT_dec_segments, kT_dec_restart, kT_dec_fill, kT_count };
 struct KernelTimer {
@@ -42,7 +42,9 @@ struct EncParams {
     uint8_t probe_xchg;      // 1: ds_wrxchg colour-table probe (needs the LDS order self-test to have passed)
     uint8_t use_ticket;      // 1: slab ids by atomic ticket (start order); 0: by blockIdx
     uint8_t ablate;          // profiling only
-    uint8_t prefetch;        // 1: wavefronts walk quads_per_wg slabs and prefetch the next one
+    uint8_t warm;            // 1: slabs find their entry state themselves (look-back window), E1/E2 only for flagged images
+    uint8_t only_flagged;    // set by the launcher: this pass handles images with need_generic[img] != 0 only
+    uint32_t n_units;        // set by the launcher: (image, group of quads_per_wg x 4 slabs) work units
     uint32_t quads_per_wg;   // consecutive 4-slab groups one workgroup walks through
     // workspace
     uint32_t* sum_tab;   u64* sum_valid;  int* sum_le;     // E1 out        [n_images*spi]
@@ -52,6 +54,8 @@ struct EncParams {
     u64* status;         // look-back records [n_images*spi]   -- zeroed before every launch
     uint32_t* ticket;    // per-image slab ticket counters [n_images] -- zeroed before every launch
     uint32_t* err;       // liveness-bound flag               -- zeroed before every launch
+    uint32_t* need_generic;  // [n_images] image needs the E1/E2 path  -- zeroed before every launch
+    uint32_t* any_generic;   // [1]                                    -- zeroed before every launch
     // order-free mode (scratch != nullptr): slabs park their bytes in scratch slots, E4 compacts
     uint8_t* scratch;    // [n_images*spi][kEncScratchStride]
     uint32_t* slab_size; // [n_images*spi]

@@ -96,7 +96,6 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
     const uint32_t total_px = off;
 
     std::vector<uint32_t> entry((size_t)(nseg + 1) * 65u, 0u), fix((size_t)(nseg + 1) * 65u, 0u);
-    std::vector<uint32_t> exits((size_t)(nseg + 1) * 65u, 0u);       // exits[j+1] = state P4 left segment j in (hints of the next round)
     std::vector<sym_t> summary((size_t)(nseg + 1) * 65u);
     std::vector<SlotRec> srec(nseg);
     std::vector<uint8_t> slot_in(nseg), alpha_in(nseg);
@@ -109,7 +108,7 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
         // P2 + S2
         if (refine) {
             for (uint32_t j = start; j < n_active; ++j) {
-                const uint32_t* hs = j == start ? &entry[(size_t)j * 65u] : &exits[(size_t)j * 65u];
+                const uint32_t* hs = &entry[(size_t)j * 65u];      // as the kernels: entry states of the previous round
                 const uint32_t epx = hs[64];
                 slot_in[j] = (uint8_t)hash_px(epx); alpha_in[j] = (uint8_t)(epx >> 24);
             }
@@ -142,7 +141,7 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
         for (uint32_t j = start; j < n_active; ++j) {
             const uint32_t base = 14u + j * B, end = base + B < chunks_end ? base + B : chunks_end;
             SymTab t;
-            const uint32_t* ent = (j == start) ? &entry[(size_t)j * 65u] : &exits[(size_t)j * 65u];
+            const uint32_t* ent = &entry[(size_t)j * 65u];
             const uint32_t a_in = alpha_in[j];
             auto hint = [&](uint32_t src) -> uint32_t { return refine ? ent[src] >> 24 : a_in; };
             const sym_t px = fast ? summarize_segment_fast(in, base + phase[j], end, slot_in[j], alpha_in[j], lut, t, hint)
@@ -192,8 +191,6 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
                                     : decode_segment_fast<3>(in, base + phase[j], end, px, lut, t, out, px_off[j], npx);
             else px = och == 4 ? decode_segment<4>(in, base + phase[j], end, px, t, out, px_off[j], npx)
                                : decode_segment<3>(in, base + phase[j], end, px, t, out, px_off[j], npx);
-            memcpy(&exits[(size_t)(j + 1) * 65u], t.v, 256);
-            exits[(size_t)(j + 1) * 65u + 64u] = px;
             if (j + 1 < n_active) {
                 const uint32_t* nxt = &entry[(size_t)(j + 1) * 65u];
                 if (nxt[64] != px || memcmp(nxt, t.v, 256) != 0) {
