@@ -35,6 +35,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_s4_pmc_traffic.json")
+
+
+def measured_traffic(kernel_prefix: str, grid_threads: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
+    (tools/gpu_session.sh: separate FETCH_SIZE / WRITE_SIZE runs; the counters cannot be collected from inside
+    the process).  Returned only when the profiled launch had the same grid, i.e. the same workload; FETCH_SIZE
+    is doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibration in the file)."""
+    try:
+        doc = json.load(open(TRAFFIC_FILE))
+    except OSError:
+        return None, None
+    for name, k in doc["kernels"].items():
+        if name.startswith(kernel_prefix) and k.get("grid") == grid_threads and "FETCH_SIZE_KB" in k and "WRITE_SIZE_KB" in k:
+            nbytes = (k["FETCH_SIZE_KB"] * doc["read_correction"] + k["WRITE_SIZE_KB"]) * 1024.0
+            return nbytes, f"profiles/{os.path.basename(TRAFFIC_FILE)}: {name} (2 x FETCH_SIZE + WRITE_SIZE)"
+    return None, None
 
 
 def cpu_baseline(kind: str, w: int, h: int, budget_s: float) -> dict:
@@ -181,6 +198,8 @@ def main() -> None:
         per_launch_ms = slabs_ms / max(1, slabs_calls)
         alg_bytes = F * npx * 4                           # 4 B read per pixel
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        slabs = (npx + 1023) // 1024
+        traffic, traffic_src = measured_traffic("qoimi::enc_slabs<4, 16, 1, 0, 1>", ((slabs + 3) // 4) * F * 256)
         out = {
             "metric": "Mpixels/s encode+decode, 4K RGBA", "value": round(value, 1), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
@@ -197,7 +216,7 @@ def main() -> None:
             "decode_rounds": dstats["rounds"], "decode_redo_segments": dstats["redo_segments"],
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
             "roofline": {"bound": "hbm", "kernel": "enc_slabs", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": round(per_launch_ms, 4)},
         }
         if single:

@@ -271,14 +271,25 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     std::vector<DecImage> imgs((size_t)n_images);
     uint32_t B = c->seg_bytes;
     if (B == 0) {
-        // One lane decodes one segment.  Small batches get small segments so that the lanes still fill the
-        // resident wavefronts of the two table-bound passes (~98 K lanes); large batches cap at 2 KiB (the
-        // 520-byte symbolic summary per segment then costs a quarter of the stream traffic).
-        uint64_t bytes = 0;
-        for (int i = 0; i < n_images; ++i) bytes += (uint64_t)(sizes[i] > 0 ? sizes[i] : 0);
-        uint64_t want = bytes / 98304u;
-        B = 128;
-        while (B < 2048u && B < want) B <<= 1;
+        // One lane decodes one segment.  Two costs pull in opposite directions (constants measured on MI355X):
+        //   * a lane walks its segment serially, ~0.6 us per chunk-step over the four passes, and the two
+        //     table-bound passes hold ~98 K lanes at a time: t_walk ~ B/1.2 * 0.6 us * ceil(lanes / 98304)
+        //   * the per-image chains (S1/S2/S3 level 2) walk the image's 64-segment groups one after the other,
+        //     ~0.5 us per group over the three chains: t_chain ~ (largest stream / B / 64) * 0.5 us
+        // Small batches therefore get small segments (more lanes), a single large image not too small ones.
+        // Large batches end at 2 KiB (the 520-byte symbolic summary per segment is then a quarter of the stream).
+        uint64_t bytes = 0, largest = 0;
+        for (int i = 0; i < n_images; ++i) {
+            const uint64_t sz = (uint64_t)(sizes[i] > 0 ? sizes[i] : 0);
+            bytes += sz; if (sz > largest) largest = sz;
+        }
+        double best = 1e30;
+        for (uint32_t cand = 128; cand <= 2048u; cand <<= 1) {
+            const double lanes = (double)bytes / cand;
+            const double rounds = lanes <= 98304.0 ? 1.0 : lanes / 98304.0;
+            const double t = (cand / 1.2) * 0.6 * rounds + ((double)largest / cand / 64.0) * 0.5;
+            if (t < best) { best = t; B = cand; }
+        }
     }
     uint64_t total = 0, total_g = 0;
     for (int i = 0; i < n_images; ++i) {

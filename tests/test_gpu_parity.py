@@ -201,3 +201,42 @@ def test_16k_frame_round_trip(api, ctx):
     assert torch.equal(out[:w * h * 4], b.pixels[:w * h * 4])
     # checksum-of-checksums against the CPU oracle on a 1/64 strip of the same frame is
     # covered at 4K; here the whole-image property is the check.
+
+
+@pytest.mark.parametrize("env", [
+    {"QOIMI_ENC_WARM": "0"},                              # entry states from per-slab summaries + scans for every image
+    {"QOIMI_ENC_LOOKBACK": "1"},                          # single-pass decoupled look-back instead of scratch + compaction
+    {"QOIMI_ENC_PROBE": "0"},                             # order-independent colour-table probe (ds_or masks)
+    {"QOIMI_DEC_FINE": "0", "QOIMI_SEG_BYTES": "2048"},   # lane-per-segment P1/P2 instead of 128-byte pieces
+    {"QOIMI_SEG_BYTES": "1024"},                          # P1/P2 on 8 pieces per segment
+    {"QOIMI_DEC_REFINE": "0", "QOIMI_SEG_BYTES": "2048"},  # repair rounds without alpha hints
+])
+def test_selectable_paths(api, oracle, env):
+    """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = api.Context(0)
+        w, h, n = 1024, 600, 4
+        b = DeviceBatch(c, w, h, 4, n)
+        kinds = ["photo", "noise", "uiflat", "constant"]
+        for i in range(n):
+            c.synth_frames(synth.KIND_ID[kinds[i]], synth.DEFAULT_SEED, 40 + i, 1, w, h,
+                           b.pixels.data_ptr() + i * b.pixel_stride, b.pixel_stride, b.stream)
+        lens = b.encode()
+        for i in range(n):
+            host = synth.frame_rgba(kinds[i], w, h, 40 + i)
+            assert b.stream_bytes(i, lens[i]) == oracle.encode(host, w, h, 4), (env, kinds[i])
+        out = torch.zeros(n * b.pixel_stride, dtype=torch.uint8, device="cuda")
+        b.decode_into(out, lens)
+        assert torch.equal(out.view(n, -1)[:, :w * h * 4], b.pixels.view(n, -1)[:, :w * h * 4]), env
+        c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
