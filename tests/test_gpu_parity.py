@@ -240,3 +240,13 @@ def test_selectable_paths(api, oracle, env):
                 del os.environ[k]
             else:
                 os.environ[k] = v
+
+
+def test_differential_fuzz(api, oracle):
+    """tools/fuzz_decode.py (qoifuzz.c's input convention, but results are compared with the oracle):
+    mutated / truncated / spliced streams, every `channels` argument incl. invalid ones."""
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_decode", os.path.join(sys_path, "fuzz_decode.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    assert fz.run(300, 20260922, api=api, oracle=oracle) == 0
