@@ -156,7 +156,11 @@ struct SlotRec { uint8_t hc, h_rel, h_alpha, a_abs, ac; };
 struct SlotState { uint32_t hc, h_rel, h_alpha, a_abs, ac; };
 
 QOIMI_HD uint32_t lin_hash(uint32_t rgb) {   // 3r+5g+7b of packed bytes (alpha ignored)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(rgb, 0x00070503u, 0u, false);          // one v_dot4_u32_u8
+#else
     return (rgb & 0xFF) * 3u + ((rgb >> 8) & 0xFF) * 5u + ((rgb >> 16) & 0xFF) * 7u;
+#endif
 }
 QOIMI_HD void slot_init(SlotState& s) { s.hc = 0; s.h_rel = 1; s.h_alpha = 0; s.a_abs = 0; s.ac = 0; }
 QOIMI_HD void slot_step(SlotState& s, const Chunk& c) {
@@ -357,7 +361,7 @@ QOIMI_HD void slotf_step(SlotFast& s, uint32_t w32, uint32_t b5, uint32_t info) 
     const uint32_t rgb = w32 >> 8;                                       // r,g,b (RGB / RGBA payload)
     const uint32_t lrgb = lin_hash(rgb);
     const uint32_t ex = luma_extra(w32, info);
-    const uint32_t rel = s.hc + lut_slot_shift(info) + 3u * (ex & 0xFFu) + 7u * (ex >> 16);
+    const uint32_t rel = s.hc + lut_slot_shift(info) + lin_hash(ex);       // ex = (b2>>4, 0, b2&15): 3*(b2>>4) + 7*(b2&15)
     const bool a_abs = (s.fl & 4u) != 0u;
     const uint32_t hc_rgb = lrgb + (a_abs ? 11u * s.ac : 0u);
     const uint32_t hc_rgba = lrgb + 11u * b5;
@@ -396,7 +400,7 @@ QOIMI_HD void symf_step(SymState& s, uint32_t w32, uint32_t b5, uint32_t delta0,
     s.pc = hi ? pb : pa;
     s.ph = hi ? hb : ha;
     const uint32_t lrgb = lin_hash(rgb);
-    const uint32_t s_rel = s.slot + lut_slot_shift(info) + 3u * (ex & 0xFFu) + 7u * (ex >> 16);
+    const uint32_t s_rel = s.slot + lut_slot_shift(info) + lin_hash(ex);
     const uint32_t sa = lo ? b1 : s_rel, sb = lrgb + 11u * (lo ? b5 : s.alpha);
     s.slot = (hi ? sb : sa) & 63u;
     if (hi && lo) s.alpha = b5;                                           // QOI_OP_RGBA

@@ -647,7 +647,7 @@ __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, 
 // flagged.  A workgroup serves unit u = (image u % n_images, group u / n_images) so that the slabs in flight
 // spread over all images.
 template <int CH, int K, int PROBE, int ABL, int ENTRY>
-__global__ __launch_bounds__(256) void enc_slabs(EncParams p) {
+__global__ __launch_bounds__(256, 6) void enc_slabs(EncParams p) {
     __shared__ EncLds<K> s_lds[4];
     __shared__ uint32_t s_ticket;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
