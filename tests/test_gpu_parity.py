@@ -250,3 +250,32 @@ def test_differential_fuzz(api, oracle):
     spec = importlib.util.spec_from_file_location("fuzz_decode", os.path.join(sys_path, "fuzz_decode.py"))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
     assert fz.run(300, 20260922, api=api, oracle=oracle) == 0
+
+
+def test_decode_batch_mixed_shapes(api, ctx, oracle):
+    """One decode batch of differently shaped images (incl. a truncated and a 22-byte stream), 3- and 4-channel output."""
+    import torch
+    from qoi_amd import synth
+    shapes = [(640, 360, "photo"), (97, 1, "noise"), (1, 211, "uiflat"), (1030, 517, "constant"), (333, 444, "photo")]
+    streams, descs = [], []
+    for i, (w, h, kind) in enumerate(shapes):
+        s = oracle.encode(synth.frame_rgba(kind, w, h, 60 + i), w, h, 4)
+        if i == 4:
+            s = s[:len(s) // 2]                         # truncated: remaining pixels repeat the last one (qoi.h:544)
+        streams.append(s); descs.append(api.QoiDesc(w, h, 4, 0))
+    streams.append(b"qoif" + (5).to_bytes(4, "big") + (3).to_bytes(4, "big") + bytes([4, 0]) + b"\0" * 7 + b"\x01")
+    descs.append(api.QoiDesc(5, 3, 4, 0))
+    sstride = (max(len(s) for s in streams) + 8 + 255) // 256 * 256
+    for och in (4, 3):
+        pstride = (max(d.width * d.height for d in descs) * och + 255) // 256 * 256
+        buf = torch.zeros(len(streams) * sstride, dtype=torch.uint8, device="cuda")
+        for i, s in enumerate(streams):
+            buf[i * sstride:i * sstride + len(s)] = torch.from_numpy(np.frombuffer(s, dtype=np.uint8).copy()).cuda()
+        out = torch.full((len(streams) * pstride,), 0xCD, dtype=torch.uint8, device="cuda")
+        ctx.decode_batch(buf.data_ptr(), sstride, [len(s) for s in streams], descs, och, out.data_ptr(), pstride)
+        for i, s in enumerate(streams):
+            want, _ = oracle.decode(s, och)
+            got = out[i * pstride:i * pstride + want.size].cpu().numpy()
+            assert np.array_equal(got, want), (och, i, shapes[i] if i < len(shapes) else "size22")
+            if want.size < pstride:
+                assert int(out[i * pstride + want.size]) == 0xCD, "wrote past the image"
