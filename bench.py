@@ -8,8 +8,9 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 
 A STEP = one pass of the hot path over one batch: every rank encodes its F resident
 3840x2160 RGBA frames (qoimi_encode_batch) and decodes the streams back
-(qoimi_decode_batch).  Frames are synthetic (`photo` class of qoi_amd/synth.py), generated
-on the device, distinct per frame and rank, F*33 MB >> the 256 MiB Infinity Cache, and
+(qoimi_decode_batch); F = 256 by default (8.5 GB of pixels; 1024 = the per-GPU shard of BASELINE
+configs[4] also fits, 176 GB with workspaces).  Frames are synthetic (`photo` class of qoi_amd/synth.py),
+generated on the device, distinct per frame and rank, F*33 MB >> the 256 MiB Infinity Cache, and
 already resident in HBM when the timed region starts.  value = pixels round-tripped per
 second over all ranks.  The round trip is verified bit-exact after the timed region.
 
@@ -98,13 +99,14 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=32, help="4K frames resident per GPU (= per step)")
+    ap.add_argument("--frames", type=int, default=256, help="4K frames resident per GPU (= per step); BASELINE configs[4] is 1024 per GPU")
     ap.add_argument("--kind", default="photo", choices=["photo", "noise", "uiflat", "constant"])
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--encode-only", action="store_true", help="diagnostics: time the encoder alone (no decode, no check)")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-frame figure (profiling runs: keeps every launch batch-sized)")
     args = ap.parse_args()
 
     import torch
@@ -165,7 +167,7 @@ def main() -> None:
     # BASELINE configs[1]: ONE 4K frame, encode + decode, device-resident (33 MB: served by the 256 MiB Infinity
     # Cache on repeat runs and bound by launch latency, not by HBM - reported next to the batch figure, never as it)
     single = None
-    if not args.encode_only and rank == 0:
+    if not args.encode_only and not args.no_single and rank == 0:
         one = [sizes[0]]
         for _ in range(3):
             ctx.encode_batch(pixels.data_ptr(), pstride, desc, 1, streams.data_ptr(), sstride, lens.data_ptr(), stream)
@@ -205,9 +207,9 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"batch of {F} x {w}x{h} RGBA frames per GPU per step (BASELINE configs[4] shape; "
-                                   f"configs[1] frame size), encode + decode, content={args.kind}, HBM-resident, "
-                                   f"bit-exact round trip verified",
+            "config": {"workload": f"batch of {F} x {w}x{h} RGBA frames per GPU per step (BASELINE configs[4]: 8192 such frames "
+                                   f"over 8 GPUs = 1024 per GPU; --frames 1024 runs that shard, the default keeps a quarter of it "
+                                   f"resident), encode + decode, content={args.kind}, HBM-resident, bit-exact round trip verified",
                        "frames_per_gpu": F, "width": w, "height": h, "content": args.kind,
                        "stream_bytes_per_px": round(total_stream_bytes / total_px, 4), "parallelism": f"frames sharded x{world}"},
             "verified_bit_exact": n_ok == world,
