@@ -453,7 +453,9 @@ __global__ __launch_bounds__(256) void dec_slot_walk_fine(DecParams p) {
         if (active) {
             uint32_t w32, b5; R.peek(pos, w32, b5);
             const uint32_t b1 = w32 & 0xFFu;
-            slotf_step(s, w32, b5, s_lut.info[b1]);
+            const uint32_t info = s_lut.info[b1];
+            if (__ballot(lut_hi(info))) slotf_step(s, w32, b5, info);     // some lane stands on QOI_OP_RGB / QOI_OP_RGBA
+            else slotf_step_norgb(s, w32, info);
             pos += len_of(b1);
             active = pos < end;
         }
@@ -743,13 +745,16 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
                 uint32_t pc_rel = pc;
                 add_byte0(pc_rel, delta0); add_byte1(pc_rel, delta0); add_byte2(pc_rel, delta0);
                 add_byte0(pc_rel, er); add_byte2_from0(pc_rel, eb);
-                const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);
-                const uint32_t pc_rgb = (pc & 0xFF000000u) | (rgba & 0x00FFFFFFu);
                 const bool hi = lut_hi(info), lo = lut_lo(info);
-                const uint32_t lrgb = __builtin_amdgcn_udot4(rgba, 0x00070503u, 0u, false);
                 const uint32_t s_rel = slot + lut_slot_shift(info) + 3u * er + 7u * eb;
-                const uint32_t sb = lrgb + 11u * (lo ? b5 : alpha);
-                const uint32_t pb = lo ? rgba : pc_rgb, hb = lo ? (15u << 8) : (ph | (7u << 8));
+                uint32_t sb = 0, pb = 0, hb = 0;
+                if (__ballot(hi)) {                       // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
+                    const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);
+                    const uint32_t pc_rgb = (pc & 0xFF000000u) | (rgba & 0x00FFFFFFu);
+                    const uint32_t lrgb = __builtin_amdgcn_udot4(rgba, 0x00070503u, 0u, false);
+                    sb = lrgb + 11u * (lo ? b5 : alpha);
+                    pb = lo ? rgba : pc_rgb; hb = lo ? (15u << 8) : (ph | (7u << 8));
+                }
                 const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
                 const uint32_t ndelta0 = lq[0], ninfo = lq[256];
                 const uint32_t pa = lo ? t_c : pc_rel, ha = lo ? t_m : ph, sa = lo ? b1 : s_rel;
@@ -930,11 +935,14 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
                 uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
                 // the ways a chunk sets the pixel that need no table (qoi.h:547-575)
                 const uint32_t rel = apply_relative(px, w32, delta0, info);
-                const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);                     // r,g,b,a = chunk bytes 1..4
-                const uint32_t rgbv = (px & 0xFF000000u) | (rgba & 0x00FFFFFFu);
                 const bool hi = lut_hi(info), lo = lut_lo(info);
-                const uint32_t b = lo ? rgba : rgbv;
                 const uint32_t npx = lut_pixels(info);
+                uint32_t b = 0;
+                if (__ballot(hi)) {                       // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
+                    const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);                 // r,g,b,a = chunk bytes 1..4
+                    const uint32_t rgbv = (px & 0xFF000000u) | (rgba & 0x00FFFFFFu);
+                    b = lo ? rgba : rgbv;
+                }
                 // next chunk's table entry
                 const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
                 const uint32_t ndelta0 = lq[0], ninfo = lq[256];

@@ -375,6 +375,14 @@ QOIMI_HD void slotf_step(SlotFast& s, uint32_t w32, uint32_t b5, uint32_t info) 
     s.fl = hi ? fb : fa;
     s.ac = (hi && lo) ? b5 : s.ac;
 }
+// the same step for a chunk that is known not to be QOI_OP_RGB / QOI_OP_RGBA (the kernels take this form when no
+// lane of the wavefront stands on one - natural images carry one such chunk in a thousand)
+QOIMI_HD void slotf_step_norgb(SlotFast& s, uint32_t w32, uint32_t info) {
+    const uint32_t rel = s.hc + lut_slot_shift(info) + lin_hash(luma_extra(w32, info));
+    const bool lo = lut_lo(info);                                        // INDEX
+    s.hc = (lo ? (w32 & 0xFFu) : rel) & 63u;
+    s.fl = lo ? (s.fl & 4u) : s.fl;
+}
 QOIMI_HD void slotf_finish(const SlotFast& s, SlotRec& r) {
     r.hc = (uint8_t)s.hc; r.h_rel = (uint8_t)(s.fl & 1u); r.h_alpha = (uint8_t)((s.fl >> 1) & 1u);
     r.a_abs = (uint8_t)((s.fl >> 2) & 1u); r.ac = (uint8_t)s.ac;
