@@ -373,11 +373,20 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
             active = m < end;
         }
     }
+    // From the byte where the chains met, the chunk sequence no longer depends on the entry phase: the same
+    // walk also yields the speculative slot/alpha transfer (P2) of this tail; dec_slot_heads_fine later adds the
+    // few chunks between the piece's actual entry position and the meeting point.
+    const uint32_t moff = merged ? m - base : 255u;       // chains met at base + moff (<= 132)
     uint32_t add = 0;
+    SlotFast st; slotf_init(st);
     while (__ballot(active)) {
         if (active) {
-            const uint32_t b1 = R.byte(m);
-            add += lut_pixels(s_lut.info[b1]);
+            uint32_t w32, b5; R.peek(m, w32, b5);
+            const uint32_t b1 = w32 & 0xFFu;
+            const uint32_t info = s_lut.info[b1];
+            add += lut_pixels(info);
+            if (__ballot(lut_hi(info))) slotf_step(st, w32, b5, info);    // some lane stands on QOI_OP_RGB / QOI_OP_RGBA
+            else slotf_step_norgb(st, w32, info);
             m += len_of(b1);
             active = m < end;
         }
@@ -387,7 +396,12 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
         s.c0 += add; s.c1 += add; s.c2 += add; s.c3 += add; s.c4 += add;
     }
     ParseRec r; parse_finish(s, base, kFineBytes, r);
-    if (have) p.fine_exit[F] = (uint16_t)r.exit_phase;
+    if (have) {
+        p.fine_exit[F] = (uint16_t)r.exit_phase;
+        SlotRec tr; slotf_finish(st, tr);
+        p.fine_tail[F] = slot_pack(tr);
+        p.fine_moff[F] = (uint8_t)moff;
+    }
     // compose the G (8..64) pieces of every segment: lane `sub` = e < 5 walks the pieces for entry phase e
     s_rec[wave][lane][0] = r.exit_phase;
 #pragma unroll
@@ -414,9 +428,11 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     }
 }
 
-// P2 on 128-byte pieces: entry phase of a piece from the segment's entry phase and the exit maps of the
-// pieces before it (written by dec_parse_fine), then the slot transfers of the pieces are composed in order.
-__global__ __launch_bounds__(256) void dec_slot_walk_fine(DecParams p) {
+// P2 on 128-byte pieces.  dec_parse_fine already walked every piece from the byte where its five phase chains
+// met and left the slot transfer of that tail; what is missing is the head: the few chunks from the piece's
+// actual entry position (segment entry phase pushed through the exit maps of the pieces before it) to the
+// meeting point.  Head and tail compose to the piece's transfer, the pieces' transfers to the segment's.
+__global__ __launch_bounds__(256) void dec_slot_heads_fine(DecParams p) {
     __shared__ uint32_t s_buf[4][kFineDwords * 64];
     __shared__ uint32_t s_x[4][64];
     __shared__ LdsLut s_lut;
@@ -435,10 +451,10 @@ __global__ __launch_bounds__(256) void dec_slot_walk_fine(DecParams p) {
     const uint32_t cend = min(cbase + p.seg_bytes, im.chunks_end);
     const uint32_t base = cbase + sub * kFineBytes;
     const uint32_t end = min(base + kFineBytes, cend);
-    FineBuf R;
-    R.init(lds_addr_of(&s_buf[wave][lane]), p.streams + im.stream_off, min(base, im.chunks_end), im.chunks_end + kTrailerBytes);
     // entry phase of this piece
     s_x[wave][lane] = have ? p.fine_exit[F] : 0u;
+    const uint32_t moff = have ? p.fine_moff[F] : 255u;
+    const uint32_t tail = have ? p.fine_tail[F] : slot_pack(SlotRec{0, 1, 0, 0, 0});
     __builtin_amdgcn_wave_barrier();
     const uint32_t g0 = lane - sub;
     uint32_t ph = have ? p.entry_phase[q] : 0u;
@@ -447,20 +463,40 @@ __global__ __launch_bounds__(256) void dec_slot_walk_fine(DecParams p) {
         if (k < sub) ph = (mp >> (3u * ph)) & 7u;
     }
     uint32_t pos = base + ph;
+    const uint32_t stop = moff == 255u ? end : min(base + moff, end);     // never met: the head is the whole piece
+    bool active = have && pos < stop;
+    // bytes [pos, stop + 8) of the lanes that have a head at all; usually one or two 16-byte pieces
+    const uint32_t lo16 = min(base, im.chunks_end);
+    FineBuf R;
+    {
+        const uint8_t* stream = p.streams + im.stream_off;
+        const uint8_t* pp = stream + lo16;
+        const uint8_t* abase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(pp) & ~(uintptr_t)15);
+        const uint8_t* aend = stream + im.chunks_end + kTrailerBytes;
+        R.buf = lds_addr_of(&s_buf[wave][lane]);
+        R.aoff = lo16 - (uint32_t)(pp - abase);
+        const uint32_t need = active ? (stop - R.aoff + 8u + 15u) >> 4 : 0u;      // 16-byte pieces this lane needs
+        for (uint32_t r = 0; r < kFinePieces; ++r) {
+            if (!__ballot(r < need)) break;
+            if (r < need) {
+                const uint4 v = abase + 16u * r < aend ? load_global16(abase + 16u * r) : make_uint4(0u, 0u, 0u, 0u);
+                lds_u32* qd = (lds_u32*)(R.buf + r * 1024u);
+                qd[0] = v.x; qd[64] = v.y; qd[128] = v.z; qd[192] = v.w;
+            }
+        }
+    }
     SlotFast s; slotf_init(s);
-    bool active = have && pos < end;
     while (__ballot(active)) {
         if (active) {
             uint32_t w32, b5; R.peek(pos, w32, b5);
             const uint32_t b1 = w32 & 0xFFu;
-            const uint32_t info = s_lut.info[b1];
-            if (__ballot(lut_hi(info))) slotf_step(s, w32, b5, info);     // some lane stands on QOI_OP_RGB / QOI_OP_RGBA
-            else slotf_step_norgb(s, w32, info);
+            slotf_step(s, w32, b5, s_lut.info[b1]);
             pos += len_of(b1);
-            active = pos < end;
+            active = pos < stop;
         }
     }
     SlotRec r; slotf_finish(s, r);
+    if (moff != 255u) r = slot_compose(r, slot_unpack(tail));
     __builtin_amdgcn_wave_barrier();
     s_x[wave][lane] = slot_pack(r);
     __builtin_amdgcn_wave_barrier();
@@ -1057,7 +1093,7 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
         hipLaunchKernelGGL(dec_summarize<true>, dim3(b64), dim3(64), 0, st, p);
         tm->mark(kT_dec_summarize, st);
     } else {
-    if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_walk_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+    if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_heads_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(dec_slot_walk, dim3(b256), dim3(256), 0, st, p);
     tm->mark(kT_dec_slot_walk, st);
     hipLaunchKernelGGL(dec_chain_slots_l1, dim3(p.total_grps), dim3(64), 0, st, p);

@@ -337,6 +337,8 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
         p.images = w.take<DecImage>((size_t)n_images);
         p.first_bad = w.take<uint32_t>((size_t)n_images);
         p.fine_exit = w.take<uint16_t>(p.fine_per_seg ? Q * p.fine_per_seg : 1);
+        p.fine_tail = w.take<uint32_t>(p.fine_per_seg ? Q * p.fine_per_seg : 1);
+        p.fine_moff = w.take<uint8_t>(p.fine_per_seg ? Q * p.fine_per_seg : 1);
         p.parse = w.take<ParseRec>(Q); p.entry_phase = w.take<uint8_t>(Q); p.px_off = w.take<uint32_t>(Q);
         p.slot_rec = w.take<SlotRec>(Q); p.slot_in = w.take<uint8_t>(Q); p.alpha_in = w.take<uint8_t>(Q);
         p.summary = w.take<u64>(Q * 65); p.entry = w.take<uint32_t>(Q * 65); p.fix = w.take<uint32_t>(Q * 65);
