@@ -178,6 +178,9 @@ __device__ __forceinline__ uint32_t apply_relative(uint32_t px, uint32_t w32, ui
 // store as well).  Pixels of a group shared with the neighbouring segment (head / tail) are written
 // one by one.
 // ---------------------------------------------------------------------------------
+#ifndef QOIMI_DRAIN_GROUP
+#define QOIMI_DRAIN_GROUP 4
+#endif
 template <int OCH>
 struct LaneWriter {
     static constexpr uint32_t kRing = 16;
@@ -194,19 +197,35 @@ struct LaneWriter {
         if (OCH == 4) reinterpret_cast<uint32_t*>(out)[i] = px;
         else { uint8_t* d = out + (size_t)i * 3u; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
     }
-    // write out every complete aligned group; a leading partial group (segment head) pixel by pixel
+    // write out every complete aligned group of kGroup pixels; a leading partial group (segment head) pixel by
+    // pixel.  kGroup = 4: one 16-byte store per group.  (8-pixel groups - a whole 32-byte sector per lane at a
+    // time - halve the partial writes the memory side sees (WRITE_SIZE is 2.4 x the pixel bytes with 4) but the
+    // kernel is not bound by its stores: it runs as fast with the stores compiled out, r01 session v1.)
+    static constexpr uint32_t kGroup = QOIMI_DRAIN_GROUP;
+    __device__ __forceinline__ void store4(uint32_t i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+#ifdef QOIMI_ABL_NOSTORE
+        if (v0 == 0x12345678u && v1 == v2 + v3)
+#endif
+        if (OCH == 4) {
+            *reinterpret_cast<uint4*>(out + (size_t)i * 4u) = make_uint4(v0, v1, v2, v3);
+        } else {                                                      // 4 pixels -> 3 dwords of packed r,g,b
+            const uint32_t a = v0 & 0xFFFFFFu, b = v1 & 0xFFFFFFu, c = v2 & 0xFFFFFFu, e = v3 & 0xFFFFFFu;
+            uint32_t* d = reinterpret_cast<uint32_t*>(out + (size_t)i * 3u);
+            d[0] = a | (b << 24); d[1] = (b >> 8) | (c << 16); d[2] = (c >> 16) | (e << 8);
+        }
+    }
     __device__ __forceinline__ void drain() {
         while ((fpos & 3u) != 0u && fpos < ppos) { store_one(fpos, at(fpos)); ++fpos; }
-        while (fpos + 4u <= ppos) {
-            const uint32_t v0 = at(fpos), v1 = at(fpos + 1u), v2 = at(fpos + 2u), v3 = at(fpos + 3u);
-            if (OCH == 4) {
-                *reinterpret_cast<uint4*>(out + (size_t)fpos * 4u) = make_uint4(v0, v1, v2, v3);
-            } else {                                                      // 4 pixels -> 3 dwords of packed r,g,b
-                const uint32_t a = v0 & 0xFFFFFFu, b = v1 & 0xFFFFFFu, c = v2 & 0xFFFFFFu, e = v3 & 0xFFFFFFu;
-                uint32_t* d = reinterpret_cast<uint32_t*>(out + (size_t)fpos * 3u);
-                d[0] = a | (b << 24); d[1] = (b >> 8) | (c << 16); d[2] = (c >> 16) | (e << 8);
-            }
-            fpos += 4u;
+        if (kGroup == 8u && (fpos & 4u) != 0u && fpos + 4u <= ppos) {          // segment head / after a splat
+            store4(fpos, at(fpos), at(fpos + 1u), at(fpos + 2u), at(fpos + 3u)); fpos += 4u;
+        }
+        while (fpos + kGroup <= ppos) {
+            uint32_t v[kGroup];
+#pragma unroll
+            for (uint32_t k = 0; k < kGroup; ++k) v[k] = at(fpos + k);
+#pragma unroll
+            for (uint32_t k = 0; k < kGroup; k += 4u) store4(fpos + k, v[k], v[k + 1u], v[k + 2u], v[k + 3u]);
+            fpos += kGroup;
         }
     }
     __device__ __forceinline__ void put(uint32_t px) {
@@ -715,8 +734,8 @@ struct LdsSymTab {
 // verify in 2-5 rounds with the hints (one segment per round without them).
 template <bool REFINE>
 __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
-    __shared__ uint32_t s_tabc[64 * 64];
-    __shared__ uint16_t s_tabm[64 * 64];
+    __shared__ uint32_t s_tabc[65 * 64];          // row 64: kSymParkRow
+    __shared__ uint16_t s_tabm[65 * 64];
     __shared__ uint32_t s_ring[LaneReader::kSlots * 64];
     __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 64];
     __shared__ LdsLut s_lut;
@@ -761,6 +780,7 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
         slot = have ? p.slot_in[q] : 0u; alpha = have ? p.alpha_in[q] : 0u;
     }
     const uint32_t alpha_in0 = alpha;
+    const uint32_t runmask = j == 0u ? 0u : kLutRunBit;      // RUN chunks store nothing new except as a stream's first chunk (SymState)
     bool active = have && pos < end;
     uint32_t w32, b5; R.peek(pos, w32, b5);
     uint32_t delta0, info;
@@ -801,8 +821,9 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
                 const uint32_t th = REFINE ? (uint32_t)s_hint[(t_m & 0x7Fu) * 64u + lane] : alpha_in0;
                 const uint32_t ta = (t_m & 0x800u) ? (t_c >> 24) : th;
                 alpha = hi ? (lo ? b5 : alpha) : (lo ? ta : alpha);
-                *(lds_u32*)(tc_base + (slot << 8)) = pc;          // index update after every chunk (qoi.h:577)
-                *(lds_u16*)(tm_base + (slot << 7)) = (uint16_t)ph;
+                const uint32_t wslot = (info & runmask) ? kSymParkRow : slot;
+                *(lds_u32*)(tc_base + (wslot << 8)) = pc;         // index update after every chunk (qoi.h:577)
+                *(lds_u16*)(tm_base + (wslot << 7)) = (uint16_t)ph;
                 pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
                 active = pos < end;
             }

@@ -235,12 +235,21 @@ QOIMI_HD sym_t sym_compose(sym_t b, sym_t a_src) {
     return sym_make(c, sym_src(a_src), sym_abs(b) | sym_abs(a_src));
 }
 
-struct SymState { uint32_t pc, ph, slot, alpha; };   // running pixel: constants, source|absmask<<8; speculated slot/alpha
+// After every chunk the decoder stores the pixel at index[hash(pixel)] (qoi.h:577).  A QOI_OP_RUN chunk leaves the
+// pixel as it is, so - except as the very first chunk of a stream, when the start pixel is not in the table yet -
+// its store rewrites what the previous chunk stored: the summary skips it (the word goes to the spare row
+// kSymParkRow).  This matters: a segment that begins inside a run would otherwise store the entry pixel at the
+// SPECULATED entry slot, and one wrong guess (the entry pixel taken from a table word that an earlier
+// mis-speculation misplaced) used to spoil a table word for all later segments; frames whose alpha changes through
+// the colour table needed up to 90 restart rounds for that reason alone, 2-3 with the store skipped.
+constexpr uint32_t kSymParkRow = 64u;
+constexpr uint32_t kLutRunBit = 1u << 15;         // lut_entry: info bit 15
+struct SymState { uint32_t pc, ph, slot, alpha, runmask; };   // running pixel: constants, source|absmask<<8; speculated slot/alpha; kLutRunBit unless first segment
 // Tab: accessor with get(slot) / set(slot, sym_t).
 template <class Tab>
-QOIMI_HD void sym_init(SymState& s, uint32_t slot, uint32_t alpha, Tab& tab) {
+QOIMI_HD void sym_init(SymState& s, uint32_t slot, uint32_t alpha, Tab& tab, bool stream_start) {
     for (uint32_t k = 0; k < 64; ++k) tab.set(k, sym_make(0u, k, 0u));
-    s.pc = 0u; s.ph = 64u; s.slot = slot; s.alpha = alpha;
+    s.pc = 0u; s.ph = 64u; s.slot = slot; s.alpha = alpha; s.runmask = stream_start ? 0u : kLutRunBit;
 }
 template <class Tab>
 QOIMI_HD void sym_step(SymState& s, const Chunk& c, Tab& tab) {
@@ -253,15 +262,15 @@ QOIMI_HD void sym_step(SymState& s, const Chunk& c, Tab& tab) {
     const uint32_t s_rgba = lin_hash(rgb) + 11u * (c.rgba >> 24);
     s.slot = (c.is_rgb ? s_rgb : (c.is_rgba ? s_rgba : (c.is_index ? c.b1 : s.slot + lin_hash(c.delta)))) & 63u;
     s.alpha = c.is_rgba ? (c.rgba >> 24) : s.alpha;
-    tab.set(s.slot, (sym_t)s.pc | ((sym_t)s.ph << 32));          // index update after every chunk (qoi.h:577)
+    tab.set((c.is_run && s.runmask) ? kSymParkRow : s.slot, (sym_t)s.pc | ((sym_t)s.ph << 32));   // index update after every chunk (qoi.h:577)
 }
 QOIMI_HD sym_t sym_pixel(const SymState& s) { return (sym_t)s.pc | ((sym_t)s.ph << 32); }
 
 // Processes every chunk that starts in [pos, seg_end).  slot/alpha: speculated entry values.
 template <class Tab>
 QOIMI_HD sym_t summarize_segment(const uint8_t* in, uint32_t pos, uint32_t seg_end,
-                                 uint32_t slot, uint32_t alpha, Tab& tab) {
-    SymState s; sym_init(s, slot, alpha, tab);
+                                 uint32_t slot, uint32_t alpha, Tab& tab, bool stream_start) {
+    SymState s; sym_init(s, slot, alpha, tab, stream_start);
     while (pos < seg_end) {
         const Chunk c = crack(load8(in + pos));
         sym_step(s, c, tab);
@@ -320,20 +329,21 @@ QOIMI_HD uint32_t decode_segment(const uint8_t* in, uint32_t pos, uint32_t seg_e
 //   info    bits 0..2   chunk length (1,2,4,5)                         qoi.h:547-575
 //           bits 3..8   pixels produced (1, RUN: 1..62)               qoi.h:573-575
 //           bits 9..14  slot shift of the chunk: lin_hash(delta) & 63 (LUMA: of its base)
+//           bit  15     RUN (qoi.h:573-575)
 //           bit  28     LUMA (second byte adds (b2>>4) to r and (b2&15) to b, qoi.h:566-571)
 //           bits 30,31  op class: 0 relative (DIFF/LUMA/RUN), 1 INDEX, 2 RGB, 3 RGBA
 // =====================================================================================
 QOIMI_HD void lut_entry(uint32_t b, uint32_t& delta, uint32_t& info) {
     const uint32_t top = b >> 6;
-    uint32_t len = 1, npx = 1, code = 0, luma = 0;
+    uint32_t len = 1, npx = 1, code = 0, luma = 0, run = 0;
     delta = 0;
     if (b == 0xFEu) { len = 4; code = 2; }
     else if (b == 0xFFu) { len = 5; code = 3; }
     else if (top == 0u) { code = 1; }
     else if (top == 1u) { delta = diff_delta(b); }
     else if (top == 2u) { len = 2; luma = 1; delta = luma_delta(b, 0u); }
-    else { npx = (b & 0x3Fu) + 1u; }
-    info = len | (npx << 3) | ((lin_hash(delta) & 63u) << 9) | (luma << 28) | (code << 30);
+    else { npx = (b & 0x3Fu) + 1u; run = 1; }
+    info = len | (npx << 3) | ((lin_hash(delta) & 63u) << 9) | (run << 15) | (luma << 28) | (code << 30);
 }
 QOIMI_HD uint32_t lut_len(uint32_t info) { return info & 7u; }
 QOIMI_HD uint32_t lut_pixels(uint32_t info) { return (info >> 3) & 63u; }
@@ -413,7 +423,7 @@ QOIMI_HD void symf_step(SymState& s, uint32_t w32, uint32_t b5, uint32_t delta0,
     s.slot = (hi ? sb : sa) & 63u;
     if (hi && lo) s.alpha = b5;                                           // QOI_OP_RGBA
     else if (lo) s.alpha = (sym_abs(t) & 8u) ? (uint32_t)t >> 24 : hint(sym_src(t));   // QOI_OP_INDEX
-    tab.set(s.slot, (sym_t)s.pc | ((sym_t)s.ph << 32));          // index update after every chunk (qoi.h:577)
+    tab.set((info & s.runmask) ? kSymParkRow : s.slot, (sym_t)s.pc | ((sym_t)s.ph << 32));   // index update after every chunk (qoi.h:577)
 }
 
 // ---- P4: concrete step, same function as pixel_step --------------------------------------
@@ -457,9 +467,9 @@ QOIMI_HD void slot_walk_segment_fast(const uint8_t* in, uint32_t pos, uint32_t s
 }
 template <class Lut, class Tab, class Hint>
 QOIMI_HD sym_t summarize_segment_fast(const uint8_t* in, uint32_t pos, uint32_t seg_end, uint32_t slot, uint32_t alpha,
-                                      const Lut& lut, Tab& tab, const Hint& hint) {
+                                      const Lut& lut, Tab& tab, const Hint& hint, bool stream_start) {
     PtrReader R{in};
-    SymState s; sym_init(s, slot, alpha, tab);
+    SymState s; sym_init(s, slot, alpha, tab, stream_start);
     while (pos < seg_end) {
         uint32_t w32, b5; R.peek(pos, w32, b5);
         const uint32_t b1 = w32 & 0xFFu;

@@ -20,7 +20,7 @@
 using namespace qoimi;
 
 namespace {
-struct SymTab { sym_t v[64]; sym_t get(uint32_t k) const { return v[k]; } void set(uint32_t k, sym_t x) { v[k] = x; } };
+struct SymTab { sym_t v[65]; sym_t get(uint32_t k) const { return v[k]; } void set(uint32_t k, sym_t x) { v[k] = x; } };
 struct Tab32 { uint32_t v[64]; uint32_t get(uint32_t k) const { return v[k]; } void set(uint32_t k, uint32_t x) { v[k] = x; } };
 }
 
@@ -47,6 +47,7 @@ extern "C" int host_check_lut(void) {
     int bad = 0;
     for (uint32_t b = 0; b < 256; ++b) {
         if (len_of(b) != chunk_len(b) || lut_len(lut.info[b]) != chunk_len(b) || lut_pixels(lut.info[b]) != chunk_pixels(b)) ++bad;
+        if (((lut.info[b] & kLutRunBit) != 0u) != crack((unsigned long long)b).is_run) ++bad;
     }
     return bad;
 }
@@ -144,8 +145,8 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
             const uint32_t* ent = &entry[(size_t)j * 65u];
             const uint32_t a_in = alpha_in[j];
             auto hint = [&](uint32_t src) -> uint32_t { return refine ? ent[src] >> 24 : a_in; };
-            const sym_t px = fast ? summarize_segment_fast(in, base + phase[j], end, slot_in[j], alpha_in[j], lut, t, hint)
-                                  : summarize_segment(in, base + phase[j], end, slot_in[j], alpha_in[j], t);
+            const sym_t px = fast ? summarize_segment_fast(in, base + phase[j], end, slot_in[j], alpha_in[j], lut, t, hint, j == 0)
+                                  : summarize_segment(in, base + phase[j], end, slot_in[j], alpha_in[j], t, j == 0);
             for (int k = 0; k < 64; ++k) summary[(size_t)j * 65u + k] = t.v[k];
             summary[(size_t)j * 65u + 64u] = px;
         }

@@ -19,20 +19,30 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
   echo "$set rc=$?"
 done
 python - "$OUT" <<'PY'
+# per kernel: mean FETCH_SIZE / WRITE_SIZE (KB, as reported) over the batch launches = the launches with the
+# kernel's largest grid (verification and single-image launches use smaller grids)
 import csv, glob, json, sys, collections
 out = sys.argv[1]
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
+rows = collections.defaultdict(list)
 for f in glob.glob(out + '/pmc_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0].replace('void ', '')
         if 'qoimi::' in k:
-            agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
-res = {}
-for k in sorted(agg):
-    res[k] = {c: sum(v) / len(v) for c, v in agg[k].items()}
-    res[k]['launches'] = max(len(v) for v in agg[k].values())
-json.dump(res, open(out + '/pmc_traffic.json', 'w'), indent=1)
-for k, v in res.items():
-    print(k[:48], {c: round(x, 1) for c, x in v.items()})
+            rows[k].append((int(r['Grid_Size']), r['Counter_Name'], float(r['Counter_Value'])))
+kern = {}
+for k in sorted(rows):
+    g = max(x[0] for x in rows[k])
+    e = {'grid': g}
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        v = [x[2] for x in rows[k] if x[0] == g and x[1] == c]
+        if v:
+            e[c + '_KB'] = round(sum(v) / len(v), 1); e['launches_averaged'] = len(v)
+    kern[k] = e
+doc = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu --no-single (two separate passes, tools/gpu_session.sh)",
+       "note": "per-launch means over the batch launches (largest grid of each kernel); KB as rocprofv3 reports them. gfx950: FETCH_SIZE tallies 128-byte read requests at 64 bytes (MI355X_MICROARCH.md HBM section); calibration: enc_slab_summary is a pure streaming read of every pixel byte of the batch, its FETCH_SIZE comes out at ~0.5 x those bytes -> read bytes = 2 x FETCH_SIZE. WRITE_SIZE is taken as reported.",
+       "read_correction": 2.0, "kernels": kern}
+json.dump(doc, open(out + '/pmc_traffic.json', 'w'), indent=1)
+for k, v in kern.items():
+    print(k[:56], v)
 PY
 echo "== done"

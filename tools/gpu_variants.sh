@@ -1,0 +1,21 @@
+#!/bin/bash
+# build-flag ablations on the GPU box (diagnostic): rebuilds qoi_decode.hip / qoi_encode.hip with extra -D flags and runs the bench
+# usage: VARIANTS="base:;g4:-DQOIMI_DRAIN_GROUP=4" KINDS="photo" BENCH_ARGS="--frames 32" bash tools/gpu_variants.sh name
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out/${1:-var}; mkdir -p $OUT; export TMPDIR=/tmp
+BASEFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
+IFS=';' read -ra VS <<< "${VARIANTS:-base:}"
+for v in "${VS[@]}"; do
+  name=${v%%:*}; defs=${v#*:}
+  touch qoi_amd/csrc/qoi_decode.hip qoi_amd/csrc/qoi_encode.hip
+  make -C qoi_amd/csrc FLAGS="$BASEFLAGS $defs" > $OUT/build_$name.log 2>&1 || { echo "build $name failed"; tail -5 $OUT/build_$name.log; continue; }
+  for kind in ${KINDS:-photo}; do
+    timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --no-single --kind $kind ${BENCH_ARGS:-} > $OUT/${name}_$kind.log 2>&1
+    python - $OUT/${name}_$kind.log $name <<'PY'
+import json,sys
+for l in open(sys.argv[1]):
+    if l.startswith('{'):
+        d=json.loads(l); k=d['kernel_ms_per_step']
+        print(sys.argv[2], d['config']['content'], 'value', d['value'], 'exact', d['verified_bit_exact'], 'rounds', d.get('decode_rounds'), {x:k[x] for x in k if k[x]>0.05})
+PY
+  done
+done
