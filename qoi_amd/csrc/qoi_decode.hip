@@ -565,17 +565,69 @@ __global__ __launch_bounds__(64) void dec_chain_parse_l1(DecParams p) {
     if (lane == 0) p.grp_parse[G] = g;
 }
 
-__global__ __launch_bounds__(64) void dec_chain_parse_l2(DecParams p) {
-    const uint32_t img = blockIdx.x, lane = lane_id();
+// The l2 kernels chain the group records of ONE image.  A single 4K frame has hundreds of groups, a 16384 x 16384
+// image thousands, and a lone wavefront walking them one after the other was most of the decode time of such
+// calls.  One block of kL2Waves wavefronts per image instead: every wavefront composes the records of its
+// contiguous share of the groups (A), wavefront 0 chains the kL2Waves shares (B), every wavefront sweeps its share
+// from the entry value it was given (C): serial depth 2 * ngrp / kL2Waves + kL2Waves instead of ngrp.
+constexpr uint32_t kL2Waves = 16;
+
+__global__ __launch_bounds__(64 * kL2Waves) void dec_chain_parse_l2(DecParams p) {
+    __shared__ uint32_t s_rec[kL2Waves][6];      // share record: exit-phase map, pixels[5]
+    __shared__ uint32_t s_in[kL2Waves][2];       // share entry: phase, pixel offset
+    const uint32_t img = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const DecImage im = p.images[img];
-    uint32_t phase = 0; u64 off = 0;
-    for (uint32_t g0 = 0; g0 < im.ngrp; g0 += 64u) {
+    const uint32_t per = (im.ngrp + kL2Waves - 1u) / kL2Waves;
+    const uint32_t lo = min(wave * per, im.ngrp), hi = min(lo + per, im.ngrp);
+    // A: lanes 0..4 walk the share for entry phase = lane
+    {
+        uint32_t ph = min(lane, 4u);
+        u64 sum = 0;
+        for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {
+            ParseRec r; r.exit_phase = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) r.pixels[k] = 0;
+            if (g0 + lane < hi) r = p.grp_parse[im.grp_base + g0 + lane];
+            const uint32_t cnt = min(64u, hi - g0);
+            for (uint32_t l = 0; l < cnt; ++l) {
+                const uint32_t ex = read_lane_dyn(r.exit_phase, l);
+                const uint32_t a0 = read_lane_dyn(r.pixels[0], l), a1 = read_lane_dyn(r.pixels[1], l), a2 = read_lane_dyn(r.pixels[2], l),
+                               a3 = read_lane_dyn(r.pixels[3], l), a4 = read_lane_dyn(r.pixels[4], l);
+                sum += sel5(ph, a0, a1, a2, a3, a4);
+                ph = (ex >> (3u * ph)) & 7u;
+            }
+        }
+        const uint32_t capped = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum;   // > any legal pixel count anyway
+        uint32_t map = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) map |= read_lane(ph, k) << (3 * k);
+        if (lane == 0) s_rec[wave][0] = map;
+        if (lane < 5u) s_rec[wave][1u + lane] = capped;
+    }
+    __syncthreads();
+    // B
+    if (wave == 0 && lane == 0) {
+        uint32_t phase = 0; u64 off = 0;
+        for (uint32_t c = 0; c < kL2Waves; ++c) {
+            s_in[c][0] = phase; s_in[c][1] = (uint32_t)off;
+            off = min(off + s_rec[c][1u + phase], (u64)im.npx);
+            phase = (s_rec[c][0] >> (3u * phase)) & 7u;
+        }
+        p.images[img].total_px = (uint32_t)off;
+        p.images[img].n_active = 0;              // raised by l3
+        p.images[img].start_seg = 0;
+        p.first_bad[img] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    // C
+    uint32_t phase = s_in[wave][0]; u64 off = s_in[wave][1];
+    for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {
         ParseRec r; r.exit_phase = 0;
 #pragma unroll
         for (int k = 0; k < 5; ++k) r.pixels[k] = 0;
-        if (g0 + lane < im.ngrp) r = p.grp_parse[im.grp_base + g0 + lane];
+        if (g0 + lane < hi) r = p.grp_parse[im.grp_base + g0 + lane];
         uint32_t my_phase = 0, my_off = 0;
-        const uint32_t cnt = min(64u, im.ngrp - g0);
+        const uint32_t cnt = min(64u, hi - g0);
         for (uint32_t l = 0; l < cnt; ++l) {
             if (lane == l) { my_phase = phase; my_off = (uint32_t)min(off, (u64)im.npx); }
             const uint32_t add = read_lane_dyn(sel5(phase, r.pixels[0], r.pixels[1], r.pixels[2], r.pixels[3], r.pixels[4]), l);
@@ -583,13 +635,7 @@ __global__ __launch_bounds__(64) void dec_chain_parse_l2(DecParams p) {
             off = min(off + add, (u64)im.npx);
             phase = (ex >> (3u * phase)) & 7u;
         }
-        if (g0 + lane < im.ngrp) { p.grp_phase[im.grp_base + g0 + lane] = (uint8_t)my_phase; p.grp_off[im.grp_base + g0 + lane] = my_off; }
-    }
-    if (lane == 0) {
-        p.images[img].total_px = (uint32_t)off;
-        p.images[img].n_active = 0;              // raised by l3
-        p.images[img].start_seg = 0;
-        p.first_bad[img] = 0xFFFFFFFFu;
+        if (g0 + lane < hi) { p.grp_phase[im.grp_base + g0 + lane] = (uint8_t)my_phase; p.grp_off[im.grp_base + g0 + lane] = my_off; }
     }
 }
 
@@ -669,25 +715,50 @@ __global__ __launch_bounds__(64) void dec_chain_slots_l1(DecParams p) {
 }
 
 // S2 l2: chain the groups of one image from the group holding start_seg; the start value is the
-// hash/alpha of start_seg's concrete entry pixel
-__global__ __launch_bounds__(64) void dec_chain_slots_l2(DecParams p) {
-    const uint32_t img = blockIdx.x, lane = lane_id();
+// hash/alpha of start_seg's concrete entry pixel.  Shares as in dec_chain_parse_l2.
+__global__ __launch_bounds__(64 * kL2Waves) void dec_chain_slots_l2(DecParams p) {
+    __shared__ uint32_t s_rec[kL2Waves];         // packed transfer of the share
+    __shared__ uint32_t s_in[kL2Waves][2];       // share entry: slot, alpha
+    const uint32_t img = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const DecImage im = p.images[img];
     if (im.start_seg >= im.n_active) return;
-    const uint32_t px0 = p.entry[(size_t)(im.seg_base + im.start_seg) * 65u + 64u];
-    uint32_t slot = hash_px(px0), alpha = px0 >> 24;
     const uint32_t gfirst = im.start_seg / kGrp, gend = (im.n_active + kGrp - 1u) / kGrp;
-    for (uint32_t g0 = gfirst; g0 < gend; g0 += 64u) {
+    const uint32_t per = (gend - gfirst + kL2Waves - 1u) / kL2Waves;
+    const uint32_t lo = min(gfirst + wave * per, gend), hi = min(lo + per, gend);
+    {   // A
+        SlotRec acc = {0, 1, 0, 0, 0};
+        for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {
+            SlotRec mine = {0, 1, 0, 0, 0};
+            if (g0 + lane < hi) mine = p.grp_slot[im.grp_base + g0 + lane];
+            const uint32_t packed = slot_pack(mine);
+            const uint32_t cnt = min(64u, hi - g0);
+            for (uint32_t l = 0; l < cnt; ++l) acc = slot_compose(acc, slot_unpack(read_lane_dyn(packed, l)));
+        }
+        if (lane == 0) s_rec[wave] = slot_pack(acc);
+    }
+    __syncthreads();
+    if (wave == 0 && lane == 0) {   // B
+        const uint32_t px0 = p.entry[(size_t)(im.seg_base + im.start_seg) * 65u + 64u];
+        uint32_t slot = hash_px(px0), alpha = px0 >> 24;
+        for (uint32_t c = 0; c < kL2Waves; ++c) {
+            s_in[c][0] = slot; s_in[c][1] = alpha;
+            slot_apply(slot_unpack(s_rec[c]), slot, alpha);
+        }
+    }
+    __syncthreads();
+    // C
+    uint32_t slot = s_in[wave][0], alpha = s_in[wave][1];
+    for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {
         SlotRec mine = {0, 1, 0, 0, 0};
-        if (g0 + lane < gend) mine = p.grp_slot[im.grp_base + g0 + lane];
+        if (g0 + lane < hi) mine = p.grp_slot[im.grp_base + g0 + lane];
         const uint32_t packed = slot_pack(mine);
         uint32_t my_slot = 0, my_alpha = 0;
-        const uint32_t cnt = min(64u, gend - g0);
+        const uint32_t cnt = min(64u, hi - g0);
         for (uint32_t l = 0; l < cnt; ++l) {
             if (lane == l) { my_slot = slot; my_alpha = alpha; }
             slot_apply(slot_unpack(read_lane_dyn(packed, l)), slot, alpha);
         }
-        if (g0 + lane < gend) { p.grp_slot_in[im.grp_base + g0 + lane] = (uint8_t)my_slot; p.grp_alpha_in[im.grp_base + g0 + lane] = (uint8_t)my_alpha; }
+        if (g0 + lane < hi) { p.grp_slot_in[im.grp_base + g0 + lane] = (uint8_t)my_slot; p.grp_alpha_in[im.grp_base + g0 + lane] = (uint8_t)my_alpha; }
     }
 }
 
@@ -849,6 +920,70 @@ __device__ __forceinline__ sym_t gather_sym(sym_t tabv, sym_t pxv, uint32_t src)
     return src == 64u ? pxv : ((sym_t)lo | ((sym_t)hi << 32));
 }
 
+// The two loops of the S3 kernels.  A record is 65 symbolic words (lane k holds word k, the pixel word is read by
+// every lane); a step needs the state the previous step left, so the loop is a dependent chain of gathers - but the
+// RECORDS do not depend on it: they are fetched kChainBatch steps ahead, two batches in registers (with one record
+// of look-ahead a step cost a memory round trip, 0.4 us; the chain itself is a third of that).
+constexpr int kChainBatch = 8;
+struct SymBatch { sym_t tab[kChainBatch], px[kChainBatch]; };
+// records first .. first+kChainBatch-1 of rec[0..count), indices clamped to the last record: always kChainBatch
+// loads, so the compiler can count them (loads under a branch made every wait a wait for ALL outstanding loads,
+// the prefetched batch included)
+__device__ __forceinline__ void sym_batch_load(SymBatch& b, const sym_t* __restrict__ rec, uint32_t first, uint32_t count, uint32_t lane) {
+#pragma unroll
+    for (int i = 0; i < kChainBatch; ++i) {
+        const uint32_t k = min(first + (uint32_t)i, count - 1u);
+        b.tab[i] = rec[(size_t)k * 65u + lane]; b.px[i] = rec[(size_t)k * 65u + 64u];
+    }
+}
+// P <- rec[count-1] o ... o rec[0] o P  (symbolic composition)
+__device__ __forceinline__ void sym_compose_range(const sym_t* __restrict__ rec, uint32_t count, uint32_t lane, sym_t& P_tab, sym_t& P_px) {
+    if (count == 0u) return;
+    SymBatch cur, nxt;
+    sym_batch_load(cur, rec, 0u, count, lane);
+    for (uint32_t g = 0; g < count; g += kChainBatch) {
+        const uint32_t n = min(count - g, (uint32_t)kChainBatch);
+        sym_batch_load(nxt, rec, g + kChainBatch, count, lane);
+#pragma unroll
+        for (int i = 0; i < kChainBatch; ++i) {
+            if ((uint32_t)i < n) {
+                const sym_t c_tab = cur.tab[i], c_px = cur.px[i];
+                const sym_t n_tab = sym_compose(c_tab, gather_sym(P_tab, P_px, sym_src(c_tab)));
+                const sym_t n_px = sym_compose(c_px, gather_sym(P_tab, P_px, sym_src(c_px)));
+                P_tab = n_tab; P_px = n_px;
+            }
+        }
+        cur = nxt;
+    }
+}
+// concrete state pushed through rec[0..count); the state BEFORE record i is written to out + i*65 for i >= first_out
+__device__ __forceinline__ void sym_sweep_range(const sym_t* __restrict__ rec, uint32_t count, uint32_t lane, uint32_t& tabv, uint32_t& pxv,
+                                                uint32_t* __restrict__ out, uint32_t first_out) {
+    if (count == 0u) return;
+    SymBatch cur, nxt;
+    sym_batch_load(cur, rec, 0u, count, lane);
+    for (uint32_t g = 0; g < count; g += kChainBatch) {
+        const uint32_t n = min(count - g, (uint32_t)kChainBatch);
+        sym_batch_load(nxt, rec, g + kChainBatch, count, lane);
+#pragma unroll
+        for (int i = 0; i < kChainBatch; ++i) {
+            if ((uint32_t)i < n) {
+                if (g + (uint32_t)i >= first_out) {
+                    out[(size_t)(g + i) * 65u + lane] = tabv;
+                    if (lane == 0) out[(size_t)(g + i) * 65u + 64u] = pxv;
+                }
+                const sym_t c_tab = cur.tab[i], c_px = cur.px[i];
+                const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px);
+                const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = gather_lane(tabv, src_p & 63u);
+                const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
+                const uint32_t npx = sym_eval(c_px, src_p == 64u ? pxv : g_p);
+                tabv = ntab; pxv = npx;
+            }
+        }
+        cur = nxt;
+    }
+}
+
 __global__ __launch_bounds__(64) void dec_chain_state_l1(DecParams p) {
     const uint32_t G = blockIdx.x, lane = lane_id();
     const uint32_t img = find_image_by_group(p.images, p.n_images, G);
@@ -857,41 +992,47 @@ __global__ __launch_bounds__(64) void dec_chain_state_l1(DecParams p) {
     if (j0 + kGrp <= im.start_seg || j0 >= im.n_active) return;
     const uint32_t lo = max(j0, im.start_seg), hi = min(j0 + kGrp, im.n_active);
     sym_t P_tab = sym_make(0u, lane, 0u), P_px = sym_make(0u, 64u, 0u);          // identity
-    const sym_t* __restrict__ sum = p.summary + (size_t)(im.seg_base + lo) * 65u;
-    sym_t s_tab = sum[lane], s_px = sum[64];
-    for (uint32_t j = lo; j < hi; ++j) {
-        const sym_t c_tab = s_tab, c_px = s_px;
-        if (j + 1u < hi) { s_tab = sum[(size_t)(j + 1u - lo) * 65u + lane]; s_px = sum[(size_t)(j + 1u - lo) * 65u + 64u]; }   // prefetch
-        const sym_t n_tab = sym_compose(c_tab, gather_sym(P_tab, P_px, sym_src(c_tab)));
-        const sym_t n_px = sym_compose(c_px, gather_sym(P_tab, P_px, sym_src(c_px)));
-        P_tab = n_tab; P_px = n_px;
-    }
+    sym_compose_range(p.summary + (size_t)(im.seg_base + lo) * 65u, hi - lo, lane, P_tab, P_px);
     p.grp_summary[(size_t)G * 65u + lane] = P_tab;
     if (lane == 0) p.grp_summary[(size_t)G * 65u + 64u] = P_px;
 }
 
-__global__ __launch_bounds__(64) void dec_chain_state_l2(DecParams p) {
-    const uint32_t img = blockIdx.x, lane = lane_id();
+__global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2(DecParams p) {
+    __shared__ sym_t s_sum[kL2Waves][65];        // symbolic summary of every share
+    __shared__ uint32_t s_ent[kL2Waves][65];     // concrete state at every share's entry
+    const uint32_t img = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const DecImage im = p.images[img];
     if (im.start_seg >= im.n_active) return;
-    const size_t q0 = (size_t)im.seg_base + im.start_seg;
-    uint32_t tabv = p.entry[q0 * 65u + lane];        // concrete entry state of start_seg is given
-    uint32_t pxv = p.entry[q0 * 65u + 64u];
     const uint32_t gfirst = im.start_seg / kGrp, gend = (im.n_active + kGrp - 1u) / kGrp;
-    const sym_t* __restrict__ gs = p.grp_summary + (size_t)(im.grp_base + gfirst) * 65u;
-    sym_t s_tab = gs[lane], s_px = gs[64];
-    for (uint32_t g = gfirst; g < gend; ++g) {
-        const size_t G = (size_t)im.grp_base + g;
-        p.grp_entry[G * 65u + lane] = tabv;
-        if (lane == 0) p.grp_entry[G * 65u + 64u] = pxv;
-        const sym_t c_tab = s_tab, c_px = s_px;
-        if (g + 1u < gend) { s_tab = gs[(size_t)(g + 1u - gfirst) * 65u + lane]; s_px = gs[(size_t)(g + 1u - gfirst) * 65u + 64u]; }
-        const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px);
-        const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = gather_lane(tabv, src_p & 63u);
-        const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
-        const uint32_t npx = sym_eval(c_px, src_p == 64u ? pxv : g_p);
-        tabv = ntab; pxv = npx;
+    const uint32_t per = (gend - gfirst + kL2Waves - 1u) / kL2Waves;
+    const uint32_t lo = min(gfirst + wave * per, gend), hi = min(lo + per, gend);
+    const sym_t* __restrict__ gs = p.grp_summary + (size_t)(im.grp_base + lo) * 65u;
+    {   // A: compose the share's group summaries (as dec_chain_state_l1 composes segment summaries)
+        sym_t P_tab = sym_make(0u, lane, 0u), P_px = sym_make(0u, 64u, 0u);          // identity
+        sym_compose_range(gs, hi - lo, lane, P_tab, P_px);
+        s_sum[wave][lane] = P_tab;
+        if (lane == 0) s_sum[wave][64] = P_px;
     }
+    __syncthreads();
+    if (wave == 0) {   // B: concrete entry state of every share
+        const size_t q0 = (size_t)im.seg_base + im.start_seg;
+        uint32_t tabv = p.entry[q0 * 65u + lane];        // concrete entry state of start_seg is given
+        uint32_t pxv = p.entry[q0 * 65u + 64u];
+        for (uint32_t c = 0; c < kL2Waves; ++c) {
+            s_ent[c][lane] = tabv;
+            if (lane == 0) s_ent[c][64] = pxv;
+            const sym_t c_tab = s_sum[c][lane], c_px = s_sum[c][64];
+            const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px);
+            const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = gather_lane(tabv, src_p & 63u);
+            const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
+            const uint32_t npx = sym_eval(c_px, src_p == 64u ? pxv : g_p);
+            tabv = ntab; pxv = npx;
+        }
+    }
+    __syncthreads();
+    // C: sweep the share
+    uint32_t tabv = s_ent[wave][lane], pxv = s_ent[wave][64];
+    sym_sweep_range(gs, hi - lo, lane, tabv, pxv, p.grp_entry + (size_t)(im.grp_base + lo) * 65u, 0u);
 }
 
 __global__ __launch_bounds__(64) void dec_chain_state_l3(DecParams p) {
@@ -902,22 +1043,9 @@ __global__ __launch_bounds__(64) void dec_chain_state_l3(DecParams p) {
     if (j0 + kGrp <= im.start_seg || j0 >= im.n_active) return;
     const uint32_t lo = max(j0, im.start_seg), hi = min(j0 + kGrp, im.n_active);
     uint32_t tabv = p.grp_entry[(size_t)G * 65u + lane], pxv = p.grp_entry[(size_t)G * 65u + 64u];
-    const sym_t* __restrict__ sum = p.summary + (size_t)(im.seg_base + lo) * 65u;
-    uint32_t* __restrict__ ent = p.entry + (size_t)(im.seg_base + lo) * 65u;
-    sym_t s_tab = sum[lane], s_px = sum[64];
-    for (uint32_t j = lo; j < hi; ++j) {
-        if (j > im.start_seg) {                       // start_seg's entry state is given, never rewritten
-            ent[(size_t)(j - lo) * 65u + lane] = tabv;
-            if (lane == 0) ent[(size_t)(j - lo) * 65u + 64u] = pxv;
-        }
-        const sym_t c_tab = s_tab, c_px = s_px;
-        if (j + 1u < hi) { s_tab = sum[(size_t)(j + 1u - lo) * 65u + lane]; s_px = sum[(size_t)(j + 1u - lo) * 65u + 64u]; }
-        const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px);
-        const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = gather_lane(tabv, src_p & 63u);
-        const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
-        const uint32_t npx = sym_eval(c_px, src_p == 64u ? pxv : g_p);
-        tabv = ntab; pxv = npx;
-    }
+    // start_seg's entry state is given, never rewritten
+    sym_sweep_range(p.summary + (size_t)(im.seg_base + lo) * 65u, hi - lo, lane, tabv, pxv,
+                    p.entry + (size_t)(im.seg_base + lo) * 65u, lo == im.start_seg ? 1u : 0u);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1100,7 +1228,7 @@ void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
         tm->mark(kT_dec_parse, st);
         hipLaunchKernelGGL(dec_chain_parse_l1, dim3(p.total_grps), dim3(64), 0, st, p);
     }
-    hipLaunchKernelGGL(dec_chain_parse_l2, dim3(p.n_images), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(dec_chain_parse_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
     if (p.total_segs) hipLaunchKernelGGL(dec_chain_parse_l3, dim3(p.total_grps), dim3(64), 0, st, p);
     hipLaunchKernelGGL(dec_init_state, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_dec_chain_parse, st);
@@ -1118,14 +1246,14 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     else hipLaunchKernelGGL(dec_slot_walk, dim3(b256), dim3(256), 0, st, p);
     tm->mark(kT_dec_slot_walk, st);
     hipLaunchKernelGGL(dec_chain_slots_l1, dim3(p.total_grps), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(dec_chain_slots_l2, dim3(p.n_images), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(dec_chain_slots_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
     hipLaunchKernelGGL(dec_chain_slots_l3, dim3(p.total_grps), dim3(64), 0, st, p);
     tm->mark(kT_dec_chain_slots, st);
     hipLaunchKernelGGL(dec_summarize<false>, dim3(b64), dim3(64), 0, st, p);
     tm->mark(kT_dec_summarize, st);
     }
     hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
     hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);
     tm->mark(kT_dec_chain_state, st);
     if (out_channels == 4) hipLaunchKernelGGL(dec_segments<4>, dim3(b64), dim3(64), 0, st, p);

@@ -219,8 +219,9 @@ QOIMI_HD uint32_t sym_c(sym_t s) { return (uint32_t)s; }
 QOIMI_HD uint32_t sym_src(sym_t s) { return (uint32_t)(s >> 32) & 0x7Fu; }
 QOIMI_HD uint32_t sym_abs(sym_t s) { return (uint32_t)(s >> 40) & 0xFu; }
 QOIMI_HD uint32_t abs_bytemask(uint32_t absmask) {     // 4-bit channel mask -> 0xFF per set channel
-    return ((absmask & 1u) ? 0x000000FFu : 0u) | ((absmask & 2u) ? 0x0000FF00u : 0u) |
-           ((absmask & 4u) ? 0x00FF0000u : 0u) | ((absmask & 8u) ? 0xFF000000u : 0u);
+    // bit k of the mask to bit 8k (the four shifted copies do not overlap), then 1 -> 0xFF per byte
+    const uint32_t ones = ((absmask & 0xFu) * 0x00204081u) & 0x01010101u;
+    return (ones << 8) - ones;
 }
 // concrete value of a symbolic word given the concrete source value
 QOIMI_HD uint32_t sym_eval(sym_t s, uint32_t src_value) {

@@ -684,27 +684,47 @@ __global__ __launch_bounds__(256, 6) void enc_slabs(EncParams p) {
 // also writes the 14-byte header (qoi.h:384-388), the 8-byte end marker (qoi.h:339,480-482)
 // and *out_len (qoi.h:484).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void enc_offsets(EncParams p) {
-    __shared__ uint32_t s_part[256];
-    const uint32_t img = blockIdx.x, tid = threadIdx.x;
+// The scan walks the image in tiles of 16384 slabs (1024 threads x 16 consecutive counts, next tile's counts loaded
+// while this one is scanned): a 4K frame is one tile, a 16384 x 16384 image 16 - the first version gave every
+// thread a contiguous 1/256 of the image to add up serially and took 0.4 ms on that image.
+__global__ __launch_bounds__(1024) void enc_offsets(EncParams p) {
+    constexpr uint32_t kPer = 16, kTile = 1024u * kPer;
+    __shared__ uint32_t s_wave[16];
+    const uint32_t img = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t* __restrict__ sz = p.slab_size + (size_t)img * p.spi;
     uint32_t* __restrict__ off = p.slab_off + (size_t)img * p.spi;
-    const uint32_t per = (p.spi + 255u) / 256u;
-    const uint32_t lo = tid * per, hi = min(p.spi, lo + per);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += sz[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 256u; d <<= 1) {           // Hillis-Steele inclusive scan of the partials
-        const uint32_t v = tid >= d ? s_part[tid - d] : 0u;
+    const uint32_t n = p.spi;
+    uint32_t carry = 0;
+    uint32_t nv[kPer];
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) nv[j] = tid * kPer + j < n ? sz[tid * kPer + j] : 0u;
+    for (uint32_t base = 0; base < n; base += kTile) {
+        const uint32_t idx = base + tid * kPer;
+        uint32_t v[kPer];
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j) { v[j] = nv[j]; mine += v[j]; }
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j) nv[j] = idx + kTile + j < n ? sz[idx + kTile + j] : 0u;     // next tile
+        uint32_t incl = mine;                                  // inclusive scan over the wavefront
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t up = gather_lane(incl, lane - d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63u) s_wave[wave] = incl;
         __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) { const uint32_t s = s_wave[k]; before += k < wave ? s : 0u; total += s; }
+        __syncthreads();                                       // s_wave is rewritten by the next tile
+        uint32_t run = carry + before + incl - mine;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j) { if (idx + j < n) off[idx + j] = run; run += v[j]; }
+        carry += total;
     }
-    uint32_t run = tid ? s_part[tid - 1] : 0u;
-    for (uint32_t i = lo; i < hi; ++i) { off[i] = run; run += sz[i]; }
     uint8_t* out = p.out + (size_t)img * p.out_stride;
-    const uint32_t total = s_part[255];
+    const uint32_t total = carry;
     if (tid < (uint32_t)kHeaderBytes) {
         const uint32_t w = p.width, h = p.height;
         const u64 hdr_lo = 0x66696F71ull | ((u64)__builtin_bswap32(w) << 32);             // "qoif", width BE
@@ -819,7 +839,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm) {
     hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL, 0>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
     tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
     if (p.scratch) {
-        hipLaunchKernelGGL(enc_offsets, dim3(p.n_images), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(enc_offsets, dim3(p.n_images), dim3(1024), 0, st, p);
         tm->mark(kT_enc_offsets, st);
         hipLaunchKernelGGL(enc_compact, dim3(blocks), dim3(256), 0, st, p);
         tm->mark(kT_enc_compact, st);

@@ -274,8 +274,9 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
         // One lane decodes one segment.  Two costs pull in opposite directions (constants measured on MI355X):
         //   * a lane walks its segment serially, ~0.6 us per chunk-step over the four passes, and the two
         //     table-bound passes hold ~98 K lanes at a time: t_walk ~ B/1.2 * 0.6 us * ceil(lanes / 98304)
-        //   * the per-image chains (S1/S2/S3 level 2) walk the image's 64-segment groups one after the other,
-        //     ~0.5 us per group over the three chains: t_chain ~ (largest stream / B / 64) * 0.5 us
+        //   * the per-image chains (S1/S2/S3 level 2) walk the image's 64-segment groups, ~0.5 us per group over
+        //     the three chains, 16 wavefronts per image in two sweeps plus a 16-step hand-over:
+        //     t_chain ~ (groups / 8 + 16) * 0.5 us with groups = largest stream / B / 64
         // Small batches therefore get small segments (more lanes), a single large image not too small ones.
         // Large batches end at 2 KiB (the 520-byte symbolic summary per segment is then a quarter of the stream).
         uint64_t bytes = 0, largest = 0;
@@ -287,7 +288,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
         for (uint32_t cand = 128; cand <= 2048u; cand <<= 1) {
             const double lanes = (double)bytes / cand;
             const double rounds = lanes <= 98304.0 ? 1.0 : lanes / 98304.0;
-            const double t = (cand / 1.2) * 0.6 * rounds + ((double)largest / cand / 64.0) * 0.5;
+            const double t = (cand / 1.2) * 0.6 * rounds + ((double)largest / cand / 64.0 / 8.0 + 16.0) * 0.5;
             if (t < best) { best = t; B = cand; }
         }
     }
