@@ -535,6 +535,60 @@ __global__ __launch_bounds__(256) void dec_slot_heads_fine(DecParams p) {
 __device__ __forceinline__ uint32_t sel5(uint32_t ph, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4) {
     return ph == 0u ? a0 : ph == 1u ? a1 : ph == 2u ? a2 : ph == 3u ? a3 : a4;
 }
+// The records of S1 and S2 compose associatively, so 64 of them (one per lane) are chained with a log-step scan
+// over the wavefront - six rounds - instead of 64 dependent steps on broadcast lanes (22 us per kernel on a
+// single frame, where these chains are a good part of the whole decode).
+// Phase maps: 3 bits per entry phase; (a then b)[k] = b[a[k]].
+constexpr uint32_t kMapIdentity = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12);
+__device__ __forceinline__ uint32_t map_compose(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 5u; ++k) r |= ((b >> (3u * ((a >> (3u * k)) & 7u))) & 7u) << (3u * k);
+    return r;
+}
+__device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) { const uint32_t s = a + b; return s < a ? 0xFFFFFFFFu : s; }
+// inclusive scans over the 64 lanes
+__device__ __forceinline__ uint32_t wave_scan_map(uint32_t m, uint32_t lane) {
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t up = gather_lane(m, lane - d); if (lane >= d) m = map_compose(up, m); }
+    return m;
+}
+__device__ __forceinline__ uint32_t wave_scan_sat(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t up = gather_lane(v, lane - d); if (lane >= d) v = sat_add(up, v); }
+    return v;
+}
+// record of 64 consecutive records (lane l holds record l; lanes past the end hold the identity): the composed map
+// and, per entry phase, the pixels along that phase's path (saturating: far above any legal pixel count anyway)
+__device__ __forceinline__ ParseRec parse_fold64(const ParseRec& r, uint32_t lane) {
+    const uint32_t incl = wave_scan_map(r.exit_phase, lane);
+    const uint32_t excl = from_lane_below(incl, kMapIdentity);
+    ParseRec g;
+    g.exit_phase = read_lane(incl, 63);
+#pragma unroll
+    for (uint32_t k = 0; k < 5u; ++k) {
+        const uint32_t ph = (excl >> (3u * k)) & 7u;
+        g.pixels[k] = read_lane(wave_scan_sat(sel5(ph, r.pixels[0], r.pixels[1], r.pixels[2], r.pixels[3], r.pixels[4]), lane), 63);
+    }
+    return g;
+}
+// entry (phase, pixels before) of every one of the 64 records for a concrete entry phase; total: the pixels of all 64
+__device__ __forceinline__ void parse_sweep64(const ParseRec& r, uint32_t lane, uint32_t phase0, uint32_t& my_phase, uint32_t& my_before,
+                                              uint32_t& exit_phase, uint32_t& total) {
+    const uint32_t incl = wave_scan_map(r.exit_phase, lane);
+    const uint32_t excl = from_lane_below(incl, kMapIdentity);
+    my_phase = (excl >> (3u * phase0)) & 7u;
+    const uint32_t sums = wave_scan_sat(sel5(my_phase, r.pixels[0], r.pixels[1], r.pixels[2], r.pixels[3], r.pixels[4]), lane);
+    my_before = from_lane_below(sums, 0u);
+    total = read_lane(sums, 63);
+    exit_phase = (read_lane(incl, 63) >> (3u * phase0)) & 7u;
+}
+__device__ __forceinline__ ParseRec parse_identity() {
+    ParseRec r; r.exit_phase = kMapIdentity;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r.pixels[k] = 0;
+    return r;
+}
 
 __global__ __launch_bounds__(64) void dec_chain_parse_l1(DecParams p) {
     const uint32_t G = blockIdx.x, lane = lane_id();
@@ -542,26 +596,9 @@ __global__ __launch_bounds__(64) void dec_chain_parse_l1(DecParams p) {
     const DecImage im = p.images[img];
     const uint32_t j0 = (G - im.grp_base) * kGrp;
     const uint32_t cnt = min(kGrp, im.nseg - j0);
-    ParseRec r; r.exit_phase = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) r.pixels[k] = 0;
+    ParseRec r = parse_identity();
     if (lane < cnt) r = p.parse[im.seg_base + j0 + lane];
-    // lanes 0..4 walk the group for entry phase = lane; records are broadcast from their lanes
-    uint32_t ph = min(lane, 4u);
-    u64 sum = 0;
-    for (uint32_t l = 0; l < cnt; ++l) {
-        const uint32_t ex = read_lane_dyn(r.exit_phase, l);
-        const uint32_t a0 = read_lane_dyn(r.pixels[0], l), a1 = read_lane_dyn(r.pixels[1], l), a2 = read_lane_dyn(r.pixels[2], l),
-                       a3 = read_lane_dyn(r.pixels[3], l), a4 = read_lane_dyn(r.pixels[4], l);
-        sum += sel5(ph, a0, a1, a2, a3, a4);
-        ph = (ex >> (3u * ph)) & 7u;
-    }
-    const uint32_t capped = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum;   // > any legal pixel count anyway
-    // gather the five lanes' results into one record
-    ParseRec g;
-    g.exit_phase = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { g.exit_phase |= read_lane(ph, k) << (3 * k); g.pixels[k] = read_lane(capped, k); }
+    const ParseRec g = parse_fold64(r, lane);
     if (lane == 0) p.grp_parse[G] = g;
 }
 
@@ -579,30 +616,24 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_parse_l2(DecParams p)
     const DecImage im = p.images[img];
     const uint32_t per = (im.ngrp + kL2Waves - 1u) / kL2Waves;
     const uint32_t lo = min(wave * per, im.ngrp), hi = min(lo + per, im.ngrp);
-    // A: lanes 0..4 walk the share for entry phase = lane
-    {
-        uint32_t ph = min(lane, 4u);
-        u64 sum = 0;
+    {   // A: record of the share, 64 groups per fold
+        ParseRec S = parse_identity();
         for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {
-            ParseRec r; r.exit_phase = 0;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) r.pixels[k] = 0;
+            ParseRec r = parse_identity();
             if (g0 + lane < hi) r = p.grp_parse[im.grp_base + g0 + lane];
-            const uint32_t cnt = min(64u, hi - g0);
-            for (uint32_t l = 0; l < cnt; ++l) {
-                const uint32_t ex = read_lane_dyn(r.exit_phase, l);
-                const uint32_t a0 = read_lane_dyn(r.pixels[0], l), a1 = read_lane_dyn(r.pixels[1], l), a2 = read_lane_dyn(r.pixels[2], l),
-                               a3 = read_lane_dyn(r.pixels[3], l), a4 = read_lane_dyn(r.pixels[4], l);
-                sum += sel5(ph, a0, a1, a2, a3, a4);
-                ph = (ex >> (3u * ph)) & 7u;
-            }
-        }
-        const uint32_t capped = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum;   // > any legal pixel count anyway
-        uint32_t map = 0;
+            const ParseRec b = parse_fold64(r, lane);
+            ParseRec n;
+            n.exit_phase = map_compose(S.exit_phase, b.exit_phase);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) map |= read_lane(ph, k) << (3 * k);
-        if (lane == 0) s_rec[wave][0] = map;
-        if (lane < 5u) s_rec[wave][1u + lane] = capped;
+            for (uint32_t k = 0; k < 5u; ++k)
+                n.pixels[k] = sat_add(S.pixels[k], sel5((S.exit_phase >> (3u * k)) & 7u, b.pixels[0], b.pixels[1], b.pixels[2], b.pixels[3], b.pixels[4]));
+            S = n;
+        }
+        if (lane == 0) {
+            s_rec[wave][0] = S.exit_phase;
+#pragma unroll
+            for (uint32_t k = 0; k < 5u; ++k) s_rec[wave][1u + k] = S.pixels[k];
+        }
     }
     __syncthreads();
     // B
@@ -622,20 +653,16 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_parse_l2(DecParams p)
     // C
     uint32_t phase = s_in[wave][0]; u64 off = s_in[wave][1];
     for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {
-        ParseRec r; r.exit_phase = 0;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) r.pixels[k] = 0;
+        ParseRec r = parse_identity();
         if (g0 + lane < hi) r = p.grp_parse[im.grp_base + g0 + lane];
-        uint32_t my_phase = 0, my_off = 0;
-        const uint32_t cnt = min(64u, hi - g0);
-        for (uint32_t l = 0; l < cnt; ++l) {
-            if (lane == l) { my_phase = phase; my_off = (uint32_t)min(off, (u64)im.npx); }
-            const uint32_t add = read_lane_dyn(sel5(phase, r.pixels[0], r.pixels[1], r.pixels[2], r.pixels[3], r.pixels[4]), l);
-            const uint32_t ex = read_lane_dyn(r.exit_phase, l);
-            off = min(off + add, (u64)im.npx);
-            phase = (ex >> (3u * phase)) & 7u;
+        uint32_t my_phase, my_before, exit_phase, total;
+        parse_sweep64(r, lane, phase, my_phase, my_before, exit_phase, total);
+        if (g0 + lane < hi) {
+            p.grp_phase[im.grp_base + g0 + lane] = (uint8_t)my_phase;
+            p.grp_off[im.grp_base + g0 + lane] = (uint32_t)min(off + my_before, (u64)im.npx);
         }
-        if (g0 + lane < hi) { p.grp_phase[im.grp_base + g0 + lane] = (uint8_t)my_phase; p.grp_off[im.grp_base + g0 + lane] = my_off; }
+        off = min(off + total, (u64)im.npx);
+        phase = exit_phase;
     }
 }
 
@@ -645,22 +672,19 @@ __global__ __launch_bounds__(64) void dec_chain_parse_l3(DecParams p) {
     const DecImage im = p.images[img];
     const uint32_t j0 = (G - im.grp_base) * kGrp;
     const uint32_t cnt = min(kGrp, im.nseg - j0);
-    ParseRec r; r.exit_phase = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) r.pixels[k] = 0;
+    ParseRec r = parse_identity();
     if (lane < cnt) r = p.parse[im.seg_base + j0 + lane];
-    uint32_t phase = p.grp_phase[G]; u64 off = p.grp_off[G];
-    uint32_t my_phase = 0, my_off = 0, n_active = 0;     // n_active: segments that start before the pixel limit
-    for (uint32_t l = 0; l < cnt; ++l) {
-        if (lane == l) { my_phase = phase; my_off = (uint32_t)off; }
-        if (off < im.npx) n_active = j0 + l + 1u;
-        const uint32_t add = read_lane_dyn(sel5(phase, r.pixels[0], r.pixels[1], r.pixels[2], r.pixels[3], r.pixels[4]), l);
-        const uint32_t ex = read_lane_dyn(r.exit_phase, l);
-        off = min(off + add, (u64)im.npx);
-        phase = (ex >> (3u * phase)) & 7u;
-    }
+    const uint32_t phase0 = p.grp_phase[G]; const u64 off0 = p.grp_off[G];
+    uint32_t my_phase, my_before, exit_phase, total;
+    parse_sweep64(r, lane, phase0, my_phase, my_before, exit_phase, total);
+    const uint32_t my_off = (uint32_t)min(off0 + my_before, (u64)im.npx);
     if (lane < cnt) { p.entry_phase[im.seg_base + j0 + lane] = (uint8_t)my_phase; p.px_off[im.seg_base + j0 + lane] = my_off; }
-    if (lane == 0 && n_active) atomicMax(&p.images[img].n_active, n_active);
+    // n_active: segments that start before the pixel limit.  Only the group that holds the last such segment
+    // reports (its successor starts at the limit, or it is the image's last group): one atomic per image, not one per
+    // group on the same word.
+    const u64 act = __ballot(lane < cnt && my_off < im.npx);
+    const bool boundary = j0 + cnt == im.nseg || off0 + total >= (u64)im.npx;
+    if (lane == 0 && act && boundary) atomicMax(&p.images[img].n_active, j0 + 64u - (uint32_t)__builtin_clzll(act));
 }
 
 // ---------------------------------------------------------------------------------
@@ -698,6 +722,17 @@ __global__ __launch_bounds__(256) void dec_slot_walk(DecParams p) {
     if (have) { SlotRec r; slotf_finish(s, r); p.slot_rec[q] = r; }
 }
 
+// S2 with the same log-step scans.  Lane l holds the packed transfer of record l (identity outside the range).
+constexpr uint32_t kSlotIdentity = 1u << 8;                    // slot_pack({0, 1, 0, 0, 0})
+__device__ __forceinline__ uint32_t wave_scan_slots(uint32_t w, uint32_t lane) {
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = gather_lane(w, lane - d);
+        if (lane >= d) w = slot_pack(slot_compose(slot_unpack(up), slot_unpack(w)));
+    }
+    return w;
+}
+
 // S2 l1: compose the transfers of the group's segments that are still to be decoded
 __global__ __launch_bounds__(64) void dec_chain_slots_l1(DecParams p) {
     const uint32_t G = blockIdx.x, lane = lane_id();
@@ -706,12 +741,10 @@ __global__ __launch_bounds__(64) void dec_chain_slots_l1(DecParams p) {
     const uint32_t j0 = (G - im.grp_base) * kGrp;
     if (j0 + kGrp <= im.start_seg || j0 >= im.n_active) return;
     const uint32_t lo = max(j0, im.start_seg), hi = min(j0 + kGrp, im.n_active);
-    SlotRec mine = {0, 1, 0, 0, 0};
-    if (j0 + lane >= lo && j0 + lane < hi) mine = p.slot_rec[im.seg_base + j0 + lane];
-    const uint32_t packed = slot_pack(mine);
-    SlotRec acc = {0, 1, 0, 0, 0};
-    for (uint32_t l = lo - j0; l < hi - j0; ++l) acc = slot_compose(acc, slot_unpack(read_lane_dyn(packed, l)));
-    if (lane == 0) p.grp_slot[G] = acc;
+    uint32_t mine = kSlotIdentity;
+    if (j0 + lane >= lo && j0 + lane < hi) mine = slot_pack(p.slot_rec[im.seg_base + j0 + lane]);
+    const uint32_t incl = wave_scan_slots(mine, lane);
+    if (lane == 63u) p.grp_slot[G] = slot_unpack(incl);
 }
 
 // S2 l2: chain the groups of one image from the group holding start_seg; the start value is the
@@ -728,11 +761,9 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_slots_l2(DecParams p)
     {   // A
         SlotRec acc = {0, 1, 0, 0, 0};
         for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {
-            SlotRec mine = {0, 1, 0, 0, 0};
-            if (g0 + lane < hi) mine = p.grp_slot[im.grp_base + g0 + lane];
-            const uint32_t packed = slot_pack(mine);
-            const uint32_t cnt = min(64u, hi - g0);
-            for (uint32_t l = 0; l < cnt; ++l) acc = slot_compose(acc, slot_unpack(read_lane_dyn(packed, l)));
+            uint32_t mine = kSlotIdentity;
+            if (g0 + lane < hi) mine = slot_pack(p.grp_slot[im.grp_base + g0 + lane]);
+            acc = slot_compose(acc, slot_unpack(read_lane(wave_scan_slots(mine, lane), 63)));
         }
         if (lane == 0) s_rec[wave] = slot_pack(acc);
     }
@@ -749,16 +780,13 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_slots_l2(DecParams p)
     // C
     uint32_t slot = s_in[wave][0], alpha = s_in[wave][1];
     for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {
-        SlotRec mine = {0, 1, 0, 0, 0};
-        if (g0 + lane < hi) mine = p.grp_slot[im.grp_base + g0 + lane];
-        const uint32_t packed = slot_pack(mine);
-        uint32_t my_slot = 0, my_alpha = 0;
-        const uint32_t cnt = min(64u, hi - g0);
-        for (uint32_t l = 0; l < cnt; ++l) {
-            if (lane == l) { my_slot = slot; my_alpha = alpha; }
-            slot_apply(slot_unpack(read_lane_dyn(packed, l)), slot, alpha);
-        }
+        uint32_t mine = kSlotIdentity;
+        if (g0 + lane < hi) mine = slot_pack(p.grp_slot[im.grp_base + g0 + lane]);
+        const uint32_t incl = wave_scan_slots(mine, lane);
+        uint32_t my_slot = slot, my_alpha = alpha;
+        slot_apply(slot_unpack(from_lane_below(incl, kSlotIdentity)), my_slot, my_alpha);
         if (g0 + lane < hi) { p.grp_slot_in[im.grp_base + g0 + lane] = (uint8_t)my_slot; p.grp_alpha_in[im.grp_base + g0 + lane] = (uint8_t)my_alpha; }
+        slot_apply(slot_unpack(read_lane(incl, 63)), slot, alpha);
     }
 }
 
@@ -770,15 +798,11 @@ __global__ __launch_bounds__(64) void dec_chain_slots_l3(DecParams p) {
     const uint32_t j0 = (G - im.grp_base) * kGrp;
     if (j0 + kGrp <= im.start_seg || j0 >= im.n_active) return;
     const uint32_t lo = max(j0, im.start_seg), hi = min(j0 + kGrp, im.n_active);
-    SlotRec mine = {0, 1, 0, 0, 0};
-    if (j0 + lane >= lo && j0 + lane < hi) mine = p.slot_rec[im.seg_base + j0 + lane];
-    const uint32_t packed = slot_pack(mine);
-    uint32_t slot = p.grp_slot_in[G], alpha = p.grp_alpha_in[G];
-    uint32_t my_slot = 0, my_alpha = 0;
-    for (uint32_t l = lo - j0; l < hi - j0; ++l) {
-        if (lane == l) { my_slot = slot; my_alpha = alpha; }
-        slot_apply(slot_unpack(read_lane_dyn(packed, l)), slot, alpha);
-    }
+    uint32_t mine = kSlotIdentity;
+    if (j0 + lane >= lo && j0 + lane < hi) mine = slot_pack(p.slot_rec[im.seg_base + j0 + lane]);
+    const uint32_t incl = wave_scan_slots(mine, lane);
+    uint32_t my_slot = p.grp_slot_in[G], my_alpha = p.grp_alpha_in[G];
+    slot_apply(slot_unpack(from_lane_below(incl, kSlotIdentity)), my_slot, my_alpha);
     if (j0 + lane >= lo && j0 + lane < hi) { p.slot_in[im.seg_base + j0 + lane] = (uint8_t)my_slot; p.alpha_in[im.seg_base + j0 + lane] = (uint8_t)my_alpha; }
 }
 

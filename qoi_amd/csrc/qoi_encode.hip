@@ -684,28 +684,35 @@ __global__ __launch_bounds__(256, 6) void enc_slabs(EncParams p) {
 // also writes the 14-byte header (qoi.h:384-388), the 8-byte end marker (qoi.h:339,480-482)
 // and *out_len (qoi.h:484).
 // ---------------------------------------------------------------------------------
-// The scan walks the image in tiles of 16384 slabs (1024 threads x 16 consecutive counts, next tile's counts loaded
-// while this one is scanned): a 4K frame is one tile, a 16384 x 16384 image 16 - the first version gave every
-// thread a contiguous 1/256 of the image to add up serially and took 0.4 ms on that image.
+// The scan walks the image in tiles of 16384 slabs, 1024 per wavefront: counts are loaded coalesced (next tile's
+// while this one is scanned), turned through a wavefront-private LDS stripe so that a lane holds 16 consecutive
+// counts, scanned (lane-serial, then six rounds over the wavefront, then over the 16 wavefronts) and written back
+// the same way.  A 4K frame is one tile, a 16384 x 16384 image 16 - the first version gave every thread a
+// contiguous 1/256 of the image to add up serially and took 0.4 ms on that image.
 __global__ __launch_bounds__(1024) void enc_offsets(EncParams p) {
-    constexpr uint32_t kPer = 16, kTile = 1024u * kPer;
+    constexpr uint32_t kPer = 16, kStripe = 64u * kPer, kTile = 16u * kStripe;
+    __shared__ uint32_t s_turn[16][kStripe + 64u];             // element e of a stripe at e + e/16 (bank spread)
     __shared__ uint32_t s_wave[16];
     const uint32_t img = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t* __restrict__ sz = p.slab_size + (size_t)img * p.spi;
     uint32_t* __restrict__ off = p.slab_off + (size_t)img * p.spi;
     const uint32_t n = p.spi;
+    uint32_t* turn = s_turn[wave];
     uint32_t carry = 0;
     uint32_t nv[kPer];
 #pragma unroll
-    for (uint32_t j = 0; j < kPer; ++j) nv[j] = tid * kPer + j < n ? sz[tid * kPer + j] : 0u;
+    for (uint32_t j = 0; j < kPer; ++j) { const uint32_t e = wave * kStripe + j * 64u + lane; nv[j] = e < n ? sz[e] : 0u; }
     for (uint32_t base = 0; base < n; base += kTile) {
-        const uint32_t idx = base + tid * kPer;
+        const uint32_t sbase = base + wave * kStripe;          // first slab of this wavefront's stripe
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j) { const uint32_t e = j * 64u + lane; turn[e + (e >> 4)] = nv[j]; }
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j) { const uint32_t e = sbase + kTile + j * 64u + lane; nv[j] = e < n ? sz[e] : 0u; }   // next tile
+        __builtin_amdgcn_wave_barrier();
         uint32_t v[kPer];
         uint32_t mine = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < kPer; ++j) { v[j] = nv[j]; mine += v[j]; }
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; ++j) nv[j] = idx + kTile + j < n ? sz[idx + kTile + j] : 0u;     // next tile
+        for (uint32_t k = 0; k < kPer; ++k) { v[k] = turn[lane * 17u + k]; mine += v[k]; }
         uint32_t incl = mine;                                  // inclusive scan over the wavefront
 #pragma unroll
         for (uint32_t d = 1; d < 64u; d <<= 1) {
@@ -720,7 +727,11 @@ __global__ __launch_bounds__(1024) void enc_offsets(EncParams p) {
         __syncthreads();                                       // s_wave is rewritten by the next tile
         uint32_t run = carry + before + incl - mine;
 #pragma unroll
-        for (uint32_t j = 0; j < kPer; ++j) { if (idx + j < n) off[idx + j] = run; run += v[j]; }
+        for (uint32_t k = 0; k < kPer; ++k) { turn[lane * 17u + k] = run; run += v[k]; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; ++j) { const uint32_t e = j * 64u + lane; if (sbase + e < n) off[sbase + e] = turn[e + (e >> 4)]; }
+        __builtin_amdgcn_wave_barrier();
         carry += total;
     }
     uint8_t* out = p.out + (size_t)img * p.out_stride;
