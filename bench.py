@@ -36,7 +36,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_s4_pmc_traffic.json")
+def _latest_traffic_file() -> str:
+    """The most recent committed PMC traffic summary (profiles/rNN_sM_pmc_traffic.json, written by tools/gpu_session.sh)."""
+    import glob
+    import re
+    best, key = "", (-1, -1)
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_s*_pmc_traffic.json")):
+        m = re.search(r"r(\d+)_s(\d+)_pmc_traffic\.json$", f)
+        if m and (int(m.group(1)), int(m.group(2))) > key:
+            best, key = f, (int(m.group(1)), int(m.group(2)))
+    return best
+
+
+TRAFFIC_FILE = _latest_traffic_file()
 
 
 def measured_traffic(kernel_prefix: str, grid_threads: int):

@@ -421,6 +421,7 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
         p.fine_tail[F] = slot_pack(tr);
         p.fine_moff[F] = (uint8_t)moff;
     }
+    if (G == 1u) { if (have) p.parse[q] = r; return; }     // 128-byte segments: the piece is the segment
     // compose the G (8..64) pieces of every segment: lane `sub` = e < 5 walks the pieces for entry phase e
     s_rec[wave][lane][0] = r.exit_phase;
 #pragma unroll

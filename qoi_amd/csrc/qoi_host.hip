@@ -324,9 +324,9 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
     const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
-    {   // P1/P2 on 128-byte pieces when a segment is 8, 16, 32 or 64 of them
+    {   // P1/P2 on 128-byte pieces when a segment is 1, 8, 16, 32 or 64 of them
         const uint32_t g = B / 128u;
-        const bool ok = B % 128u == 0u && g >= 8u && g <= 64u && (g & (g - 1u)) == 0u && c->dec_fine;
+        const bool ok = B % 128u == 0u && (g == 1u || (g >= 8u && g <= 64u)) && (g & (g - 1u)) == 0u && c->dec_fine;
         p.fine_per_seg = ok ? g : 0u;
         p.fine_shift = 0;
         while (ok && (1u << p.fine_shift) < g) ++p.fine_shift;
