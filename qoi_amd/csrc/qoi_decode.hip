@@ -17,6 +17,7 @@
 //     groups are summarised in parallel, one wavefront chains the group summaries of an
 //     image, then the groups are swept in parallel again.
 #include "qoi_dev.h"
+#include <type_traits>
 #include "qoi_kernels.h"
 #include "qoi_decode_core.h"
 
@@ -70,13 +71,15 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_
 // unread): a period consumes <= 5*PERIOD_ bytes (+5 for the one-chunk look-ahead of the callers), a refill
 // tops the ring up in 16-byte pieces; with RD_=32, NP_=4, PERIOD_=8: o >= 17 after every refill, so the 8 bytes
 // a peek reads are always there.
-template <int RD_, int NP_, int PERIOD_>
+template <int RD_, int NP_, int PERIOD_, int LOOK_ = 8>
 struct LaneReaderT {
     static constexpr uint32_t RD = RD_;
     static constexpr uint32_t kSlots = RD + 1;
     static constexpr uint32_t kPeriod = PERIOD_;
     static_assert((RD_ & (RD_ - 1)) == 0 && RD_ >= 16, "ring size");
-    static_assert(4 * RD_ - 16 - 12 - (5 * PERIOD_ + 5) >= 8 + 3, "ring too small for the period");
+    // LOOK_: bytes a caller reads beyond its position (8: one peek; 16: the four-dword window of dec_segments)
+    static_assert(4 * RD_ - 16 - 12 - (5 * PERIOD_ + 5) >= LOOK_ + 3, "ring too small for the period");
+    static_assert(16 * NP_ >= 5 * PERIOD_, "refill rate below the worst-case consumption");
     uint32_t ring;             // LDS byte address of ring[0][lane]; dword k of the ring at ring + k*256
     const uint8_t* abase;      // 16-byte aligned start of the fetched range
     const uint8_t* aend;       // first byte that must not be read (stream + size)
@@ -133,6 +136,14 @@ struct LaneReaderT {
     __device__ __forceinline__ bool due(uint32_t it) const { return (it % kPeriod) == 0u; }
 };
 typedef LaneReaderT<16, 2, 4> LaneReader;
+
+// chunk length in P3/P4: from the chunk-table word that was fetched a step ahead (two instructions) or by
+// arithmetic on the tag byte (seven, but off the LDS round trip)
+#ifdef QOIMI_LEN_ARITH
+#define QOIMI_STEP_LEN(b1, info) len_of(b1)
+#else
+#define QOIMI_STEP_LEN(b1, info) lut_len(info)
+#endif
 
 // 256-entry chunk table (qoi_decode_core.h: lut_entry) in LDS; built by the first 256 threads / by 64 lanes x 4
 struct LdsLut {
@@ -227,6 +238,13 @@ struct LaneWriter {
             for (uint32_t k = 0; k < kGroup; k += 4u) store4(fpos + k, v[k], v[k + 1u], v[k + 2u], v[k + 3u]);
             fpos += kGroup;
         }
+    }
+    // px at ppos and at ppos + 1, the second one counted only if `two` (else it is overwritten by the next put):
+    // no branch; the caller guarantees two free places
+    __device__ __forceinline__ void put2(uint32_t px, bool two) {
+        *(lds_u32*)(row + (ppos & (kRing - 1u)) * 256u) = px;
+        *(lds_u32*)(row + ((ppos + 1u) & (kRing - 1u)) * 256u) = px;
+        ppos += two ? 2u : 1u;
     }
     __device__ __forceinline__ void put(uint32_t px) {
         if (__builtin_expect(ppos - fpos == kRing, 0)) drain();           // only long runs fill the ring between drains
@@ -830,9 +848,9 @@ struct LdsSymTab {
 // verify in 2-5 rounds with the hints (one segment per round without them).
 template <bool REFINE>
 __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
+    __shared__ __attribute__((aligned(4096))) uint32_t s_ring[LaneReader::kSlots * 64];
     __shared__ uint32_t s_tabc[65 * 64];          // row 64: kSymParkRow
     __shared__ uint16_t s_tabm[65 * 64];
-    __shared__ uint32_t s_ring[LaneReader::kSlots * 64];
     __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 64];
     __shared__ LdsLut s_lut;
     const uint32_t lane = lane_id();
@@ -876,7 +894,10 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
         slot = have ? p.slot_in[q] : 0u; alpha = have ? p.alpha_in[q] : 0u;
     }
     const uint32_t alpha_in0 = alpha;
-    const uint32_t runmask = j == 0u ? 0u : kLutRunBit;      // RUN chunks store nothing new except as a stream's first chunk (SymState)
+    // RUN chunks store nothing new except as a stream's first chunk (SymState); the refinement rounds skip the store
+    // (round 1 keeps it: its entry slots come from S2, not from a possibly spoiled entry pixel, and the three ops
+    // per step cost this kernel 6 %)
+    const uint32_t runmask = (REFINE && j != 0u) ? kLutRunBit : 0u;
     bool active = have && pos < end;
     uint32_t w32, b5; R.peek(pos, w32, b5);
     uint32_t delta0, info;
@@ -890,7 +911,7 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
                 const uint32_t b1 = w32 & 0xFFu;
                 const uint32_t t_c = *(const lds_u32*)(tc_base + ((w32 & 63u) << 8));
                 const uint32_t t_m = *(const lds_u16*)(tm_base + ((w32 & 63u) << 7));
-                const uint32_t npos = pos + len_of(b1);
+                const uint32_t npos = pos + QOIMI_STEP_LEN(b1, info);
                 uint32_t nw32, nb5; R.peek(npos, nw32, nb5);      // next chunk's bytes travel while this one is executed
                 const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)info, 28, 1);        // all ones for LUMA
                 const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
@@ -1087,10 +1108,16 @@ struct LdsTab32 {
 // (instructions per step) x (~9 cycles).  The next chunk's bytes are fetched while the current one executes.
 template <int OCH>
 __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
-    __shared__ uint32_t s_tab[64 * 64];
-    __shared__ uint32_t s_ring[LaneReader::kSlots * 64];
-    __shared__ uint32_t s_out[LaneWriter<OCH>::kRing * 64];
-    __shared__ LdsLut s_lut;
+    // One LDS block, carved by hand: colour tables at 0 (16 KiB), pixel ring at 16 KiB (4 KiB), stream ring behind
+    // it, chunk table last.  With the tables and rings on 16 KiB / 4 KiB boundaries their addresses are formed with
+    // an OR (the index bits of the base are clear), and the whole is 26 880 bytes: six wavefronts per CU.
+    constexpr uint32_t kTabDw = 64u * 64u, kOutDw = LaneWriter<OCH>::kRing * 64u, kRingDw = LaneReader::kSlots * 64u;
+    static_assert(kOutDw * 4u == 4096u, "pixel ring is one 4 KiB block");
+    __shared__ __attribute__((aligned(16384))) uint32_t s_mem[kTabDw + kOutDw + kRingDw + sizeof(LdsLut) / 4u];
+    uint32_t* const s_tab = s_mem;
+    uint32_t* const s_out = s_mem + kTabDw;
+    uint32_t* const s_ring = s_mem + kTabDw + kOutDw;
+    LdsLut& s_lut = *reinterpret_cast<LdsLut*>(s_mem + kTabDw + kOutDw + kRingDw);
     const uint32_t lane = lane_id();
     build_lut(s_lut, lane, 64u);
     const uint32_t q = blockIdx.x * 64u + lane;
@@ -1103,7 +1130,8 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
     const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
     uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
-    LaneReader R;
+    typedef LaneReader Reader;
+    Reader R;
     R.init(lds_addr_of(&s_ring[lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
     LaneWriter<OCH> W;
     W.init(lds_addr_of(&s_out[lane]), p.pixels + (size_t)img * p.pixel_stride, have ? p.px_off[q] : 0u);
@@ -1132,48 +1160,61 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
     // Inside a step the LDS round trips are software-pipelined: the colour-table read of this chunk, the bytes
     // of the next chunk and the next chunk's table entry are all in flight while this chunk's arithmetic runs
     // (a wavefront is mostly alone on its SIMD here, nothing else hides the ~100-cycle LDS latency).
-    while (__ballot(active)) {
-        R.land();
-        R.issue(pos);
-        W.drain();
-#pragma unroll
-        for (uint32_t u = 0; u < LaneReader::kPeriod; ++u) {
-            if (active) {
-                // colour-table slot the tag byte may name (issued after the previous step's table write)
-                const uint32_t t = *(const lds_u32*)(tab_base + ((w32 & 63u) << 8));
-                const uint32_t npos = pos + len_of(w32 & 0xFFu);
-                uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
-                // the ways a chunk sets the pixel that need no table (qoi.h:547-575)
-                const uint32_t rel = apply_relative(px, w32, delta0, info);
-                const bool hi = lut_hi(info), lo = lut_lo(info);
-                const uint32_t npx = lut_pixels(info);
-                uint32_t b = 0;
-                if (__ballot(hi)) {                       // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
-                    const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);                 // r,g,b,a = chunk bytes 1..4
-                    const uint32_t rgbv = (px & 0xFF000000u) | (rgba & 0x00FFFFFFu);
-                    b = lo ? rgba : rgbv;
+    // Two copies of the loop: only a wavefront that holds a segment which may reach the image's pixel limit (the
+    // last active segment of an image, or one whose successor starts at the limit: truncated / over-long streams)
+    // pays for the clipping of every chunk's pixel count.
+    const bool clip_lane = have && (j + 1u >= im.n_active || p.px_off[q + 1u] >= limit);
+    auto run = [&](auto clip_tag) {
+        constexpr bool CLIP = decltype(clip_tag)::value;
+        while (__ballot(active)) {
+            R.land();
+            R.issue(pos);
+            W.drain();
+    #pragma unroll
+            for (uint32_t u = 0; u < Reader::kPeriod; ++u) {
+                if (active) {
+                    // colour-table slot the tag byte may name (issued after the previous step's table write)
+                    const uint32_t t = *(const lds_u32*)(tab_base + ((w32 & 63u) << 8));
+                    const uint32_t npos = pos + QOIMI_STEP_LEN(w32 & 0xFFu, info);
+                    uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
+                    // the ways a chunk sets the pixel that need no table (qoi.h:547-575)
+                    const uint32_t rel = apply_relative(px, w32, delta0, info);
+                    const bool hi = lut_hi(info), lo = lut_lo(info);
+                    const uint32_t npx = lut_pixels(info);
+                    uint32_t b = 0;
+                    if (__ballot(hi)) {                       // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
+                        const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);                 // r,g,b,a = chunk bytes 1..4
+                        const uint32_t rgbv = (px & 0xFF000000u) | (rgba & 0x00FFFFFFu);
+                        b = lo ? rgba : rgbv;
+                    }
+                    // next chunk's table entry
+                    const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
+                    const uint32_t ndelta0 = lq[0], ninfo = lq[256];
+                    const uint32_t a = lo ? t : rel;
+                    px = hi ? b : a;
+                    // index[QOI_COLOR_HASH(px) % 64] = px after every chunk (qoi.h:577)
+                    const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
+                    *(lds_u32*)(tab_base + ((h & 63u) << 8)) = px;
+                    uint32_t rem = CLIP ? min(npx, limit - W.ppos) : npx;     // over-long run clipped (Appendix B item 8)
+                    pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
+                    // rem >= 1: the lane was below the pixel limit.  The first two pixels of a chunk go out in straight-line
+                    // code (in a natural image almost every step has SOME lane on a short QOI_OP_RUN, so the branch for
+                    // it was taken in every step: -6 % on photo content, +7 % on flat content whose steps all take the
+                    // rare path); the ring has room - W.drain() left <= 3 pixels, a period adds
+                    // <= 2 * kPeriod here, and the rare path below drains when it leaves more than 8 behind.
+                    W.put2(px, rem > 1u);
+                    rem -= rem > 1u ? 2u : 1u;
+                    if (rem) {                                                 // QOI_OP_RUN of three or more (qoi.h:573-575)
+                        if (rem >= kLongRun) W.splat(px, rem);
+                        while (rem) { W.put(px); --rem; }
+                        if (W.ppos - W.fpos > LaneWriter<OCH>::kRing - 2u * Reader::kPeriod) W.drain();
+                    }
+                    active = pos < end && (!CLIP || W.ppos < limit);
                 }
-                // next chunk's table entry
-                const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
-                const uint32_t ndelta0 = lq[0], ninfo = lq[256];
-                const uint32_t a = lo ? t : rel;
-                px = hi ? b : a;
-                // index[QOI_COLOR_HASH(px) % 64] = px after every chunk (qoi.h:577)
-                const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
-                *(lds_u32*)(tab_base + ((h & 63u) << 8)) = px;
-                uint32_t rem = min(npx, limit - W.ppos);                   // over-long run clipped (Appendix B item 8)
-                pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
-                W.put(px);                                                 // rem >= 1: the lane was below the pixel limit
-                if (--rem) {                                               // QOI_OP_RUN (qoi.h:573-575)
-                    // a long run bypasses the ring (ring out, then aligned 4-pixel stores of the repeated pixel):
-                    // flat content is all runs
-                    if (rem >= kLongRun) W.splat(px, rem);
-                    while (rem) { W.put(px); --rem; }
-                }
-                active = pos < end && W.ppos < limit;
             }
         }
-    }
+    };
+    if (__ballot(clip_lane)) run(std::true_type{}); else run(std::false_type{});
     if (have) {
         W.finish();
         if (j + 1u < im.n_active) {

@@ -242,7 +242,8 @@ QOIMI_HD sym_t sym_compose(sym_t b, sym_t a_src) {
 // kSymParkRow).  This matters: a segment that begins inside a run would otherwise store the entry pixel at the
 // SPECULATED entry slot, and one wrong guess (the entry pixel taken from a table word that an earlier
 // mis-speculation misplaced) used to spoil a table word for all later segments; frames whose alpha changes through
-// the colour table needed up to 90 restart rounds for that reason alone, 2-3 with the store skipped.
+// the colour table needed up to 90 restart rounds for that reason alone, 2-3 with the store skipped.  The
+// refinement rounds (entry slot taken from the hinted entry pixel) skip it; round 1 (entry slot from S2) does not need to.
 constexpr uint32_t kSymParkRow = 64u;
 constexpr uint32_t kLutRunBit = 1u << 15;         // lut_entry: info bit 15
 struct SymState { uint32_t pc, ph, slot, alpha, runmask; };   // running pixel: constants, source|absmask<<8; speculated slot/alpha; kLutRunBit unless first segment

@@ -145,8 +145,8 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
             const uint32_t* ent = &entry[(size_t)j * 65u];
             const uint32_t a_in = alpha_in[j];
             auto hint = [&](uint32_t src) -> uint32_t { return refine ? ent[src] >> 24 : a_in; };
-            const sym_t px = fast ? summarize_segment_fast(in, base + phase[j], end, slot_in[j], alpha_in[j], lut, t, hint, j == 0)
-                                  : summarize_segment(in, base + phase[j], end, slot_in[j], alpha_in[j], t, j == 0);
+            const sym_t px = fast ? summarize_segment_fast(in, base + phase[j], end, slot_in[j], alpha_in[j], lut, t, hint, j == 0 || !refine)
+                                  : summarize_segment(in, base + phase[j], end, slot_in[j], alpha_in[j], t, j == 0 || !refine);
             for (int k = 0; k < 64; ++k) summary[(size_t)j * 65u + k] = t.v[k];
             summary[(size_t)j * 65u + 64u] = px;
         }

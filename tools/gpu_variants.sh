@@ -2,7 +2,7 @@
 # build-flag ablations on the GPU box (diagnostic): rebuilds qoi_decode.hip / qoi_encode.hip with extra -D flags and runs the bench
 # usage: VARIANTS="base:;g4:-DQOIMI_DRAIN_GROUP=4" KINDS="photo" BENCH_ARGS="--frames 32" bash tools/gpu_variants.sh name
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out/${1:-var}; mkdir -p $OUT; export TMPDIR=/tmp
-BASEFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
+BASEFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-int-to-pointer-cast"
 IFS=';' read -ra VS <<< "${VARIANTS:-base:}"
 for v in "${VS[@]}"; do
   name=${v%%:*}; defs=${v#*:}
