@@ -7,8 +7,8 @@ checks memory safety, this harness checks RESULTS: the drop-in qoi_decode of lib
 the oracle (the unmodified reference where oracle/_ref is built, else the C restatement) on NULL-ness, on the
 desc it fills and on every pixel.
 
-    python tools/fuzz_decode.py --iters 2000 --seed 1            # needs an MI355X
-    python tools/fuzz_decode.py --replay crash.bin               # one input in qoifuzz's format
+    python tests/fuzz_decode.py --iters 2000 --seed 1            # needs an MI355X
+    python tests/fuzz_decode.py --replay crash.bin               # one input in qoifuzz's format
 
 Mutations start from encoder-made streams (all content classes, both channel counts) and apply byte flips,
 chunk-soup splices, truncations, header edits and size lies; pixel counts are capped so that a mutated header

@@ -245,9 +245,9 @@ def test_selectable_paths(api, oracle, env):
 
 
 def test_differential_fuzz(api, oracle):
-    """tools/fuzz_decode.py (qoifuzz.c's input convention, but results are compared with the oracle):
+    """tests/fuzz_decode.py (qoifuzz.c's input convention, but results are compared with the oracle):
     mutated / truncated / spliced streams, every `channels` argument incl. invalid ones."""
-    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys_path = os.path.dirname(os.path.abspath(__file__))
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_decode", os.path.join(sys_path, "fuzz_decode.py"))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)

@@ -1,9 +1,20 @@
-"""tools/qoibench_mi355x.py: qoibench.c's table and flags, reference row on CPU."""
+"""tools/qoibench_mi355x.py: qoibench.c's table and flags, driven here with a CPU build of the
+reference in the baseline row and no GPU (the tool itself has no CPU codec)."""
 import importlib.util
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ref(m):
+    from oracle import oracle_py
+    oracle_py.load_ref() or oracle_py.load_port()          # builds the checker libraries if needed
+    here = os.path.join(ROOT, "oracle")
+    path, prefix = (os.path.join(here, "_ref", "libqoiref.so"), "ref_")
+    if not os.path.exists(path):
+        path, prefix = os.path.join(here, "liboracle.so"), "oracle_"
+    return m.RefCodec(path, prefix)
 
 
 def _load():
@@ -16,7 +27,8 @@ def _load():
 def test_table_format_and_totals(tmp_path):
     m = _load()
     lines = []
-    rc = m.main(["1", str(tmp_path), "--synth", "1", "--nogpu", "--nowarmup"], out=lambda s="": lines.extend(str(s).split("\n")))
+    rc = m.main(["1", str(tmp_path), "--synth", "1", "--nowarmup"], out=lambda s="": lines.extend(str(s).split("\n")),
+                ref=_ref(m), use_gpu=False)
     assert rc == 0
     text = "\n".join(lines)
     head = "          decode ms   encode ms   decode mpps   encode mpps   size kb    rate"      # qoibench.c:339
@@ -31,8 +43,8 @@ def test_table_format_and_totals(tmp_path):
 def test_onlytotals_and_flags(tmp_path):
     m = _load()
     lines = []
-    m.main(["1", str(tmp_path), "--synth", "1", "--nogpu", "--onlytotals", "--noencode", "--nowarmup"],
-           out=lambda s="": lines.extend(str(s).split("\n")))
+    m.main(["1", str(tmp_path), "--synth", "1", "--onlytotals", "--noencode", "--nowarmup"],
+           out=lambda s="": lines.extend(str(s).split("\n")), ref=_ref(m), use_gpu=False)
     rows = [l for l in lines if l.startswith("qoi-ref:")]
     assert len(rows) == 2                                 # directory total + grand total only
     assert all(float(r.split()[2]) == 0.0 for r in rows)  # --noencode: encode ms column stays 0

@@ -11,31 +11,36 @@ unless --nowarmup, mean of N runs, allocation of the result inside the timed reg
 --noverify --noencode --nodecode --norecurse --onlytotals, and the output table
 (`qoibench.c:335-360`: decode ms | encode ms | decode mpps | encode mpps | size kb | rate).
 
-What differs: images are read from `*.qoi` files (decoded once with the oracle to obtain the raw pixels) instead
-of `*.png` — PNG decoding is the job of libpng/stb_image, third-party code the reference does not vendor and this
-image does not have; the libpng/stbi comparison rows are therefore absent (qoibench's own --nopng).  Rows:
+What differs: PNGs are read with `tools/png_io.py` (the reference uses stb_image / libpng, third-party code it does
+not vendor and this image does not have); the libpng/stbi comparison rows are absent (qoibench's own --nopng).
+Rows:
 
-    qoi-ref:     the reference implementation on one host core (the oracle build; a baseline)
     qoi-mi355x:  qoi_encode()/qoi_decode() of libqoi_mi355x.so, host pointers in and out (the drop-in; pays PCIe)
     qoi-dev:     the same kernels on device-resident buffers (qoimi_encode_batch / qoimi_decode_batch)
+    qoi-ref:     only with --ref-lib PATH [--ref-prefix P]: a CPU build of the reference's qoi_encode/qoi_decode
+                 (any shared object exporting `<P>qoi_encode` / `<P>qoi_decode`) timed beside, one host core
 
---nogpu prints the reference row only (no MI355X needed); --synth K writes K synthetic .qoi files of every
-content class into the directory first (there are no test images in the reference tree).
+--synth K writes K synthetic .png files of every content class into the directory first (there are no test images
+in the reference tree).  The tool itself contains no CPU codec and needs the MI355X for its own rows.
 """
 from __future__ import annotations
 
 import argparse
 import os
-import struct
 import sys
 import time
+
+import ctypes
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-ROWS = ("qoi-ref:   ", "qoi-mi355x:", "qoi-dev:   ")
+import png_io  # noqa: E402
+
+ROWS = ("qoi-mi355x:", "qoi-dev:   ", "qoi-ref:   ")
 
 
 class Result:
@@ -76,16 +81,43 @@ def bench_fn(nowarmup: bool, runs: int, fn) -> int:
     return total // runs
 
 
+class RefCodec:
+    """A CPU build of the reference ABI (qoi.h:278, 289) loaded from a shared object - the optional baseline row."""
+
+    class Desc(ctypes.Structure):
+        _fields_ = [("width", ctypes.c_uint), ("height", ctypes.c_uint), ("channels", ctypes.c_ubyte), ("colorspace", ctypes.c_ubyte)]
+
+    def __init__(self, path: str, prefix: str = ""):
+        lib = ctypes.CDLL(path)
+        self.enc = getattr(lib, prefix + "qoi_encode"); self.dec = getattr(lib, prefix + "qoi_decode")
+        self.enc.restype = ctypes.c_void_p
+        self.enc.argtypes = [ctypes.c_void_p, ctypes.POINTER(self.Desc), ctypes.POINTER(ctypes.c_int)]
+        self.dec.restype = ctypes.c_void_p
+        self.dec.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(self.Desc), ctypes.c_int]
+        self.free = ctypes.CDLL(None).free
+        self.free.argtypes = [ctypes.c_void_p]; self.free.restype = None
+
+    def encode(self, pixels: np.ndarray, w: int, h: int, ch: int):
+        d = self.Desc(w, h, ch, 0); n = ctypes.c_int(0)
+        p = self.enc(pixels.ctypes.data, ctypes.byref(d), ctypes.byref(n))
+        return p, n.value
+
+
+def load_image(path: str):
+    """uint8[h, w, ch] like qoibench.c:389-398: the PNG's own 3 channels, anything else as RGBA."""
+    data = open(path, "rb").read()
+    w, h, ch = png_io.png_info(data)
+    ch = 3 if ch == 3 else 4
+    px, w, h = png_io.read_png(data, ch)
+    return np.ascontiguousarray(px), w, h, ch
+
+
 def benchmark_image(path: str, opt, ref, gpu) -> Result:
-    stream_in = open(path, "rb").read()
-    pixels, d = ref.decode(stream_in, 0)
-    if pixels is None:
-        raise SystemExit(f"Error decoding {path}")
-    w, h, ch = d.width, d.height, d.channels
+    try:
+        pixels, w, h, ch = load_image(path)
+    except (OSError, png_io.PngError):
+        raise SystemExit(f"Error decoding header {path}")             # qoibench.c:385-388
     res = Result(); res.count = 1; res.raw_size = w * h * ch; res.px = w * h
-    from oracle import oracle_py
-    desc_ref = oracle_py.QoiDesc(w, h, ch, 0)
-    encoded = ref.encode(pixels, w, h, ch)
     if gpu:
         api, ctx, torch = gpu
         desc = api.QoiDesc(w, h, ch, api.QOI_SRGB)
@@ -94,31 +126,18 @@ def benchmark_image(path: str, opt, ref, gpu) -> Result:
             raise SystemExit(f"Error encoding {path}")
         if not opt.noverify:                                       # qoibench.c:408-417
             back, _ = api.qoi_decode(enc_gpu, ch)
-            if back is None or not np.array_equal(back, pixels):
+            if back is None or not np.array_equal(back, pixels.reshape(-1)):
                 raise SystemExit(f"QOI roundtrip pixel mismatch for {path}")
-    # row 0: reference on the host
-    if not opt.nodecode:
-        def f():
-            p, _ = ref.decode_raw(buf_addr, len(encoded), 4); ref.free(p)
-        import ctypes
-        cbuf = (ctypes.c_ubyte * len(encoded)).from_buffer_copy(encoded); buf_addr = ctypes.addressof(cbuf)
-        res.libs[0][2] = bench_fn(opt.nowarmup, opt.runs, f)
-    if not opt.noencode:
-        def f():
-            p, n = ref.encode_raw(pixels.ctypes.data, desc_ref); ref.free(p)
-        res.libs[0][1] = bench_fn(opt.nowarmup, opt.runs, f)
-        res.libs[0][0] = len(encoded)
-    if gpu:
-        # row 1: drop-in, host pointers
+        # row 0: drop-in, host pointers
         if not opt.nodecode:
-            res.libs[1][2] = bench_fn(opt.nowarmup, opt.runs, lambda: api.qoi_decode(enc_gpu, 4))
+            res.libs[0][2] = bench_fn(opt.nowarmup, opt.runs, lambda: api.qoi_decode(enc_gpu, 4))
         if not opt.noencode:
-            res.libs[1][1] = bench_fn(opt.nowarmup, opt.runs, lambda: api.qoi_encode(pixels, desc))
-            res.libs[1][0] = len(enc_gpu)
-        # row 2: device-resident
+            res.libs[0][1] = bench_fn(opt.nowarmup, opt.runs, lambda: api.qoi_encode(pixels, desc))
+            res.libs[0][0] = len(enc_gpu)
+        # row 1: device-resident
         pstride = (w * h * 4 + 255) // 256 * 256
         sstride = (api.encode_bound(w, h, ch) + 255) // 256 * 256
-        dpx = torch.from_numpy(pixels.copy()).cuda()
+        dpx = torch.from_numpy(pixels.reshape(-1).copy()).cuda()
         dst = torch.empty(sstride, dtype=torch.uint8, device="cuda")
         dout = torch.empty(pstride, dtype=torch.uint8, device="cuda")
         dlen = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -132,10 +151,26 @@ def benchmark_image(path: str, opt, ref, gpu) -> Result:
             ctx.decode_batch(dst.data_ptr(), sstride, [len(enc_gpu)], [desc], 4, dout.data_ptr(), pstride, st)
         enc()
         if not opt.nodecode:
-            res.libs[2][2] = bench_fn(opt.nowarmup, opt.runs, dec)
+            res.libs[1][2] = bench_fn(opt.nowarmup, opt.runs, dec)
         if not opt.noencode:
-            res.libs[2][1] = bench_fn(opt.nowarmup, opt.runs, enc)
-            res.libs[2][0] = len(enc_gpu)
+            res.libs[1][1] = bench_fn(opt.nowarmup, opt.runs, enc)
+            res.libs[1][0] = len(enc_gpu)
+    if ref:
+        # row 2: a CPU build of the reference on the host (baseline; malloc/free inside the timed region)
+        p, n = ref.encode(pixels, w, h, ch)
+        if not p:
+            raise SystemExit(f"Error encoding {path}")
+        encoded = ctypes.string_at(p, n); ref.free(p)
+        cbuf = (ctypes.c_ubyte * n).from_buffer_copy(encoded); buf_addr = ctypes.addressof(cbuf)
+        if not opt.nodecode:
+            def f():
+                d = RefCodec.Desc(); q = ref.dec(buf_addr, n, ctypes.byref(d), 4); ref.free(q)
+            res.libs[2][2] = bench_fn(opt.nowarmup, opt.runs, f)
+        if not opt.noencode:
+            def f():
+                q, _ = ref.encode(pixels, w, h, ch); ref.free(q)
+            res.libs[2][1] = bench_fn(opt.nowarmup, opt.runs, f)
+            res.libs[2][0] = n
     return res
 
 
@@ -149,15 +184,15 @@ def benchmark_directory(path: str, grand: Result, opt, ref, gpu, rows, out):
     dirtotal = Result()
     has_shown_head = False
     for e in entries:
-        if not e.endswith(".qoi"):
+        if not e.endswith(".png"):
             continue
         if not has_shown_head:
             has_shown_head = True
-            out(f"## Benchmarking {path}/*.qoi -- {opt.runs} runs\n")
+            out(f"## Benchmarking {path}/*.png -- {opt.runs} runs\n")
         f = os.path.join(path, e)
         res = benchmark_image(f, opt, ref, gpu)
         if not opt.onlytotals:
-            w, h = struct.unpack(">II", open(f, "rb").read(12)[4:12])
+            w, h, _ = png_io.png_info(open(f, "rb").read())
             out(f"## {f} size: {w}x{h}")
             out(print_result(res, rows))
         dirtotal.add(res)
@@ -168,38 +203,40 @@ def benchmark_directory(path: str, grand: Result, opt, ref, gpu, rows, out):
 
 
 def write_synth(directory: str, k: int):
-    from oracle import oracle_py
     from qoi_amd import synth
-    port = oracle_py.load_port()
     os.makedirs(directory, exist_ok=True)
     for kind in synth.KINDS:
         for i in range(k):
             w, h = (1920, 1080) if i % 2 == 0 else (640, 480)
-            s = port.encode(synth.frame_rgba(kind, w, h, i), w, h, 4)
-            open(os.path.join(directory, f"{kind}_{i}.qoi"), "wb").write(s)
+            open(os.path.join(directory, f"{kind}_{i}.png"), "wb").write(png_io.write_png(synth.frame_rgba(kind, w, h, i), 1))
 
 
-def main(argv=None, out=print) -> int:
+def main(argv=None, out=print, ref=None, use_gpu=True) -> int:
+    """`ref` / `use_gpu=False`: the tests drive the table and flag logic with a CPU reference build and no GPU."""
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("runs", type=int)
     ap.add_argument("directory")
-    for f in ("nowarmup", "noverify", "noencode", "nodecode", "norecurse", "onlytotals", "nogpu"):
+    for f in ("nowarmup", "noverify", "noencode", "nodecode", "norecurse", "onlytotals"):
         ap.add_argument("--" + f, action="store_true")
     ap.add_argument("--synth", type=int, default=0)
+    ap.add_argument("--ref-lib", default="", help="shared object with a CPU build of the reference ABI: adds the qoi-ref row")
+    ap.add_argument("--ref-prefix", default="", help="symbol prefix in --ref-lib (e.g. ref_)")
     opt = ap.parse_args(argv)
     if opt.runs < 1:
         raise SystemExit("Invalid number of runs")                  # qoibench.c:598-600
     if opt.synth:
         write_synth(opt.directory, opt.synth)
-    from oracle import oracle_py
-    ref = oracle_py.load_ref() or oracle_py.load_port()
+    if ref is None and opt.ref_lib:
+        ref = RefCodec(opt.ref_lib, opt.ref_prefix)
     gpu = None
-    rows = (0,)
-    if not opt.nogpu:
+    rows = ()
+    if use_gpu:
         import torch
         from qoi_amd import api
-        gpu = (api, api.Context(0), torch)
-        rows = (0, 1, 2)
+        gpu = (api, api.Context(0), torch)                           # fails loudly without the library / a gfx950 GPU
+        rows = (0, 1)
+    if ref:
+        rows = rows + (2,)
     grand = Result()
     benchmark_directory(opt.directory, grand, opt, ref, gpu, rows, out)
     if grand.count > 0:
