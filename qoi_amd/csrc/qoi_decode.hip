@@ -82,14 +82,16 @@ struct LaneReaderT {
     static_assert(16 * NP_ >= 5 * PERIOD_, "refill rate below the worst-case consumption");
     uint32_t ring;             // LDS byte address of ring[0][lane]; dword k of the ring at ring + k*256
     const uint8_t* abase;      // 16-byte aligned start of the fetched range
-    const uint8_t* aend;       // first byte that must not be read (stream + size)
+    const uint8_t* alast;      // last 16-byte granule that starts before stream + size
     uint32_t aoff;             // abase - stream: stream position p sits at ring byte (p - aoff)
     uint32_t wr;               // dwords landed in the ring, counted from abase
     uint4 pend[NP_]; uint32_t npend;
 
     __device__ __forceinline__ uint4 load16(const uint8_t* p) const {
-        // an aligned 16-byte granule that starts inside the stream never crosses a page
-        return p < aend ? load_global16(p) : make_uint4(0u, 0u, 0u, 0u);
+        // An aligned 16-byte granule that starts inside the stream never crosses a page.  A granule past the end is
+        // replaced by the last one inside (no branch, no zero fill): those ring bytes stand for stream positions that
+        // no chunk reads.
+        return load_global16(p < alast ? p : alast);
     }
     __device__ __forceinline__ void put4(uint32_t at, const uint4& v) {       // at: multiple of 4
         const uint32_t a = ring + (at & (RD - 1u)) * 256u;
@@ -101,7 +103,7 @@ struct LaneReaderT {
         ring = ring_addr;
         const uint8_t* p = stream + pos0;
         abase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)15);
-        aend = stream + size;
+        alast = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(stream + size - 1u) & ~(uintptr_t)15);
         aoff = pos0 - (uint32_t)(p - abase);
 #pragma unroll
         for (uint32_t r = 0; r < RD / 4u; ++r) put4(4u * r, load16(abase + 16u * r));
@@ -233,7 +235,10 @@ struct LaneWriter {
         while (fpos + kGroup <= ppos) {
             uint32_t v[kGroup];
 #pragma unroll
-            for (uint32_t k = 0; k < kGroup; ++k) v[k] = at(fpos + k);
+            for (uint32_t k = 0; k < kGroup; k += 4u) {                   // an aligned group of 4 never wraps in the ring
+                const lds_u32* g = (const lds_u32*)(row + ((fpos + k) & (kRing - 1u)) * 256u);
+                v[k] = g[0]; v[k + 1u] = g[64]; v[k + 2u] = g[128]; v[k + 3u] = g[192];
+            }
 #pragma unroll
             for (uint32_t k = 0; k < kGroup; k += 4u) store4(fpos + k, v[k], v[k + 1u], v[k + 2u], v[k + 3u]);
             fpos += kGroup;
