@@ -840,10 +840,15 @@ struct LdsSymTab {
     __device__ __forceinline__ void set(uint32_t k, sym_t v) { col[k * 64u] = v; }
 };
 
-// The symbolic table is kept as two LDS arrays, constants (u32) and source|absmask (u16): 24 KiB per
-// wavefront instead of 32, which lets a fifth wavefront onto the CU (this kernel is bound by how many
-// lanes are resident, see dec_segments).  Same step as symf_step (qoi_decode_core.h), with the SDWA byte
-// adds and with the LDS round trips of a step in flight together.
+// The symbolic table is kept as two LDS arrays, constants (u32) and a one-byte code for source and absolute mask:
+// 20 KiB per wavefront instead of 32, which lets a sixth wavefront onto the CU (this kernel is bound by how many
+// lanes are resident, see dec_segments).  Only three masks occur - nothing absolute, r,g,b absolute (QOI_OP_RGB
+// keeps the alpha), everything absolute (QOI_OP_RGBA; the source no longer matters) - so the code is
+//   source (0..64)          nothing absolute
+//   65 + source             r,g,b absolute
+//   255                     all absolute
+// Same step as symf_step (qoi_decode_core.h), with the SDWA byte adds and with the LDS round trips of a step in
+// flight together.
 //
 // REFINE (rounds after a failed exit-state check): the entry states the previous round computed serve as
 // hints - slot and alpha at segment entry come from the hinted entry pixel (no P2/S2 in these rounds), and
@@ -851,12 +856,18 @@ struct LdsSymTab {
 // alpha of that entry word.  Streams whose alpha changes through the colour table (UI content with
 // several alpha levels) mis-speculate the slot of a later QOI_OP_RGB in almost every segment in round 1 and
 // verify in 2-5 rounds with the hints (one segment per round without them).
+constexpr uint32_t kSymCodeRgb = 65u, kSymCodeAbs = 255u;
+__device__ __forceinline__ uint32_t sym_code_expand(uint32_t code) {       // -> source | absmask << 8 (sym_t bits 32..43)
+    return code == kSymCodeAbs ? (15u << 8) : (code >= kSymCodeRgb ? ((code - kSymCodeRgb) | (7u << 8)) : code);
+}
+
 template <bool REFINE>
 __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     __shared__ __attribute__((aligned(4096))) uint32_t s_ring[LaneReader::kSlots * 64];
-    __shared__ uint32_t s_tabc[65 * 64];          // row 64: kSymParkRow
-    __shared__ uint16_t s_tabm[65 * 64];
-    __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 64];
+    constexpr uint32_t kRows = REFINE ? 65u : 64u;                  // row 64: kSymParkRow (refinement rounds only)
+    __shared__ uint32_t s_tabc[kRows * 64];
+    __shared__ uint8_t s_tabm[kRows * 64];                          // source / mask codes, see sym_code
+    __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 4];
     __shared__ LdsLut s_lut;
     const uint32_t lane = lane_id();
     build_lut(s_lut, lane, 64u);
@@ -872,13 +883,13 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
     LaneReader R;
     R.init(lds_addr_of(&s_ring[lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
-    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
     const uint32_t tc_base = lds_addr_of(&s_tabc[lane]);             // slot k at + k*256
-    const uint32_t tm_base = lds_addr_of(&s_tabm[lane]);             // slot k at + k*128
+    const uint32_t tm_base = lds_addr_of(&s_tabm[lane]);             // slot k at + k*64
     const uint32_t lut_base = lds_addr_of(&s_lut.delta[0]);
     // identity: slot k = entry slot k + 0, pixel = entry pixel + 0 (sym_init)
-    for (uint32_t k = 0; k < 64u; ++k) { *(lds_u32*)(tc_base + k * 256u) = 0u; *(lds_u16*)(tm_base + k * 128u) = (uint16_t)k; }
-    uint32_t pc = 0u, ph = 64u;
+    for (uint32_t k = 0; k < 64u; ++k) { *(lds_u32*)(tc_base + k * 256u) = 0u; *(lds_u8*)(tm_base + k * 64u) = (uint8_t)k; }
+    uint32_t pc = 0u, ph = 64u;                                       // ph: code of the running pixel (entry pixel, nothing absolute)
     uint32_t slot, alpha;
     if (REFINE) {
         const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
@@ -915,7 +926,7 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
             if (active) {
                 const uint32_t b1 = w32 & 0xFFu;
                 const uint32_t t_c = *(const lds_u32*)(tc_base + ((w32 & 63u) << 8));
-                const uint32_t t_m = *(const lds_u16*)(tm_base + ((w32 & 63u) << 7));
+                const uint32_t t_m = *(const lds_u8*)(tm_base + ((w32 & 63u) << 6));
                 const uint32_t npos = pos + QOIMI_STEP_LEN(b1, info);
                 uint32_t nw32, nb5; R.peek(npos, nw32, nb5);      // next chunk's bytes travel while this one is executed
                 const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)info, 28, 1);        // all ones for LUMA
@@ -931,7 +942,7 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
                     const uint32_t pc_rgb = (pc & 0xFF000000u) | (rgba & 0x00FFFFFFu);
                     const uint32_t lrgb = __builtin_amdgcn_udot4(rgba, 0x00070503u, 0u, false);
                     sb = lrgb + 11u * (lo ? b5 : alpha);
-                    pb = lo ? rgba : pc_rgb; hb = lo ? (15u << 8) : (ph | (7u << 8));
+                    pb = lo ? rgba : pc_rgb; hb = lo ? kSymCodeAbs : (ph < kSymCodeRgb ? ph + kSymCodeRgb : ph);
                 }
                 const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
                 const uint32_t ndelta0 = lq[0], ninfo = lq[256];
@@ -940,12 +951,12 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
                 ph = hi ? hb : ha;
                 slot = (hi ? sb : sa) & 63u;
                 // alpha after the chunk: RGBA sets it, INDEX takes the named entry's (hinted where it is still symbolic)
-                const uint32_t th = REFINE ? (uint32_t)s_hint[(t_m & 0x7Fu) * 64u + lane] : alpha_in0;
-                const uint32_t ta = (t_m & 0x800u) ? (t_c >> 24) : th;
+                const uint32_t th = REFINE ? (uint32_t)s_hint[(t_m < kSymCodeRgb ? t_m : (t_m - kSymCodeRgb) & 0x7Fu) * 64u + lane] : alpha_in0;
+                const uint32_t ta = t_m == kSymCodeAbs ? (t_c >> 24) : th;
                 alpha = hi ? (lo ? b5 : alpha) : (lo ? ta : alpha);
                 const uint32_t wslot = (info & runmask) ? kSymParkRow : slot;
                 *(lds_u32*)(tc_base + (wslot << 8)) = pc;         // index update after every chunk (qoi.h:577)
-                *(lds_u16*)(tm_base + (wslot << 7)) = (uint16_t)ph;
+                *(lds_u8*)(tm_base + (wslot << 6)) = (uint8_t)ph;
                 pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
                 active = pos < end;
             }
@@ -954,8 +965,8 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     if (have) {
         sym_t* dst = p.summary + (size_t)q * 65u;
         for (uint32_t k = 0; k < 64u; ++k)
-            dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)*(const lds_u16*)(tm_base + k * 128u) << 32);
-        dst[64] = (sym_t)pc | ((sym_t)ph << 32);
+            dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)sym_code_expand(*(const lds_u8*)(tm_base + k * 64u)) << 32);
+        dst[64] = (sym_t)pc | ((sym_t)sym_code_expand(ph) << 32);
     }
 }
 
