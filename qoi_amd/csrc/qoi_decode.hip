@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void dec_parse(DecParams p) {
     uint32_t m = base, add = 0;
     bool merged = false;
     bool active = have && m < end;
-    for (uint32_t it = 0; __ballot(active); ++it) {
+    for (uint32_t it = 0; lanes_where(active); ++it) {
         if (R.due(it)) R.refill(m);
         if (active) {
             uint32_t w32, b5; R.peek(m, w32, b5);
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     uint32_t m = base;
     bool merged = false;
     bool active = have && m < end;
-    while (__ballot(active && !merged)) {
+    while (lanes_where(active && !merged)) {
         if (active && !merged) {
             parse_step(s, m, R.byte(m));
             m = parse_front(s);
@@ -421,17 +421,20 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     const uint32_t moff = merged ? m - base : 255u;       // chains met at base + moff (<= 132)
     uint32_t add = 0;
     SlotFast st; slotf_init(st);
-    while (__ballot(active)) {
-        if (active) {
-            uint32_t w32, b5; R.peek(m, w32, b5);
-            const uint32_t b1 = w32 & 0xFFu;
-            const uint32_t info = s_lut.info[b1];
-            add += lut_pixels(info);
-            if (__ballot(lut_hi(info))) slotf_step(st, w32, b5, info);    // some lane stands on QOI_OP_RGB / QOI_OP_RGBA
-            else slotf_step_norgb(st, w32, info);
-            m += len_of(b1);
-            active = m < end;
-        }
+    // one chunk per step; the next chunk's bytes and its table word are asked for before this chunk's arithmetic
+    // No lane is masked off inside the loop: a lane that is through with its piece runs a null chunk (length 0, no
+    // pixels, slot shift 0) - with the exec mask untouched the loop has no merge copies.
+    uint32_t w32, b5; R.peek(min(m, end), w32, b5);
+    uint32_t info = s_lut.info[w32 & 0xFFu];
+    while (lanes_where(active)) {
+        const uint32_t c_info = active ? info : 0u;
+        const uint32_t nm = m + (active ? len_of(w32 & 0xFFu) : 0u);       // arithmetic: no LDS word on the cursor's chain
+        uint32_t nw32, nb5; R.peek(nm, nw32, nb5);                         // stays inside the buffer: nm <= end + 4
+        const uint32_t ninfo = s_lut.info[nw32 & 0xFFu];
+        add += lut_pixels(c_info);
+        slotf_step_split(st, w32, b5, c_info, lanes_where(lut_hi(c_info)) != 0);
+        m = nm; w32 = nw32; b5 = nb5; info = ninfo;
+        active = active && m < end;
     }
     if (merged) {
         s.p0 = s.p1 = s.p2 = s.p3 = s.p4 = m;
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(256) void dec_slot_heads_fine(DecParams p) {
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
     have = have && j >= im.start_seg && j < im.n_active;
-    if (!__ballot(have)) return;
+    if (!lanes_where(have)) return;
     const uint32_t cbase = (uint32_t)kHeaderBytes + j * p.seg_bytes;
     const uint32_t cend = min(cbase + p.seg_bytes, im.chunks_end);
     const uint32_t base = cbase + sub * kFineBytes;
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(256) void dec_slot_heads_fine(DecParams p) {
         R.aoff = lo16 - (uint32_t)(pp - abase);
         const uint32_t need = active ? (stop - R.aoff + 8u + 15u) >> 4 : 0u;      // 16-byte pieces this lane needs
         for (uint32_t r = 0; r < kFinePieces; ++r) {
-            if (!__ballot(r < need)) break;
+            if (!lanes_where(r < need)) break;
             if (r < need) {
                 const uint4 v = abase + 16u * r < aend ? load_global16(abase + 16u * r) : make_uint4(0u, 0u, 0u, 0u);
                 lds_u32* qd = (lds_u32*)(R.buf + r * 1024u);
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(256) void dec_slot_heads_fine(DecParams p) {
         }
     }
     SlotFast s; slotf_init(s);
-    while (__ballot(active)) {
+    while (lanes_where(active)) {
         if (active) {
             uint32_t w32, b5; R.peek(pos, w32, b5);
             const uint32_t b1 = w32 & 0xFFu;
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(64) void dec_chain_parse_l3(DecParams p) {
     // n_active: segments that start before the pixel limit.  Only the group that holds the last such segment
     // reports (its successor starts at the limit, or it is the image's last group): one atomic per image, not one per
     // group on the same word.
-    const u64 act = __ballot(lane < cnt && my_off < im.npx);
+    const u64 act = lanes_where(lane < cnt && my_off < im.npx);
     const bool boundary = j0 + cnt == im.nseg || off0 + total >= (u64)im.npx;
     if (lane == 0 && act && boundary) atomicMax(&p.images[img].n_active, j0 + 64u - (uint32_t)__builtin_clzll(act));
 }
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(256) void dec_slot_walk(DecParams p) {
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
     have = have && j >= im.start_seg && j < im.n_active;
-    if (!__ballot(have)) return;
+    if (!lanes_where(have)) return;
     const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
     uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(256) void dec_slot_walk(DecParams p) {
     R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
     SlotFast s; slotf_init(s);
     bool active = have && pos < end;
-    for (uint32_t it = 0; __ballot(active); ++it) {
+    for (uint32_t it = 0; lanes_where(active); ++it) {
         if (R.due(it)) R.refill(pos);
         if (active) {
             uint32_t w32, b5; R.peek(pos, w32, b5);
@@ -877,7 +880,7 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
     have = have && j >= im.start_seg && j < im.n_active;
-    if (!__ballot(have)) return;
+    if (!lanes_where(have)) return;
     const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
     uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     uint32_t delta0, info;
     {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); delta0 = lq[0]; info = lq[256]; }
     // blocks of kPeriod steps: the stream loads issued by refill() are waited for at the NEXT refill only
-    while (__ballot(active)) {
+    while (lanes_where(active)) {
         R.refill(pos);
 #pragma unroll
         for (uint32_t u = 0; u < LaneReader::kPeriod; ++u) {
@@ -937,7 +940,7 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
                 const bool hi = lut_hi(info), lo = lut_lo(info);
                 const uint32_t s_rel = slot + lut_slot_shift(info) + 3u * er + 7u * eb;
                 uint32_t sb = 0, pb = 0, hb = 0;
-                if (__ballot(hi)) {                       // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
+                if (lanes_where(hi)) {                       // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
                     const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);
                     const uint32_t pc_rgb = (pc & 0xFF000000u) | (rgba & 0x00FFFFFFu);
                     const uint32_t lrgb = __builtin_amdgcn_udot4(rgba, 0x00070503u, 0u, false);
@@ -1142,7 +1145,7 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
     have = have && j >= im.start_seg && j < im.n_active;
-    if (!__ballot(have)) return;
+    if (!lanes_where(have)) return;
     const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
     uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
@@ -1182,7 +1185,7 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
     const bool clip_lane = have && (j + 1u >= im.n_active || p.px_off[q + 1u] >= limit);
     auto run = [&](auto clip_tag) {
         constexpr bool CLIP = decltype(clip_tag)::value;
-        while (__ballot(active)) {
+        while (lanes_where(active)) {
             R.land();
             R.issue(pos);
             W.drain();
@@ -1198,7 +1201,7 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
                     const bool hi = lut_hi(info), lo = lut_lo(info);
                     const uint32_t npx = lut_pixels(info);
                     uint32_t b = 0;
-                    if (__ballot(hi)) {                       // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
+                    if (lanes_where(hi)) {                       // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
                         const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);                 // r,g,b,a = chunk bytes 1..4
                         const uint32_t rgbv = (px & 0xFF000000u) | (rgba & 0x00FFFFFFu);
                         b = lo ? rgba : rgbv;
@@ -1230,7 +1233,7 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
             }
         }
     };
-    if (__ballot(clip_lane)) run(std::true_type{}); else run(std::false_type{});
+    if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
     if (have) {
         W.finish();
         if (j + 1u < im.n_active) {

@@ -387,6 +387,26 @@ QOIMI_HD void slotf_step(SlotFast& s, uint32_t w32, uint32_t b5, uint32_t info) 
     s.fl = hi ? fb : fa;
     s.ac = (hi && lo) ? b5 : s.ac;
 }
+// The same step in the shape the kernels' loops want: the part every chunk needs first, the QOI_OP_RGB / QOI_OP_RGBA
+// part only if `any_hi` (on the device: some lane of the wavefront stands on such a chunk - one in a thousand in
+// natural images; on the host: this chunk is one).  One body for both cases keeps the loop free of merge copies.
+QOIMI_HD void slotf_step_split(SlotFast& s, uint32_t w32, uint32_t b5, uint32_t info, bool any_hi) {
+    const bool hi = lut_hi(info), lo = lut_lo(info);
+    const uint32_t rel = s.hc + lut_slot_shift(info) + lin_hash(luma_extra(w32, info));
+    uint32_t hc = lo ? (w32 & 0xFFu) : rel;                              // INDEX : relative
+    uint32_t fl = lo ? (s.fl & 4u) : s.fl;
+    if (any_hi) {
+        const bool a_abs = (s.fl & 4u) != 0u;
+        const uint32_t lrgb = lin_hash(w32 >> 8);
+        const uint32_t b = lrgb + (lo ? 11u * b5 : (a_abs ? 11u * s.ac : 0u));    // RGBA : RGB
+        const uint32_t fb = lo ? 4u : ((s.fl & 4u) | (a_abs ? 0u : 2u));
+        hc = hi ? b : hc;
+        fl = hi ? fb : fl;
+        s.ac = (hi && lo) ? b5 : s.ac;
+    }
+    s.hc = hc & 63u;
+    s.fl = fl;
+}
 // the same step for a chunk that is known not to be QOI_OP_RGB / QOI_OP_RGBA (the kernels take this form when no
 // lane of the wavefront stands on one - natural images carry one such chunk in a thousand)
 QOIMI_HD void slotf_step_norgb(SlotFast& s, uint32_t w32, uint32_t info) {
@@ -462,7 +482,7 @@ QOIMI_HD void slot_walk_segment_fast(const uint8_t* in, uint32_t pos, uint32_t s
     SlotFast s; slotf_init(s);
     while (pos < seg_end) {
         uint32_t w32, b5; R.peek(pos, w32, b5);
-        slotf_step(s, w32, b5, lut.info[w32 & 0xFFu]);
+        { const uint32_t info = lut.info[w32 & 0xFFu]; slotf_step_split(s, w32, b5, info, lut_hi(info)); }
         pos += len_of(w32 & 0xFFu);
     }
     slotf_finish(s, r);

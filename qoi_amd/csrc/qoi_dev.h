@@ -27,6 +27,9 @@ __host__ __device__ __forceinline__ uint32_t slot_of(uint32_t px) {
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// mask of the lanes where b holds (HIP's __ballot(int) first turns a bool that already sits in an SGPR pair into 0/1 in a
+// VGPR and compares that with 0: two vector instructions per loop test)
+__device__ __forceinline__ u64 lanes_where(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
 // value of lane-1 (lane 0 receives `carry`): one v_mov_b32_dpp wave_shr:1.
 __device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t carry) {
