@@ -251,6 +251,12 @@ struct LaneWriter {
         *(lds_u32*)(row + ((ppos + 1u) & (kRing - 1u)) * 256u) = px;
         ppos += two ? 2u : 1u;
     }
+    // the same with a count: n = 0 (nothing), 1 or 2
+    __device__ __forceinline__ void put2n(uint32_t px, uint32_t n) {
+        *(lds_u32*)(row + (ppos & (kRing - 1u)) * 256u) = px;
+        *(lds_u32*)(row + ((ppos + 1u) & (kRing - 1u)) * 256u) = px;
+        ppos += n;
+    }
     __device__ __forceinline__ void put(uint32_t px) {
         if (__builtin_expect(ppos - fpos == kRing, 0)) drain();           // only long runs fill the ring between drains
         *(lds_u32*)(row + (ppos & (kRing - 1u)) * 256u) = px;
@@ -1259,6 +1265,182 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------
+// P4 as a pair of wavefronts per 64 segments (one workgroup of 128 threads).  dec_segments is bound by the
+// instructions one wavefront retires (about 100 per chunk step at one instruction per ~9 cycles, with only six
+// wavefronts per CU because of the private colour tables).  The step splits cleanly where no pixel state is needed:
+//   wavefront 0, the reader:   walks the chunk boundaries, fetches bytes, looks up the chunk table and writes one
+//                              two-word record per chunk and lane into LDS - value word (byte-wise delta, or r,g,b,a
+//                              of an RGB / RGBA chunk) and control word (pixel count, op class, slot an INDEX names);
+//   wavefront 1, the decoder:  owns the colour tables and the pixel ring; turns records into pixels.
+// The two run on different SIMDs, each retires about half the instructions, and a pair needs the tables once: ten
+// wavefronts per CU instead of six.  They meet at one barrier per period of kPairPeriod steps (records are double
+// buffered: the reader fills period i while the decoder works off period i - 1).  A lane that is through with its
+// segment emits null records (no pixels, delta 0), so neither loop masks lanes off.
+// ---------------------------------------------------------------------------------
+constexpr uint32_t kPairPeriod = LaneReader::kPeriod;
+constexpr uint32_t kRecCtlMask = 0xC00001F8u;                  // chunk-table bits kept in a record: pixel count, op class
+
+template <int OCH>
+__global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
+    constexpr uint32_t kTabDw = 64u * 64u, kOutDw = LaneWriter<OCH>::kRing * 64u, kRingDw = LaneReader::kSlots * 64u;
+    constexpr uint32_t kRecDw = 2u * kPairPeriod * 2u * 64u;          // two buffers x steps x two words x lanes
+    static_assert(kOutDw * 4u == 4096u, "pixel ring is one 4 KiB block");
+    __shared__ __attribute__((aligned(16384))) uint32_t s_mem[kTabDw + kOutDw + kRingDw + kRecDw + sizeof(LdsLut) / 4u + 2u];
+    uint32_t* const s_tab = s_mem;
+    uint32_t* const s_out = s_mem + kTabDw;
+    uint32_t* const s_ring = s_mem + kTabDw + kOutDw;
+    uint32_t* const s_rec = s_mem + kTabDw + kOutDw + kRingDw;
+    LdsLut& s_lut = *reinterpret_cast<LdsLut*>(s_mem + kTabDw + kOutDw + kRingDw + kRecDw);
+    uint32_t* const s_flag = s_mem + kTabDw + kOutDw + kRingDw + kRecDw + sizeof(LdsLut) / 4u;
+    const uint32_t lane = lane_id();
+    const bool reader = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
+    build_lut(s_lut, threadIdx.x, 128u);                                // includes a barrier
+    const uint32_t q = blockIdx.x * 64u + lane;
+    bool have = q < p.total_segs;
+    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
+    const DecImage im = p.images[img];
+    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
+    have = have && j >= im.start_seg && j < im.n_active;
+    if (!lanes_where(have)) return;                                     // same answer in both wavefronts
+    const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
+    const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
+    const uint32_t pos0 = base + (have ? p.entry_phase[q] : 0u);
+    const uint32_t limit = im.npx;
+    const uint32_t rec_base = lds_addr_of(&s_rec[lane]);               // record (buffer b, step u, word w) at + ((b*P + u)*2 + w)*256
+
+    if (reader) {
+        // ------------------------------------------------------------------ wavefront 0: chunk records
+        LaneReader R;
+        uint32_t pos = pos0;
+        R.init(lds_addr_of(&s_ring[lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
+        const uint32_t lut_base = lds_addr_of(&s_lut.delta[0]);
+        bool active = have && pos < end && (have ? p.px_off[q] : 0u) < limit;
+        uint32_t w32, b5; R.peek(pos, w32, b5);
+        uint32_t delta0, info;
+        {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); delta0 = lq[0]; info = lq[256]; }
+        for (uint32_t it = 0;; ++it) {
+            const bool any = lanes_where(active) != 0;
+            if (any) { R.land(); R.issue(pos); }
+            const uint32_t buf = rec_base + (it & 1u) * (kPairPeriod * 2u * 256u);
+#pragma unroll
+            for (uint32_t u = 0; u < kPairPeriod; ++u) {
+                const uint32_t c_info = active ? info : 0u, c_delta0 = active ? delta0 : 0u;
+                const uint32_t npos = pos + lut_len(c_info);                // null chunk: length 0
+                uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
+                const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
+                const uint32_t ndelta0 = lq[0], ninfo = lq[256];
+                // byte-wise delta of a relative chunk (qoi.h:561-572): table part + the second byte of a LUMA chunk
+                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)c_info, 28, 1);      // all ones for LUMA
+                const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
+                uint32_t v = c_delta0;
+                add_byte0(v, er); add_byte2_from0(v, eb);
+                if (lanes_where(lut_hi(c_info))) {        // some lane stands on QOI_OP_RGB / QOI_OP_RGBA: value word = r,g,b,a
+                    const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);
+                    v = lut_hi(c_info) ? rgba : v;
+                }
+                const uint32_t ctl = (c_info & kRecCtlMask) | ((w32 & 63u) << 16);
+                lds_u32* rq = (lds_u32*)(buf + u * 512u);
+                rq[0] = v; rq[64] = ctl;
+                pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
+                active = active && pos < end;
+            }
+            if (lane == 0) s_flag[it & 1u] = any ? 1u : 0u;
+            __syncthreads();
+            if (!any) break;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- wavefront 1: pixels
+    LaneWriter<OCH> W;
+    W.init(lds_addr_of(&s_out[lane]), p.pixels + (size_t)img * p.pixel_stride, have ? p.px_off[q] : 0u);
+    LdsTab32 tab{&s_tab[lane]};
+    const uint32_t tab_base = lds_addr_of(&s_tab[lane]);
+    const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
+    uint32_t px = 0;
+    if (have) {
+        for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {          // 16 loads in flight, then 16 LDS writes
+            uint32_t v[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) v[k] = ent[k0 + k];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) tab.set(k0 + k, v[k]);
+        }
+        px = ent[64];
+    }
+    constexpr uint32_t kLongRun = 12;
+    const bool clip_lane = have && (j + 1u >= im.n_active || p.px_off[q + 1u] >= limit);
+    auto run = [&](auto clip_tag) {
+        constexpr bool CLIP = decltype(clip_tag)::value;
+        for (uint32_t it = 0;; ++it) {
+            if (it > 0u) {
+                W.drain();
+                const uint32_t buf = rec_base + ((it - 1u) & 1u) * (kPairPeriod * 2u * 256u);
+                uint32_t rv[kPairPeriod], rc[kPairPeriod];
+#pragma unroll
+                for (uint32_t u = 0; u < kPairPeriod; ++u) { const lds_u32* rq = (const lds_u32*)(buf + u * 512u); rv[u] = rq[0]; rc[u] = rq[64]; }
+#pragma unroll
+                for (uint32_t u = 0; u < kPairPeriod; ++u) {
+                    const uint32_t v = rv[u], ctl = rc[u];
+                    const uint32_t t = *(const lds_u32*)(tab_base + ((ctl >> 8) & 0x3F00u));     // slot an INDEX names
+                    uint32_t rel = px;
+                    add_byte0(rel, v); add_byte1(rel, v); add_byte2(rel, v);
+                    const bool hi = lut_hi(ctl), lo = lut_lo(ctl);
+                    uint32_t b = 0;
+                    if (lanes_where(hi)) {                   // QOI_OP_RGB keeps the alpha, QOI_OP_RGBA sets it (qoi.h:548-557)
+                        const uint32_t rgbv = (px & 0xFF000000u) | (v & 0x00FFFFFFu);
+                        b = lo ? v : rgbv;
+                    }
+                    const uint32_t a = lo ? t : rel;
+                    uint32_t npxl = hi ? b : a;
+                    if (CLIP) npxl = W.ppos < limit ? npxl : px;             // at the pixel limit the decoder has stopped (qoi.h:540)
+                    px = npxl;
+                    // index[QOI_COLOR_HASH(px) % 64] = px after every chunk (qoi.h:577)
+                    const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
+                    *(lds_u32*)(tab_base + ((h & 63u) << 8)) = px;
+                    uint32_t rem = lut_pixels(ctl);                           // 0: null record
+                    if (CLIP) rem = min(rem, limit - W.ppos);                 // over-long run clipped (Appendix B item 8)
+                    const uint32_t n2 = min(rem, 2u);
+                    W.put2n(px, n2);
+                    rem -= n2;
+                    if (rem) {                                                 // QOI_OP_RUN of three or more (qoi.h:573-575)
+                        if (rem >= kLongRun) W.splat(px, rem);
+                        while (rem) { W.put(px); --rem; }
+                        if (W.ppos - W.fpos > LaneWriter<OCH>::kRing - 2u * kPairPeriod) W.drain();
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_flag[it & 1u] == 0u) break;
+        }
+    };
+    if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
+    if (have) {
+        W.finish();
+        if (j + 1u < im.n_active) {
+            // exit state must equal what the next segment was started from
+            const uint32_t* __restrict__ nxt = ent + 65u;
+            bool same = nxt[64] == px;
+            for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {
+                uint32_t v[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) v[k] = nxt[k0 + k];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) same = same && (v[k] == tab.get(k0 + k));
+            }
+            if (!same) {
+                uint32_t* fx = p.fix + (size_t)(q + 1u) * 65u;
+                for (uint32_t k = 0; k < 64u; ++k) fx[k] = tab.get(k);
+                fx[64] = px;
+                atomicMin(&p.first_bad[img], j + 1u);
+            }
+        } else {
+            p.images[img].final_px = px;     // pixel repeated when the stream ends early (qoi.h:544)
+        }
+    }
+}
+
 // Pixels the chunks never reach repeat the last pixel (truncated streams, size==22).
 template <int OCH>
 __global__ __launch_bounds__(256) void dec_fill(DecParams p) {
@@ -1341,7 +1523,10 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
     hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);
     tm->mark(kT_dec_chain_state, st);
-    if (out_channels == 4) hipLaunchKernelGGL(dec_segments<4>, dim3(b64), dim3(64), 0, st, p);
+    if (p.pair) {
+        if (out_channels == 4) hipLaunchKernelGGL(dec_segments_pair<4>, dim3(b64), dim3(128), 0, st, p);
+        else hipLaunchKernelGGL(dec_segments_pair<3>, dim3(b64), dim3(128), 0, st, p);
+    } else if (out_channels == 4) hipLaunchKernelGGL(dec_segments<4>, dim3(b64), dim3(64), 0, st, p);
     else hipLaunchKernelGGL(dec_segments<3>, dim3(b64), dim3(64), 0, st, p);
     tm->mark(kT_dec_segments, st);
     hipLaunchKernelGGL(dec_prepare_restart, dim3(p.n_images), dim3(64), 0, st, p);
