@@ -223,7 +223,7 @@ def main() -> None:
         slabs = (npx + 1023) // 1024
         traffic, traffic_src = measured_traffic("qoimi::enc_slabs<4, 16, 1, 0, 1>", ((slabs + 3) // 4) * F * 256)
         # the committed PMC run is this workload iff its enc_slabs launch had this grid (same frames, same shape)
-        dec_traffic, dec_traffic_src = measured_traffic("qoimi::dec_segments<4>", -1) if traffic is not None and args.kind == "photo" else (None, None)
+        dec_traffic, dec_traffic_src = measured_traffic("qoimi::dec_segments", -1) if traffic is not None and args.kind == "photo" else (None, None)
         out = {
             "metric": "Mpixels/s encode+decode, 4K RGBA", "value": round(value, 1), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
@@ -242,7 +242,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": "enc_slabs (+ entry-state passes)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": round(per_launch_ms, 4)},
-            "roofline_decode": {"bound": "hbm", "kernel": "dec_segments", "achieved": round(dec_achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline_decode": {"bound": "hbm", "kernel": "dec_segments_pair", "achieved": round(dec_achieved, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(dec_achieved / HBM_PEAK_GBS, 4), "traffic": dec_traffic,
                                 "traffic_source": dec_traffic_src, "algorithmic_bytes_per_launch": int(dec_bytes),
                                 "ms_per_launch": round(seg_ms, 4),
