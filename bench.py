@@ -118,6 +118,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--encode-only", action="store_true", help="diagnostics: time the encoder alone (no decode, no check)")
+    ap.add_argument("--no-others", action="store_true", help="skip the noise / constant / uiflat side figures")
     ap.add_argument("--no-single", action="store_true", help="skip the single-frame figure (profiling runs: keeps every launch batch-sized)")
     args = ap.parse_args()
 
@@ -199,6 +200,31 @@ def main() -> None:
     ok = args.encode_only or bool(torch.equal(decoded.view(F, -1)[:, :npx * 4], pixels.view(F, -1)[:, :npx * 4]))
     dstats = ctx.decode_stats()
 
+    # next to the headline content always report `noise` (5 B/px written: most stream traffic) and
+    # `constant` (longest runs) - same batch, 3 timed steps each, rank 0 of a single-GPU run only
+    other = None
+    if world == 1 and not args.encode_only and not args.no_others:
+        other = {}
+        for kind in ("noise", "constant", "uiflat"):
+            if kind == args.kind:
+                continue
+            ctx.synth_frames(synth.KIND_ID[kind], synth.DEFAULT_SEED, 0, F, w, h, pixels.data_ptr(), pstride, stream)
+            ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+            ctx.encode_status(stream)
+            ksizes = [int(x) for x in lens.cpu().numpy()]
+            ctx.decode_batch(streams.data_ptr(), sstride, ksizes, descs, 4, decoded.data_ptr(), pstride, stream)   # warm-up
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(3):
+                ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+                ctx.decode_batch(streams.data_ptr(), sstride, ksizes, descs, 4, decoded.data_ptr(), pstride, stream)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t2) / 3
+            kok = bool(torch.equal(decoded.view(F, -1)[:, :npx * 4], pixels.view(F, -1)[:, :npx * 4]))
+            other[kind] = {"mpixels_per_s": round(F * npx / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
+                           "stream_bytes_per_px": round(sum(ksizes) / (F * npx), 4), "decode_rounds": ctx.decode_stats()["rounds"],
+                           "verified_bit_exact": kok}
+
     # RCCL: counters only (max elapsed; summed pixels / stream bytes / verified ranks)
     elapsed, (total_px, total_stream_bytes, n_ok) = qdist.reduce_counters(
         elapsed, [float(F * npx * args.steps), float(sum(sizes)) * args.steps, float(ok)], dev)
@@ -250,6 +276,8 @@ def main() -> None:
         }
         if single:
             out["single_frame"] = single
+        if other:
+            out["other_content"] = other
         if args.encode_only:
             out["config"]["workload"] += " [ENCODE ONLY - diagnostic run, not the benchmark]"
         if world == 1 and not args.no_cpu:

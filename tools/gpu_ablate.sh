@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/${1:-abl}; mkdir -p $OUT
 export TMPDIR=/tmp
-B="python bench.py --steps 5 --warmup 1 --no-cpu --encode-only"
+B="python bench.py --steps 5 --warmup 1 --no-cpu --no-others --encode-only"
 for v in "base:" "abl1:QOIMI_ENC_ABLATE=1" "abl2:QOIMI_ENC_ABLATE=2" "abl4:QOIMI_ENC_ABLATE=4" "abl7:QOIMI_ENC_ABLATE=7" "noticket:QOIMI_ENC_TICKET=0" "probe0:QOIMI_ENC_PROBE=0"; do
   name=${v%%:*}; envs=${v#*:}
   echo "== $name"; env $envs timeout 300 $B > $OUT/$name.log 2>&1
@@ -15,7 +15,7 @@ for l in open(sys.argv[1]):
 PY
 done
 for kind in noise uiflat constant; do
-  echo "== kind $kind"; timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu --kind $kind > $OUT/kind_$kind.log 2>&1
+  echo "== kind $kind"; timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu --no-others --kind $kind > $OUT/kind_$kind.log 2>&1
   python - "$OUT/kind_$kind.log" <<'PY'
 import json,sys
 for l in open(sys.argv[1]):
@@ -25,7 +25,7 @@ PY
 done
 if [ "${DO_PMC:-1}" = 1 ]; then
   rocprofv3 -L > $OUT/counters.txt 2>&1
-  P="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu"
+  P="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu --no-others"
   i=0
   for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
              "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA" \

@@ -6,7 +6,7 @@ for rep in 1 2; do
 for v in "${VS[@]}"; do
   name=${v%%:*}; envs=${v#*:}
   for kind in ${KINDS:-photo}; do
-    env $envs timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --no-single --kind $kind ${BENCH_ARGS:-} > $OUT/${name}_${kind}_$rep.log 2>&1
+    env $envs timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --no-others --no-single --kind $kind ${BENCH_ARGS:-} > $OUT/${name}_${kind}_$rep.log 2>&1
     python - $OUT/${name}_${kind}_$rep.log $name <<'PY'
 import json,sys
 ok=False

@@ -3,7 +3,7 @@
 # usage: ARGS="--frames 1 --kind photo" bash tools/gpu_ktrace.sh [outdir-name]
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out/${1:-kt}; mkdir -p $OUT; export TMPDIR=/tmp
 ARGS=${ARGS:---frames 1}
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OLDPWD/$OUT/run -o kt -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu --no-single $ARGS) > $OUT/run.log 2>&1
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OLDPWD/$OUT/run -o kt -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu --no-others --no-single $ARGS) > $OUT/run.log 2>&1
 python - $OUT <<'PY' | tee $OUT/timeline.txt
 import csv,glob,sys
 f=glob.glob(sys.argv[1]+'/run/**/*kernel_trace.csv',recursive=True)[0]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes (separate runs, kernel-trace only) for the bench kernels -> gpurun_out/$1/pmc_summary.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out/${1:-pmc}; mkdir -p $OUT; export TMPDIR=/tmp
-P="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu ${BENCH_ARGS:-}"
+P="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu --no-others ${BENCH_ARGS:-}"
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA" \

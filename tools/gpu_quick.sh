@@ -5,7 +5,7 @@ if [ "${DO_TESTS:-1}" = 1 ]; then
   timeout 900 python -m pytest tests -m gpu -x -q --timeout 600 ${PYTEST_ARGS:-} > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log; tail -15 $OUT/pytest.log
 fi
 for kind in ${KINDS:-photo}; do
-  timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --kind $kind ${BENCH_ARGS:-} > $OUT/bench_$kind.log 2>&1; echo "rc=$?" >> $OUT/bench_$kind.log
+  timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --no-others --kind $kind ${BENCH_ARGS:-} > $OUT/bench_$kind.log 2>&1; echo "rc=$?" >> $OUT/bench_$kind.log
   python - $OUT/bench_$kind.log <<'PY'
 import json,sys
 for l in open(sys.argv[1]):

@@ -14,7 +14,7 @@ for v in "${VS[@]}"; do
   touch qoi_amd/csrc/qoi_decode.hip qoi_amd/csrc/qoi_encode.hip
   make -C qoi_amd/csrc FLAGS="$BASEFLAGS $defs" > $OUT/build_$name.log 2>&1 || { echo "build $name failed"; tail -5 $OUT/build_$name.log; continue; }
   for kind in ${KINDS:-photo}; do
-    timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --no-single --kind $kind ${BENCH_ARGS:-} > $OUT/${name}_$kind.log 2>&1
+    timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --no-others --no-single --kind $kind ${BENCH_ARGS:-} > $OUT/${name}_$kind.log 2>&1
     python - $OUT/${name}_$kind.log $name <<'PY'
 import json,sys
 for l in open(sys.argv[1]):
