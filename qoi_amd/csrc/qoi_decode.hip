@@ -979,6 +979,163 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     }
 }
 
+constexpr uint32_t kPairPeriod = LaneReader::kPeriod;
+constexpr uint32_t kRecCtlMask = 0xC00001F8u;                  // chunk-table bits kept in a record: pixel count, op class
+constexpr uint32_t kRecSymMask = kRecCtlMask | kLutRunBit;     // dec_summarize_pair: + RUN flag; bits 9..14 carry the slot shift
+
+// The reader wavefront of a pair (dec_segments_pair, dec_summarize_pair): one record per chunk and lane.
+//   value word    byte-wise (dr,dg,db,0) of a relative chunk, LUMA's second byte included; r,g,b,a of QOI_OP_RGB / RGBA
+//   control word  bits 3..8 pixels, 30..31 op class (as in the chunk table), 16..21 the slot an INDEX names;
+//                 SYM: bit 15 RUN and bits 9..14 the slot shift of a relative chunk (QOI_COLOR_HASH is linear mod 64)
+// Runs until no lane has chunks left; the period in which that is noticed carries s_flag = 0.
+template <bool SYM>
+__device__ __forceinline__ void pair_reader(const DecParams& p, const DecImage& im, uint32_t ring_addr, uint32_t lut_base, uint32_t rec_base,
+                                            uint32_t* s_flag, uint32_t lane, uint32_t pos, uint32_t end, bool active) {
+    LaneReader R;
+    R.init(ring_addr, p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
+    uint32_t w32, b5; R.peek(pos, w32, b5);
+    uint32_t delta0, info;
+    {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); delta0 = lq[0]; info = lq[256]; }
+    for (uint32_t it = 0;; ++it) {
+        const bool any = lanes_where(active) != 0;
+        if (any) { R.land(); R.issue(pos); }
+        const uint32_t buf = rec_base + (it & 1u) * (kPairPeriod * 2u * 256u);
+#pragma unroll
+        for (uint32_t u = 0; u < kPairPeriod; ++u) {
+            const uint32_t c_info = active ? info : 0u, c_delta0 = active ? delta0 : 0u;
+            const uint32_t npos = pos + lut_len(c_info);                // null chunk: length 0
+            uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
+            const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
+            const uint32_t ndelta0 = lq[0], ninfo = lq[256];
+            // byte-wise delta of a relative chunk (qoi.h:561-572): table part + the second byte of a LUMA chunk
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)c_info, 28, 1);      // all ones for LUMA
+            const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
+            uint32_t v = c_delta0;
+            add_byte0(v, er); add_byte2_from0(v, eb);
+            if (lanes_where(lut_hi(c_info))) {        // some lane stands on QOI_OP_RGB / QOI_OP_RGBA: value word = r,g,b,a
+                const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);
+                v = lut_hi(c_info) ? rgba : v;
+            }
+            uint32_t ctl = (c_info & (SYM ? kRecSymMask : kRecCtlMask)) | ((w32 & 63u) << 16);
+            if (SYM) ctl |= ((lut_slot_shift(c_info) + 3u * er + 7u * eb) & 63u) << 9;
+            lds_u32* rq = (lds_u32*)(buf + u * 512u);
+            rq[0] = v; rq[64] = ctl;
+            pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
+            active = active && pos < end;
+        }
+        if (lane == 0) s_flag[it & 1u] = any ? 1u : 0u;
+        __syncthreads();
+        if (!any) break;
+    }
+}
+
+
+// P3 as a reader / summarizer pair of wavefronts (see dec_segments_pair, which comes later in this file, for the
+// scheme): the reader is the same function, the second wavefront keeps the symbolic tables.  dec_summarize ran at half
+// of the CU's instruction-issue rate with its six wavefronts per CU; a pair needs the tables once: ten per CU.
+template <bool REFINE>
+__global__ __launch_bounds__(128) void dec_summarize_pair(DecParams p) {
+    constexpr uint32_t kRows = REFINE ? 65u : 64u;                  // row 64: kSymParkRow (refinement rounds only)
+    constexpr uint32_t kRecDw = 2u * kPairPeriod * 2u * 64u;
+    __shared__ __attribute__((aligned(4096))) uint32_t s_ring[LaneReader::kSlots * 64];
+    __shared__ uint32_t s_tabc[kRows * 64];
+    __shared__ uint32_t s_rec[kRecDw];
+    __shared__ uint8_t s_tabm[kRows * 64];                          // source / mask codes, see sym_code_expand
+    __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 4];
+    __shared__ LdsLut s_lut;
+    __shared__ uint32_t s_flag[2];
+    const uint32_t lane = lane_id();
+    const bool reader = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
+    build_lut(s_lut, threadIdx.x, 128u);
+    const uint32_t q = blockIdx.x * 64u + lane;
+    bool have = q < p.total_segs;
+    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
+    const DecImage im = p.images[img];
+    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
+    have = have && j >= im.start_seg && j < im.n_active;
+    if (!lanes_where(have)) return;
+    const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
+    const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
+    const uint32_t pos0 = base + (have ? p.entry_phase[q] : 0u);
+    const uint32_t rec_base = lds_addr_of(&s_rec[lane]);
+    if (reader) {
+        pair_reader<true>(p, im, lds_addr_of(&s_ring[lane]), lds_addr_of(&s_lut.delta[0]), rec_base, s_flag, lane, pos0, end, have && pos0 < end);
+        return;
+    }
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    const uint32_t tc_base = lds_addr_of(&s_tabc[lane]);             // slot k at + k*256
+    const uint32_t tm_base = lds_addr_of(&s_tabm[lane]);             // slot k at + k*64
+    // identity: slot k = entry slot k + 0, pixel = entry pixel + 0 (sym_init)
+    for (uint32_t k = 0; k < 64u; ++k) { *(lds_u32*)(tc_base + k * 256u) = 0u; *(lds_u8*)(tm_base + k * 64u) = (uint8_t)k; }
+    uint32_t pc = 0u, ph = 64u;                                       // ph: code of the running pixel (entry pixel, nothing absolute)
+    uint32_t slot, alpha;
+    if (REFINE) {
+        const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
+        uint32_t epx = 0;
+        if (have) {
+            for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {
+                uint32_t v[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) v[k] = ent[k0 + k];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) s_hint[(k0 + k) * 64u + lane] = (uint8_t)(v[k] >> 24);
+            }
+            epx = ent[64];
+            s_hint[64u * 64u + lane] = (uint8_t)(epx >> 24);
+        }
+        slot = hash_px(epx); alpha = epx >> 24;
+    } else {
+        slot = have ? p.slot_in[q] : 0u; alpha = have ? p.alpha_in[q] : 0u;
+    }
+    const uint32_t alpha_in0 = alpha;
+    const uint32_t runmask = (REFINE && j != 0u) ? kLutRunBit : 0u;      // see dec_summarize
+    for (uint32_t it = 0;; ++it) {
+        if (it > 0u) {
+            const uint32_t buf = rec_base + ((it - 1u) & 1u) * (kPairPeriod * 2u * 256u);
+            uint32_t rv[kPairPeriod], rc[kPairPeriod];
+#pragma unroll
+            for (uint32_t u = 0; u < kPairPeriod; ++u) { const lds_u32* rq = (const lds_u32*)(buf + u * 512u); rv[u] = rq[0]; rc[u] = rq[64]; }
+#pragma unroll
+            for (uint32_t u = 0; u < kPairPeriod; ++u) {
+                const uint32_t v = rv[u], ctl = rc[u];
+                const uint32_t idx = (ctl >> 16) & 63u;
+                const uint32_t t_c = *(const lds_u32*)(tc_base + (idx << 8));
+                const uint32_t t_m = *(const lds_u8*)(tm_base + (idx << 6));
+                uint32_t pc_rel = pc;
+                add_byte0(pc_rel, v); add_byte1(pc_rel, v); add_byte2(pc_rel, v);
+                const bool hi = lut_hi(ctl), lo = lut_lo(ctl);
+                const uint32_t s_rel = slot + ((ctl >> 9) & 63u);
+                uint32_t sb = 0, pb = 0, hb = 0;
+                if (lanes_where(hi)) {                    // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
+                    const uint32_t pc_rgb = (pc & 0xFF000000u) | (v & 0x00FFFFFFu);
+                    const uint32_t lrgb = __builtin_amdgcn_udot4(v, 0x00070503u, 0u, false);
+                    sb = lrgb + 11u * (lo ? (v >> 24) : alpha);
+                    pb = lo ? v : pc_rgb; hb = lo ? kSymCodeAbs : (ph < kSymCodeRgb ? ph + kSymCodeRgb : ph);
+                }
+                const uint32_t pa = lo ? t_c : pc_rel, ha = lo ? t_m : ph, sa = lo ? idx : s_rel;
+                pc = hi ? pb : pa;
+                ph = hi ? hb : ha;
+                slot = (hi ? sb : sa) & 63u;
+                // alpha after the chunk: RGBA sets it, INDEX takes the named entry's (hinted where it is still symbolic)
+                const uint32_t th = REFINE ? (uint32_t)s_hint[(t_m < kSymCodeRgb ? t_m : (t_m - kSymCodeRgb) & 0x7Fu) * 64u + lane] : alpha_in0;
+                const uint32_t ta = t_m == kSymCodeAbs ? (t_c >> 24) : th;
+                alpha = hi ? (lo ? (v >> 24) : alpha) : (lo ? ta : alpha);
+                const uint32_t wslot = (ctl & runmask) ? kSymParkRow : slot;
+                *(lds_u32*)(tc_base + (wslot << 8)) = pc;         // index update after every chunk (qoi.h:577)
+                *(lds_u8*)(tm_base + (wslot << 6)) = (uint8_t)ph;
+            }
+        }
+        __syncthreads();
+        if (s_flag[it & 1u] == 0u) break;
+    }
+    if (have) {
+        sym_t* dst = p.summary + (size_t)q * 65u;
+        for (uint32_t k = 0; k < 64u; ++k)
+            dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)sym_code_expand(*(const lds_u8*)(tm_base + k * 64u)) << 32);
+        dst[64] = (sym_t)pc | ((sym_t)sym_code_expand(ph) << 32);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // S3: concrete (px, index[64]) at every segment entry.  lane = table slot; the pixel word is
 // kept redundantly by every lane.
@@ -1278,9 +1435,6 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
 // buffered: the reader fills period i while the decoder works off period i - 1).  A lane that is through with its
 // segment emits null records (no pixels, delta 0), so neither loop masks lanes off.
 // ---------------------------------------------------------------------------------
-constexpr uint32_t kPairPeriod = LaneReader::kPeriod;
-constexpr uint32_t kRecCtlMask = 0xC00001F8u;                  // chunk-table bits kept in a record: pixel count, op class
-
 template <int OCH>
 __global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
     constexpr uint32_t kTabDw = 64u * 64u, kOutDw = LaneWriter<OCH>::kRing * 64u, kRingDw = LaneReader::kSlots * 64u;
@@ -1309,46 +1463,9 @@ __global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
     const uint32_t limit = im.npx;
     const uint32_t rec_base = lds_addr_of(&s_rec[lane]);               // record (buffer b, step u, word w) at + ((b*P + u)*2 + w)*256
 
-    if (reader) {
-        // ------------------------------------------------------------------ wavefront 0: chunk records
-        LaneReader R;
-        uint32_t pos = pos0;
-        R.init(lds_addr_of(&s_ring[lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
-        const uint32_t lut_base = lds_addr_of(&s_lut.delta[0]);
-        bool active = have && pos < end && (have ? p.px_off[q] : 0u) < limit;
-        uint32_t w32, b5; R.peek(pos, w32, b5);
-        uint32_t delta0, info;
-        {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); delta0 = lq[0]; info = lq[256]; }
-        for (uint32_t it = 0;; ++it) {
-            const bool any = lanes_where(active) != 0;
-            if (any) { R.land(); R.issue(pos); }
-            const uint32_t buf = rec_base + (it & 1u) * (kPairPeriod * 2u * 256u);
-#pragma unroll
-            for (uint32_t u = 0; u < kPairPeriod; ++u) {
-                const uint32_t c_info = active ? info : 0u, c_delta0 = active ? delta0 : 0u;
-                const uint32_t npos = pos + lut_len(c_info);                // null chunk: length 0
-                uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
-                const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
-                const uint32_t ndelta0 = lq[0], ninfo = lq[256];
-                // byte-wise delta of a relative chunk (qoi.h:561-572): table part + the second byte of a LUMA chunk
-                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)c_info, 28, 1);      // all ones for LUMA
-                const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
-                uint32_t v = c_delta0;
-                add_byte0(v, er); add_byte2_from0(v, eb);
-                if (lanes_where(lut_hi(c_info))) {        // some lane stands on QOI_OP_RGB / QOI_OP_RGBA: value word = r,g,b,a
-                    const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);
-                    v = lut_hi(c_info) ? rgba : v;
-                }
-                const uint32_t ctl = (c_info & kRecCtlMask) | ((w32 & 63u) << 16);
-                lds_u32* rq = (lds_u32*)(buf + u * 512u);
-                rq[0] = v; rq[64] = ctl;
-                pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
-                active = active && pos < end;
-            }
-            if (lane == 0) s_flag[it & 1u] = any ? 1u : 0u;
-            __syncthreads();
-            if (!any) break;
-        }
+    if (reader) {                                                       // wavefront 0: chunk records
+        pair_reader<false>(p, im, lds_addr_of(&s_ring[lane]), lds_addr_of(&s_lut.delta[0]), rec_base, s_flag, lane, pos0, end,
+                           have && pos0 < end && (have ? p.px_off[q] : 0u) < limit);
         return;
     }
 
@@ -1506,7 +1623,8 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     const uint32_t b256 = (p.total_segs + 255u) / 256u, b64 = (p.total_segs + 63u) / 64u;
     tm->mark(kT_begin, st);
     if (refine) {
-        hipLaunchKernelGGL(dec_summarize<true>, dim3(b64), dim3(64), 0, st, p);
+        if (p.pair & 2u) hipLaunchKernelGGL(dec_summarize_pair<true>, dim3(b64), dim3(128), 0, st, p);
+        else hipLaunchKernelGGL(dec_summarize<true>, dim3(b64), dim3(64), 0, st, p);
         tm->mark(kT_dec_summarize, st);
     } else {
     if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_heads_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
@@ -1516,14 +1634,15 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     hipLaunchKernelGGL(dec_chain_slots_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
     hipLaunchKernelGGL(dec_chain_slots_l3, dim3(p.total_grps), dim3(64), 0, st, p);
     tm->mark(kT_dec_chain_slots, st);
-    hipLaunchKernelGGL(dec_summarize<false>, dim3(b64), dim3(64), 0, st, p);
+    if (p.pair & 2u) hipLaunchKernelGGL(dec_summarize_pair<false>, dim3(b64), dim3(128), 0, st, p);
+    else hipLaunchKernelGGL(dec_summarize<false>, dim3(b64), dim3(64), 0, st, p);
     tm->mark(kT_dec_summarize, st);
     }
     hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
     hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
     hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);
     tm->mark(kT_dec_chain_state, st);
-    if (p.pair) {
+    if (p.pair & 1u) {
         if (out_channels == 4) hipLaunchKernelGGL(dec_segments_pair<4>, dim3(b64), dim3(128), 0, st, p);
         else hipLaunchKernelGGL(dec_segments_pair<3>, dim3(b64), dim3(128), 0, st, p);
     } else if (out_channels == 4) hipLaunchKernelGGL(dec_segments<4>, dim3(b64), dim3(64), 0, st, p);

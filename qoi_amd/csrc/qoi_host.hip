@@ -80,7 +80,7 @@ struct qoimi_ctx {
     int enc_lookback = 0;               // 1: single-pass decoupled look-back instead of scratch + compaction
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
-    int dec_pair = 1;                   // 0: one wavefront per 64 segments in P4 instead of a reader/decoder pair
+    int dec_pair = 3;                   // bit 0: P4, bit 1: P3 run as reader / worker wavefront pairs; 0: one wavefront per 64 segments
     KernelTimer timer;                  // optional per-kernel HIP-event timing
     double prof_ms[kT_count] = {0};     // accumulated kernel milliseconds since profiling was (re)enabled
     long long prof_calls[kT_count] = {0};
@@ -324,7 +324,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     memset(&p, 0, sizeof p);
     p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
-    p.pair = c->dec_pair ? 1u : 0u;
+    p.pair = (uint32_t)c->dec_pair & 3u;
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
     const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
     {   // P1/P2 on 128-byte pieces when a segment is 1, 8, 16, 32 or 64 of them

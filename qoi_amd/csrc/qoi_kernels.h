@@ -90,7 +90,7 @@ struct DecParams {
     DecImage* images;      // device array [n_images]
     uint32_t n_images, total_segs, total_grps, seg_bytes;
     uint32_t fine_per_seg, fine_shift;   // 128-byte pieces per segment for P1/P2 (8..64, power of two), 0: lane per segment
-    uint32_t pair;                       // 1: P3/P4 as reader/decoder wavefront pairs (dec_segments_pair)
+    uint32_t pair;                       // bit 0: P4, bit 1: P3 as reader / worker wavefront pairs (dec_segments_pair, dec_summarize_pair)
     uint16_t* fine_exit;       // P1 fine: exit-phase map of every piece [total_segs * fine_per_seg]
     uint32_t* fine_tail;       // P1 fine: packed slot transfer of the piece from the chains' meeting point on
     uint8_t*  fine_moff;       // P1 fine: offset of the meeting point in the piece, 255: the chains never met
