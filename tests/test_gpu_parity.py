@@ -283,3 +283,34 @@ def test_decode_batch_mixed_shapes(api, ctx, oracle):
             assert np.array_equal(got, want), (och, i, shapes[i] if i < len(shapes) else "size22")
             if want.size < pstride:
                 assert int(out[i * pstride + want.size]) == 0xCD, "wrote past the image"
+
+
+def test_decode_batch_many_small_images(api, ctx, oracle):
+    """300 images of 1..40 pixels a side in ONE decode batch (every per-image chain has a single short group; image
+    tables, group bases and the per-image kernels see hundreds of entries), all content classes, both output forms."""
+    import torch
+    from qoi_amd import synth
+    rng = np.random.default_rng(5)
+    streams, descs = [], []
+    for i in range(300):
+        w, h = int(rng.integers(1, 41)), int(rng.integers(1, 41))
+        kind = synth.KINDS[i % len(synth.KINDS)]
+        px = synth.frame_rgba(kind, w, h, 1000 + i)
+        if i % 7 == 3:
+            px = px.copy(); px[..., 3] = rng.integers(0, 256, (h, w), dtype=np.uint8)      # busy alpha: RGBA chunks, INDEX alpha changes
+        streams.append(oracle.encode(np.ascontiguousarray(px), w, h, 4)); descs.append(api.QoiDesc(w, h, 4, 0))
+    sstride = (max(len(s) for s in streams) + 8 + 255) // 256 * 256
+    buf = torch.zeros(len(streams) * sstride, dtype=torch.uint8, device="cuda")
+    host = np.zeros(len(streams) * sstride, dtype=np.uint8)
+    for i, s in enumerate(streams):
+        host[i * sstride:i * sstride + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    buf.copy_(torch.from_numpy(host))
+    for och in (4, 3):
+        pstride = (40 * 40 * och + 255) // 256 * 256
+        out = torch.full((len(streams) * pstride,), 0xCD, dtype=torch.uint8, device="cuda")
+        ctx.decode_batch(buf.data_ptr(), sstride, [len(s) for s in streams], descs, och, out.data_ptr(), pstride)
+        got_all = out.cpu().numpy()
+        for i, s in enumerate(streams):
+            want, _ = oracle.decode(s, och)
+            assert np.array_equal(got_all[i * pstride:i * pstride + want.size], want), (och, i, descs[i].width, descs[i].height)
+            assert got_all[i * pstride + want.size] == 0xCD or want.size == pstride, "wrote past the image"
