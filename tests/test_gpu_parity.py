@@ -314,3 +314,28 @@ def test_decode_batch_many_small_images(api, ctx, oracle):
             want, _ = oracle.decode(s, och)
             assert np.array_equal(got_all[i * pstride:i * pstride + want.size], want), (och, i, descs[i].width, descs[i].height)
             assert got_all[i * pstride + want.size] == 0xCD or want.size == pstride, "wrote past the image"
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (7, 3), (63, 65), (1024, 1), (1, 1025), (257, 129)])
+def test_encode_batch_many_small_images(api, ctx, oracle, shape):
+    """Batches of 96 small frames of one shape, every content class in turn plus busy-alpha frames: every stream
+    byte-identical to the reference's (slabs shorter than a wavefront's 1024 pixels, images of a single slab)."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    w, h = shape
+    n = 96
+    b = DeviceBatch(ctx, w, h, 4, n)
+    rng = np.random.default_rng(w * 131 + h)
+    frames = []
+    for i in range(n):
+        px = synth.frame_rgba(synth.KINDS[i % len(synth.KINDS)], w, h, 2000 + i).copy()
+        if i % 5 == 4:
+            px[..., 3] = rng.integers(0, 4, (h, w), dtype=np.uint8) * 85
+        frames.append(np.ascontiguousarray(px))
+        b.pixels[i * b.pixel_stride:i * b.pixel_stride + w * h * 4] = torch.from_numpy(frames[-1].reshape(-1)).cuda()
+    lens = b.encode()
+    for i in range(n):
+        want = oracle.encode(frames[i], w, h, 4)
+        assert int(lens[i]) == len(want), (shape, i)
+        assert b.stream_bytes(i, len(want)) == want, (shape, i)
