@@ -106,7 +106,30 @@ def cpu_baseline(kind: str, w: int, h: int, budget_s: float) -> dict:
             "encode_mpps": round(enc_mpps, 2), "decode_mpps": round(dec_mpps, 2)}
 
 
+def cpu_baseline_all_cores(kind: str, w: int, h: int, budget_s: float) -> dict:
+    """The same measurement on every host core at once ("(ii) one process per host core, all cores,
+    core count printed"): one worker process per core, each encoding + decoding its own frames for `budget_s`;
+    the rates add up.  Workers are fresh interpreters (no CUDA state is forked)."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", kind, str(w), str(h), str(budget_s)]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
+    total = 0.0
+    done = 0
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=budget_s * 6 + 120)
+            total += float(json.loads(out.strip().splitlines()[-1])["value"]); done += 1
+        except Exception:
+            pr.kill()
+    return {"value": round(total, 1), "unit": "Mpixels/s", "cores": done, "kind": "reference",
+            "sample": f"{done} worker processes x {budget_s:.0f} s of {w}x{h} {kind} frames, encode+decode, malloc/free timed"}
+
+
 def main() -> None:
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":            # one core's share of cpu_baseline_all_cores
+        print(json.dumps(cpu_baseline(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -282,6 +305,7 @@ def main() -> None:
             out["config"]["workload"] += " [ENCODE ONLY - diagnostic run, not the benchmark]"
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.kind, w, h, args.cpu_seconds)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.kind, w, h, min(args.cpu_seconds, 6.0))
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
