@@ -979,7 +979,12 @@ __global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
     }
 }
 
-constexpr uint32_t kPairPeriod = LaneReader::kPeriod;
+// Reader ring and period of the paired kernels.  dec_segments_pair runs as fast with four pairs per CU as with five
+// (measured by padding its LDS: 2 / 3 / 4 / 5 pairs -> 2.82 / 2.14 / 1.70 / 1.80 ms), so the LDS of its fifth pair is
+// better spent on a period of 8 steps (32-dword stream ring, 8 KiB of records): half as many barriers, refills and
+// drains per chunk, -12 %.  dec_summarize_pair does use its fifth pair: it keeps the period of 4.
+typedef LaneReaderT<32, 4, 8> PairReader8;
+typedef LaneReader PairReader4;
 constexpr uint32_t kRecCtlMask = 0xC00001F8u;                  // chunk-table bits kept in a record: pixel count, op class
 constexpr uint32_t kRecSymMask = kRecCtlMask | kLutRunBit;     // dec_summarize_pair: + RUN flag; bits 9..14 carry the slot shift
 
@@ -988,10 +993,11 @@ constexpr uint32_t kRecSymMask = kRecCtlMask | kLutRunBit;     // dec_summarize_
 //   control word  bits 3..8 pixels, 30..31 op class (as in the chunk table), 16..21 the slot an INDEX names;
 //                 SYM: bit 15 RUN and bits 9..14 the slot shift of a relative chunk (QOI_COLOR_HASH is linear mod 64)
 // Runs until no lane has chunks left; the period in which that is noticed carries s_flag = 0.
-template <bool SYM>
+template <bool SYM, class READER>
 __device__ __forceinline__ void pair_reader(const DecParams& p, const DecImage& im, uint32_t ring_addr, uint32_t lut_base, uint32_t rec_base,
                                             uint32_t* s_flag, uint32_t lane, uint32_t pos, uint32_t end, bool active) {
-    LaneReader R;
+    constexpr uint32_t kPairPeriod = READER::kPeriod;
+    READER R;
     R.init(ring_addr, p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
     uint32_t w32, b5; R.peek(pos, w32, b5);
     uint32_t delta0, info;
@@ -1036,8 +1042,10 @@ __device__ __forceinline__ void pair_reader(const DecParams& p, const DecImage& 
 template <bool REFINE>
 __global__ __launch_bounds__(128) void dec_summarize_pair(DecParams p) {
     constexpr uint32_t kRows = REFINE ? 65u : 64u;                  // row 64: kSymParkRow (refinement rounds only)
+    typedef PairReader4 Reader;
+    constexpr uint32_t kPairPeriod = Reader::kPeriod;
     constexpr uint32_t kRecDw = 2u * kPairPeriod * 2u * 64u;
-    __shared__ __attribute__((aligned(4096))) uint32_t s_ring[LaneReader::kSlots * 64];
+    __shared__ __attribute__((aligned(4096))) uint32_t s_ring[Reader::kSlots * 64];
     __shared__ uint32_t s_tabc[kRows * 64];
     __shared__ uint32_t s_rec[kRecDw];
     __shared__ uint8_t s_tabm[kRows * 64];                          // source / mask codes, see sym_code_expand
@@ -1059,7 +1067,7 @@ __global__ __launch_bounds__(128) void dec_summarize_pair(DecParams p) {
     const uint32_t pos0 = base + (have ? p.entry_phase[q] : 0u);
     const uint32_t rec_base = lds_addr_of(&s_rec[lane]);
     if (reader) {
-        pair_reader<true>(p, im, lds_addr_of(&s_ring[lane]), lds_addr_of(&s_lut.delta[0]), rec_base, s_flag, lane, pos0, end, have && pos0 < end);
+        pair_reader<true, Reader>(p, im, lds_addr_of(&s_ring[lane]), lds_addr_of(&s_lut.delta[0]), rec_base, s_flag, lane, pos0, end, have && pos0 < end);
         return;
     }
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -1431,13 +1439,15 @@ __global__ __launch_bounds__(64) void dec_segments(DecParams p) {
 //                              of an RGB / RGBA chunk) and control word (pixel count, op class, slot an INDEX names);
 //   wavefront 1, the decoder:  owns the colour tables and the pixel ring; turns records into pixels.
 // The two run on different SIMDs, each retires about half the instructions, and a pair needs the tables once: ten
-// wavefronts per CU instead of six.  They meet at one barrier per period of kPairPeriod steps (records are double
+// wavefronts per CU instead of six (eight with the longer period, see PairReader8).  They meet at one barrier per period (records are double
 // buffered: the reader fills period i while the decoder works off period i - 1).  A lane that is through with its
 // segment emits null records (no pixels, delta 0), so neither loop masks lanes off.
 // ---------------------------------------------------------------------------------
 template <int OCH>
 __global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
-    constexpr uint32_t kTabDw = 64u * 64u, kOutDw = LaneWriter<OCH>::kRing * 64u, kRingDw = LaneReader::kSlots * 64u;
+    typedef PairReader8 Reader;
+    constexpr uint32_t kPairPeriod = Reader::kPeriod;
+    constexpr uint32_t kTabDw = 64u * 64u, kOutDw = LaneWriter<OCH>::kRing * 64u, kRingDw = Reader::kSlots * 64u;
     constexpr uint32_t kRecDw = 2u * kPairPeriod * 2u * 64u;          // two buffers x steps x two words x lanes
     static_assert(kOutDw * 4u == 4096u, "pixel ring is one 4 KiB block");
     __shared__ __attribute__((aligned(16384))) uint32_t s_mem[kTabDw + kOutDw + kRingDw + kRecDw + sizeof(LdsLut) / 4u + 2u];
@@ -1464,7 +1474,7 @@ __global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
     const uint32_t rec_base = lds_addr_of(&s_rec[lane]);               // record (buffer b, step u, word w) at + ((b*P + u)*2 + w)*256
 
     if (reader) {                                                       // wavefront 0: chunk records
-        pair_reader<false>(p, im, lds_addr_of(&s_ring[lane]), lds_addr_of(&s_lut.delta[0]), rec_base, s_flag, lane, pos0, end,
+        pair_reader<false, Reader>(p, im, lds_addr_of(&s_ring[lane]), lds_addr_of(&s_lut.delta[0]), rec_base, s_flag, lane, pos0, end,
                            have && pos0 < end && (have ? p.px_off[q] : 0u) < limit);
         return;
     }
@@ -1499,6 +1509,7 @@ __global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
                 for (uint32_t u = 0; u < kPairPeriod; ++u) { const lds_u32* rq = (const lds_u32*)(buf + u * 512u); rv[u] = rq[0]; rc[u] = rq[64]; }
 #pragma unroll
                 for (uint32_t u = 0; u < kPairPeriod; ++u) {
+                    if (u != 0u && (u & 3u) == 0u) W.drain();            // the 16-pixel ring takes four steps' worth (see put2n)
                     const uint32_t v = rv[u], ctl = rc[u];
                     const uint32_t t = *(const lds_u32*)(tab_base + ((ctl >> 8) & 0x3F00u));     // slot an INDEX names
                     uint32_t rel = px;
@@ -1524,7 +1535,7 @@ __global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
                     if (rem) {                                                 // QOI_OP_RUN of three or more (qoi.h:573-575)
                         if (rem >= kLongRun) W.splat(px, rem);
                         while (rem) { W.put(px); --rem; }
-                        if (W.ppos - W.fpos > LaneWriter<OCH>::kRing - 2u * kPairPeriod) W.drain();
+                        if (W.ppos - W.fpos > LaneWriter<OCH>::kRing - 2u * 4u) W.drain();
                     }
                 }
             }
