@@ -429,18 +429,24 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     SlotFast st; slotf_init(st);
     // one chunk per step; the next chunk's bytes and its table word are asked for before this chunk's arithmetic
     // No lane is masked off inside the loop: a lane that is through with its piece runs a null chunk (length 0, no
-    // pixels, slot shift 0) - with the exec mask untouched the loop has no merge copies.
-    uint32_t w32, b5; R.peek(min(m, end), w32, b5);
-    uint32_t info = s_lut.info[w32 & 0xFFu];
-    while (lanes_where(active)) {
-        const uint32_t c_info = active ? info : 0u;
-        const uint32_t nm = m + (active ? len_of(w32 & 0xFFu) : 0u);       // arithmetic: no LDS word on the cursor's chain
-        uint32_t nw32, nb5; R.peek(nm, nw32, nb5);                         // stays inside the buffer: nm <= end + 4
-        const uint32_t ninfo = s_lut.info[nw32 & 0xFFu];
+    // pixels, slot shift 0) - with the exec mask untouched the loop has no merge copies; two steps per iteration with
+    // the chunk registers swapping roles, so that the next chunk's words need no copy at the loop's end either.
+    const uint32_t end_b = active ? end : 0u;                              // lanes that take no part: m < 0 never holds
+    uint32_t wa, ba; R.peek(min(m, end), wa, ba);
+    uint32_t ia = s_lut.info[wa & 0xFFu];
+    auto step = [&](uint32_t w32, uint32_t b5, uint32_t info, uint32_t& nw32, uint32_t& nb5, uint32_t& ninfo) {
+        const bool on = m < end_b;
+        const uint32_t c_info = on ? info : 0u;
+        m += on ? len_of(w32 & 0xFFu) : 0u;                                // arithmetic: no LDS word on the cursor's chain
+        R.peek(m, nw32, nb5);                                              // stays inside the buffer: m <= end + 4
+        ninfo = s_lut.info[nw32 & 0xFFu];
         add += lut_pixels(c_info);
         slotf_step_split(st, w32, b5, c_info, lanes_where(lut_hi(c_info)) != 0);
-        m = nm; w32 = nw32; b5 = nb5; info = ninfo;
-        active = active && m < end;
+    };
+    while (lanes_where(m < end_b)) {
+        uint32_t wb, bb, ib;
+        step(wa, ba, ia, wb, bb, ib);
+        step(wb, bb, ib, wa, ba, ia);
     }
     if (merged) {
         s.p0 = s.p1 = s.p2 = s.p3 = s.p4 = m;
