@@ -437,7 +437,8 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     auto step = [&](uint32_t w32, uint32_t b5, uint32_t info, uint32_t& nw32, uint32_t& nb5, uint32_t& ninfo) {
         const bool on = m < end_b;
         const uint32_t c_info = on ? info : 0u;
-        m += on ? len_of(w32 & 0xFFu) : 0u;                                // arithmetic: no LDS word on the cursor's chain
+        m += lut_len(c_info);                                              // this kernel is VALU-bound with twelve wavefronts per CU:
+                                                                           // the table's length (2 ops) beats the arithmetic one (7)
         R.peek(m, nw32, nb5);                                              // stays inside the buffer: m <= end + 4
         ninfo = s_lut.info[nw32 & 0xFFu];
         add += lut_pixels(c_info);
