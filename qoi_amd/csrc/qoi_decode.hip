@@ -386,6 +386,15 @@ struct FineBuf {
         w32 = __builtin_amdgcn_alignbit(d1, d0, sh);
         b5 = (d1 >> sh) & 0xFFu;
     }
+    // the same without extracting byte 4 (needed by QOI_OP_RGBA only): hi = second dword, sh8 = 8 x the byte position
+    __device__ __forceinline__ void peek_raw(uint32_t pos, uint32_t& w32, uint32_t& hi, uint32_t& sh8) const {
+        const uint32_t rp = pos - aoff;
+        const lds_u32* q = (const lds_u32*)(buf + (rp >> 2) * 256u);
+        const uint32_t d0 = q[0];
+        hi = q[64];
+        sh8 = rp * 8u;
+        w32 = __builtin_amdgcn_alignbit(hi, d0, sh8);                          // alignbit takes the shift modulo 32
+    }
 };
 
 __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
@@ -432,22 +441,24 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     // pixels, slot shift 0) - with the exec mask untouched the loop has no merge copies; two steps per iteration with
     // the chunk registers swapping roles, so that the next chunk's words need no copy at the loop's end either.
     const uint32_t end_b = active ? end : 0u;                              // lanes that take no part: m < 0 never holds
-    uint32_t wa, ba; R.peek(min(m, end), wa, ba);
+    uint32_t wa, ha, sa; R.peek_raw(min(m, end), wa, ha, sa);
     uint32_t ia = s_lut.info[wa & 0xFFu];
-    auto step = [&](uint32_t w32, uint32_t b5, uint32_t info, uint32_t& nw32, uint32_t& nb5, uint32_t& ninfo) {
+    auto step = [&](uint32_t w32, uint32_t hiw, uint32_t sh8, uint32_t info, uint32_t& nw32, uint32_t& nhi, uint32_t& nsh, uint32_t& ninfo) {
         const bool on = m < end_b;
         const uint32_t c_info = on ? info : 0u;
         m += lut_len(c_info);                                              // this kernel is VALU-bound with twelve wavefronts per CU:
                                                                            // the table's length (2 ops) beats the arithmetic one (7)
-        R.peek(m, nw32, nb5);                                              // stays inside the buffer: m <= end + 4
+        R.peek_raw(m, nw32, nhi, nsh);                                     // stays inside the buffer: m <= end + 4
         ninfo = s_lut.info[nw32 & 0xFFu];
         add += lut_pixels(c_info);
-        slotf_step_split(st, w32, b5, c_info, lanes_where(lut_hi(c_info)) != 0);
+        const bool any_hi = lanes_where(lut_hi(c_info)) != 0;
+        const uint32_t b5 = any_hi ? (hiw >> (sh8 & 24u)) & 0xFFu : 0u;   // byte 4 of the chunk: QOI_OP_RGBA's alpha only
+        slotf_step_split(st, w32, b5, c_info, any_hi);
     };
     while (lanes_where(m < end_b)) {
-        uint32_t wb, bb, ib;
-        step(wa, ba, ia, wb, bb, ib);
-        step(wb, bb, ib, wa, ba, ia);
+        uint32_t wb, hb, sb, ib;
+        step(wa, ha, sa, ia, wb, hb, sb, ib);
+        step(wb, hb, sb, ib, wa, ha, sa, ia);
     }
     if (merged) {
         s.p0 = s.p1 = s.p2 = s.p3 = s.p4 = m;
