@@ -71,7 +71,10 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_
 // unread): a period consumes <= 5*PERIOD_ bytes (+5 for the one-chunk look-ahead of the callers), a refill
 // tops the ring up in 16-byte pieces; with RD_=32, NP_=4, PERIOD_=8: o >= 17 after every refill, so the 8 bytes
 // a peek reads are always there.
-template <int RD_, int NP_, int PERIOD_, int LOOK_ = 8>
+// LINE_: the ring is topped up only by whole, 64-byte aligned lines (NP_ x 16 bytes issued together, or nothing).  With many
+// long-lived lanes per CU (dec_transcode: 512) a lane's 16-byte loads come too far apart for its cache line to still be in the
+// L2 the next time (32 K lane streams per XCD on 32 K L2 lines): every line was fetched from HBM several times.
+template <int RD_, int NP_, int PERIOD_, int LOOK_ = 8, bool LINE_ = false>
 struct LaneReaderT {
     static constexpr uint32_t RD = RD_;
     static constexpr uint32_t kSlots = RD + 1;
@@ -102,11 +105,19 @@ struct LaneReaderT {
     __device__ __forceinline__ void init(uint32_t ring_addr, const uint8_t* stream, uint32_t pos0, uint32_t size) {
         ring = ring_addr;
         const uint8_t* p = stream + pos0;
-        abase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)15);
+        abase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)(LINE_ ? 16 * NP_ - 1 : 15));
         alast = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(stream + size - 1u) & ~(uintptr_t)15);
         aoff = pos0 - (uint32_t)(p - abase);
+        if (LINE_) {                                                  // loads first, LDS writes after: RD / 4 loads in flight
+            uint4 v[RD / 4u];
+#pragma unroll
+            for (uint32_t r = 0; r < RD / 4u; ++r) v[r] = load16(abase + 16u * r);
+#pragma unroll
+            for (uint32_t r = 0; r < RD / 4u; ++r) put4(4u * r, v[r]);
+        } else {
 #pragma unroll
         for (uint32_t r = 0; r < RD / 4u; ++r) put4(4u * r, load16(abase + 16u * r));
+        }
         wr = RD; npend = 0;
     }
     // chunk bytes 0..3 (w32) and byte 4 (b5) of the chunk at stream position pos
@@ -130,7 +141,7 @@ struct LaneReaderT {
     }
     __device__ __forceinline__ void issue(uint32_t pos) {
         const uint32_t space = RD - (wr - ((pos - aoff) >> 2));
-        npend = min((uint32_t)NP_, space >> 2);
+        npend = LINE_ ? ((space >> 2) >= (uint32_t)NP_ ? (uint32_t)NP_ : 0u) : min((uint32_t)NP_, space >> 2);
 #pragma unroll
         for (int i = 0; i < NP_; ++i) if ((uint32_t)i < npend) pend[i] = load16(abase + (size_t)wr * 4u + 16u * i);
     }
@@ -194,10 +205,17 @@ __device__ __forceinline__ uint32_t apply_relative(uint32_t px, uint32_t w32, ui
 #ifndef QOIMI_DRAIN_GROUP
 #define QOIMI_DRAIN_GROUP 4
 #endif
-template <int OCH>
+// RING_: pixels the LDS ring of a lane holds (power of two).  GROUP_: pixels written together - an aligned group leaves as
+// GROUP_/4 back-to-back 16-byte stores of the same lane.  What the memory side makes of a lane's output stream depends on
+// how close in time the pieces of a cache line arrive (tools/ubench/store_patterns.hip, MI355X, 9 GB in 64-lane wavefronts
+// with 6.9 KB between the lanes' streams): 16 bytes per drain, the pieces of a line several hundred cycles apart - 1.0-1.4
+// TB/s (the L2 no longer merges them); 64 bytes per lane in one burst - 3.6 TB/s; 4 lanes x 16 bytes to one line - the same.
+// dec_segments_rec therefore drains groups of 16 pixels from a ring of 32 (dec_segments / dec_segments_pair: 4 from 16).
+template <int OCH, uint32_t RING_ = 16, uint32_t GROUP_ = QOIMI_DRAIN_GROUP>
 struct LaneWriter {
-    static constexpr uint32_t kRing = 16;
-    uint32_t row;         // LDS byte address of row[0][lane]; pixel i at row + (i & 15)*256
+    static constexpr uint32_t kRing = RING_;
+    static_assert((RING_ & (RING_ - 1u)) == 0u && GROUP_ % 4u == 0u && GROUP_ < RING_, "ring / group sizes");
+    uint32_t row;         // LDS byte address of row[0][lane]; pixel i at row + (i & (kRing-1))*256
     uint8_t* out;
     uint32_t ppos;        // next pixel index
     uint32_t fpos;        // first pixel still in the ring
@@ -210,11 +228,8 @@ struct LaneWriter {
         if (OCH == 4) reinterpret_cast<uint32_t*>(out)[i] = px;
         else { uint8_t* d = out + (size_t)i * 3u; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
     }
-    // write out every complete aligned group of kGroup pixels; a leading partial group (segment head) pixel by
-    // pixel.  kGroup = 4: one 16-byte store per group.  (8-pixel groups - a whole 32-byte sector per lane at a
-    // time - halve the partial writes the memory side sees (WRITE_SIZE is 2.4 x the pixel bytes with 4) but the
-    // kernel is not bound by its stores: it runs as fast with the stores compiled out, r01 session v1.)
-    static constexpr uint32_t kGroup = QOIMI_DRAIN_GROUP;
+    // write out every complete aligned group of kGroup pixels; a leading partial group (segment head) pixel by pixel
+    static constexpr uint32_t kGroup = GROUP_;
     __device__ __forceinline__ void store4(uint32_t i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
 #ifdef QOIMI_ABL_NOSTORE
         if (v0 == 0x12345678u && v1 == v2 + v3)
@@ -228,9 +243,9 @@ struct LaneWriter {
         }
     }
     __device__ __forceinline__ void drain() {
-        while ((fpos & 3u) != 0u && fpos < ppos) { store_one(fpos, at(fpos)); ++fpos; }
-        if (kGroup == 8u && (fpos & 4u) != 0u && fpos + 4u <= ppos) {          // segment head / after a splat
-            store4(fpos, at(fpos), at(fpos + 1u), at(fpos + 2u), at(fpos + 3u)); fpos += 4u;
+        while ((fpos & (kGroup - 1u)) != 0u && fpos < ppos) {             // segment head / after a splat: up to the next group boundary
+            if (kGroup > 4u && (fpos & 3u) == 0u && fpos + 4u <= ppos) { store4(fpos, at(fpos), at(fpos + 1u), at(fpos + 2u), at(fpos + 3u)); fpos += 4u; }
+            else { store_one(fpos, at(fpos)); ++fpos; }
         }
         while (fpos + kGroup <= ppos) {
             uint32_t v[kGroup];
@@ -278,9 +293,12 @@ struct LaneWriter {
         }
         fpos = ppos;
     }
-    __device__ __forceinline__ void finish() {                            // everything left, tail group pixel by pixel
+    __device__ __forceinline__ void finish() {                            // everything left, groups of 4 first, the rest pixel by pixel
         drain();
-        while (fpos < ppos) { store_one(fpos, at(fpos)); ++fpos; }
+        while (fpos < ppos) {
+            if ((fpos & 3u) == 0u && fpos + 4u <= ppos) { store4(fpos, at(fpos), at(fpos + 1u), at(fpos + 2u), at(fpos + 3u)); fpos += 4u; }
+            else { store_one(fpos, at(fpos)); ++fpos; }
+        }
     }
 };
 
@@ -397,6 +415,10 @@ struct FineBuf {
     }
 };
 
+// TAIL: the walk behind the chains' meeting point also accumulates the speculative slot transfer (P2) of that tail for
+// dec_slot_heads_fine.  With chunk records (DecParams::use_rec) the transcoder walks every chunk from its true entry
+// position anyway and leaves the whole transfer: the parse then carries chunk lengths and pixel counts only.
+template <bool TAIL>
 __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     __shared__ uint32_t s_buf[4][kFineDwords * 64];
     __shared__ uint32_t s_rec[4][64][6];          // per lane: exit map, pixels[5]
@@ -451,9 +473,11 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
         R.peek_raw(m, nw32, nhi, nsh);                                     // stays inside the buffer: m <= end + 4
         ninfo = s_lut.info[nw32 & 0xFFu];
         add += lut_pixels(c_info);
-        const bool any_hi = lanes_where(lut_hi(c_info)) != 0;
-        const uint32_t b5 = any_hi ? (hiw >> (sh8 & 24u)) & 0xFFu : 0u;   // byte 4 of the chunk: QOI_OP_RGBA's alpha only
-        slotf_step_split(st, w32, b5, c_info, any_hi);
+        if (TAIL) {
+            const bool any_hi = lanes_where(lut_hi(c_info)) != 0;
+            const uint32_t b5 = any_hi ? (hiw >> (sh8 & 24u)) & 0xFFu : 0u;   // byte 4 of the chunk: QOI_OP_RGBA's alpha only
+            slotf_step_split(st, w32, b5, c_info, any_hi);
+        }
     };
     while (lanes_where(m < end_b)) {
         uint32_t wb, hb, sb, ib;
@@ -467,9 +491,11 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     ParseRec r; parse_finish(s, base, kFineBytes, r);
     if (have) {
         p.fine_exit[F] = (uint16_t)r.exit_phase;
-        SlotRec tr; slotf_finish(st, tr);
-        p.fine_tail[F] = slot_pack(tr);
-        p.fine_moff[F] = (uint8_t)moff;
+        if (TAIL) {
+            SlotRec tr; slotf_finish(st, tr);
+            p.fine_tail[F] = slot_pack(tr);
+            p.fine_moff[F] = (uint8_t)moff;
+        }
     }
     if (G == 1u) { if (have) p.parse[q] = r; return; }     // 128-byte segments: the piece is the segment
     // compose the G (8..64) pieces of every segment: lane `sub` = e < 5 walks the pieces for entry phase e
@@ -1587,6 +1613,478 @@ __global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
     }
 }
 
+// =====================================================================================
+// Chunk records (qoi_decode_core.h "Chunk RECORDS"): dec_transcode writes them once, dec_summarize_rec (P3) and
+// dec_segments_rec (P4) read them.
+//
+// Why: profiles/r01_s8_sq_counters.txt - the two table-bound passes ran at half of the CU's issue rate, each as a
+// READER wavefront (byte cursor, chunk table, LUMA expansion: ~45 instructions per chunk step) beside the wavefront that
+// owns the colour tables, and the 16 KiB of tables per 64 segments (+ stream ring + record buffers: 39 KiB per pair) held
+// a CU to four such pairs.  The reader's work does not depend on pixel state and was done twice (P3 and P4), after P1
+// and P2 had walked the same chunks already.  Now the walk that P2 needs anyway (from every segment's true entry
+// position) leaves one 32-bit record per chunk; P3 / P4 are single wavefronts of 20 KiB (tables + pixel ring / source
+// codes): EIGHT per CU, each stepping through ~35-40 instructions per chunk with its records arriving as 16-byte
+// buffer loads a block of eight steps ahead - no LDS ring, no cursor, a wave-uniform loop count.
+// =====================================================================================
+// ring of 32 dwords, topped up by 32-byte pieces every 4 steps: 8.4 KiB per wavefront, sixteen wavefronts per CU (measured
+// against a 64-dword ring with whole 64-byte lines and eight per CU: 3.6 vs 4.0 ms per 256 4K frames - the walk is a chain of
+// LDS round trips and wants the wavefronts more than the line-sized loads)
+#ifndef QOIMI_TR_RD
+#define QOIMI_TR_RD 32
+#define QOIMI_TR_NP 2
+#define QOIMI_TR_PERIOD 4
+#define QOIMI_TR_LINE 1
+#endif
+#ifndef QOIMI_TR_WAVES
+#define QOIMI_TR_WAVES 4
+#endif
+typedef LaneReaderT<QOIMI_TR_RD, QOIMI_TR_NP, QOIMI_TR_PERIOD, 8, QOIMI_TR_LINE != 0> TransReader;
+constexpr uint32_t kTrThreads = 64u * QOIMI_TR_WAVES;
+struct LdsLutT { uint32_t tpl[256], info[256]; };   // record template; chunk-table word with QOI_OP_RGBA's length set to 0 (visited twice)
+
+// P2 + transcode: lane = segment.  Walks every chunk that starts in the segment from its true entry position (S1),
+// writes the chunk records of the segment as 16-byte granules from the start of its region (null-padded) and leaves
+// the speculative slot/alpha transfer (slot_rec, same function as dec_slot_walk).  A QOI_OP_RGBA chunk is visited in
+// two consecutive steps (stash record, alpha record); only the second advances the cursor.
+__global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
+    __shared__ uint32_t s_ring[QOIMI_TR_WAVES][TransReader::kSlots * 64];
+    __shared__ LdsLutT s_lut;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    for (uint32_t b = threadIdx.x; b < 256u; b += kTrThreads) {
+        uint32_t d, i; lut_entry(b, d, i);
+        s_lut.tpl[b] = rec_template(b);
+        s_lut.info[b] = b == 0xFFu ? (i & ~7u) : i;
+    }
+    __syncthreads();
+    const uint32_t q = blockIdx.x * kTrThreads + threadIdx.x;
+    bool have = q < p.total_segs;
+    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
+    const DecImage im = p.images[img];
+    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
+    have = have && j >= im.start_seg && j < im.n_active;
+    if (!lanes_where(have)) return;
+    const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
+    const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
+    uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
+    TransReader R;
+    R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
+    const uint32_t lut_base = lds_addr_of(&s_lut.tpl[0]);
+    bool active = have && pos < end;
+    uint32_t w32, b5; R.peek(pos, w32, b5);
+    uint32_t tpl, info;
+    {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); tpl = lq[0]; info = lq[256]; }
+    SlotFast st; slotf_init(st);
+    uint32_t pend = 0u;                          // 1: the stash record of the QOI_OP_RGBA chunk under the cursor is out
+    bool any_pend = false;
+    uint32_t ngran = 0u;
+    // granule row g of this wavefront's 64 segments: one contiguous KiB
+    u32x4* dst = reinterpret_cast<u32x4*>(p.recs + (size_t)(blockIdx.x * QOIMI_TR_WAVES + wave) * p.rec_rows * 256u) + lane;
+    while (lanes_where(active)) {
+        R.land(); R.issue(pos);
+#pragma unroll
+            for (uint32_t g = 0; g < TransReader::kPeriod / 4u; ++g) {
+            const bool live = active;                                    // the granule holds at least one record of this lane
+            uint32_t rr[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t c_info = active ? info : 0u;
+                uint32_t rec = active ? tpl : 0u;                        // null record once the lane is through
+#ifdef QOIMI_TR_LEN_ARITH
+                // chunk length by arithmetic on the tag byte: keeps the chunk table's LDS round trip out of the cursor's chain
+                uint32_t adv = active ? len_of(w32 & 0xFFu) : 0u;
+                adv = (w32 & 0xFFu) == 0xFFu ? 0u : adv;             // QOI_OP_RGBA: first visit, see below
+#else
+                uint32_t adv = lut_len(c_info);
+#endif
+                // byte-wise delta of a relative chunk: table part + the second byte of a LUMA chunk (qoi.h:566-571)
+                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)c_info, 28, 1);      // all ones for LUMA
+                const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
+                add_byte0(rec, er); add_byte2_from0(rec, eb);
+                // speculative slot/alpha transfer (slotf_step_split): QOI_COLOR_HASH is linear mod 64, so a relative chunk
+                // shifts the slot by the hash of its delta; QOI_OP_INDEX names it
+                const bool lo = lut_lo(c_info);
+                const uint32_t rel = st.hc + __builtin_amdgcn_udot4(rec, 0x00070503u, 0u, false);
+                uint32_t hc = lo ? (w32 & 0xFFu) : rel;
+                uint32_t fl = lo ? (st.fl & 4u) : st.fl;
+                if (lanes_where(lut_hi(c_info)) != 0 || any_pend) {     // QOI_OP_RGB / QOI_OP_RGBA somewhere in the wavefront (rare in natural images)
+                    const bool hi = lut_hi(c_info);
+                    const bool rgba = hi && lo, second = rgba && pend != 0u, first = rgba && pend == 0u;
+                    const uint32_t rgb = (w32 >> 8) & 0x00FFFFFFu;
+                    const uint32_t rec_hi = second ? rec_make(3u, 1u, b5) : (rec | rgb);      // rec still is the class-2 template here
+                    rec = hi ? rec_hi : rec;
+                    adv = second ? 5u : adv;
+                    const bool a_abs = (st.fl & 4u) != 0u;
+                    const uint32_t lrgb = __builtin_amdgcn_udot4(rgb, 0x00070503u, 0u, false);
+                    const uint32_t hb = lrgb + (lo ? 11u * b5 : (a_abs ? 11u * st.ac : 0u));
+                    const uint32_t fb = lo ? 4u : ((st.fl & 4u) | (a_abs ? 0u : 2u));
+                    hc = hi ? (first ? st.hc : hb) : hc;
+                    fl = hi ? (first ? st.fl : fb) : fl;
+                    st.ac = second ? b5 : st.ac;
+                    pend = first ? 1u : 0u;
+                    any_pend = lanes_where(pend != 0u) != 0;
+                }
+                st.hc = hc & 63u; st.fl = fl;
+                const uint32_t npos = pos + adv;
+                uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
+                const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
+                const uint32_t ntpl = lq[0], ninfo = lq[256];
+                rr[u] = rec;
+                pos = npos; w32 = nw32; b5 = nb5; tpl = ntpl; info = ninfo;
+                active = active && pos < end;
+            }
+            if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; dst[(size_t)ngran * 64u] = v; ++ngran; }
+        }
+    }
+    if (have) {
+        p.rec_gran[q] = ngran;
+        SlotRec r; slotf_finish(st, r); p.slot_rec[q] = r;
+    }
+}
+
+// Record source of a P3 / P4 wavefront: lane l reads the granules of segment 64 * block + l through a raw buffer descriptor
+// over the granule rows of the block (row g: 64 lanes x 16 bytes, contiguous).  A lane that is through (or has no segment) asks for an offset outside the
+// descriptor and gets zeros - the null record - so the loops never mask lanes off.
+struct RecSource {
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t off;          // byte offset of the lane's column in a granule row
+    uint32_t n_gran;       // granules of the lane
+    static constexpr uint32_t kNowhere = 0x7FFFFFF0u;
+    __device__ __forceinline__ void init(const DecParams& p, uint32_t block64, uint32_t lane, uint32_t grans) {
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.recs + (size_t)block64 * p.rec_rows * 256u), 0, (int)(p.rec_rows * 1024u), 0x00020000);
+        off = lane * 16u; n_gran = grans;
+    }
+    __device__ __forceinline__ u32x4 granule(uint32_t g) const {
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, g < n_gran ? off + 1024u * g : kNowhere, 0, 0);
+    }
+};
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o); v = t > v ? t : v; }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// Source / mask codes of the symbolic table as BYTES, laid out so that a wavefront's access to 64 different rows is free
+// of bank conflicts: the byte of (row r, lane l) sits in dword (r & 31) * 32 + (l & 31), byte 2 * (r >> 5) + (l >> 5) -
+// the 32 lanes of either half hit 32 different banks whatever their rows.  ([row][lane] bytes put four lanes into one
+// dword and a half-wavefront onto 16 banks: SQ_LDS_BANK_CONFLICT was 47 % of the LDS cycles of dec_summarize.)
+__device__ __forceinline__ uint32_t symcode_addr(uint32_t lane_base, uint32_t row) {
+    // lane_base = table base (4 KiB aligned) + (l & 31) * 4 + (l >> 5): bits 1 and 7..11 are clear, two bit-field inserts fill them
+    const uint32_t a = ((row >> 4) & 2u) | (lane_base & ~2u);
+    return ((row << 7) & 0xF80u) | (a & ~0xF80u);
+}
+
+// P3 on records.  One wavefront per 64 segments; 20 KiB of LDS (24 in the refinement rounds): eight per CU.
+// Same step as dec_summarize / symr_step (qoi_decode_core.h).
+template <bool REFINE>
+__global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
+    __shared__ __attribute__((aligned(16384))) uint32_t s_tabc[64 * 64];
+    __shared__ __attribute__((aligned(4096))) uint8_t s_tabm[64 * 64];
+    __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 4];
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    const uint32_t lane = lane_id();
+    const uint32_t q = blockIdx.x * 64u + lane;
+    bool have = q < p.total_segs;
+    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
+    const DecImage im = p.images[img];
+    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
+    have = have && j >= im.start_seg && j < im.n_active;
+    if (!lanes_where(have)) return;
+    RecSource S; S.init(p, blockIdx.x, lane, have ? p.rec_gran[q] : 0u);
+    const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);            // blocks of two granules = eight steps
+    u32x4 n0 = S.granule(0u), n1 = S.granule(1u);
+    const uint32_t tc_base = lds_addr_of(&s_tabc[lane]);                 // slot k at + k*256
+    const uint32_t tm_lane = lds_addr_of(&s_tabm[0]) + (lane & 31u) * 4u + (lane >> 5);
+    // identity: slot k = entry slot k + 0, pixel = entry pixel + 0 (sym_init)
+    for (uint32_t k = 0; k < 64u; ++k) { *(lds_u32*)(tc_base + k * 256u) = 0u; *(lds_u8*)symcode_addr(tm_lane, k) = (uint8_t)k; }
+    uint32_t pc = 0u, ph = 64u;                                           // ph: code of the running pixel (entry pixel, nothing absolute)
+    uint32_t slot, alpha, stash = 0u;
+    if (REFINE) {
+        const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
+        uint32_t epx = 0;
+        if (have) {
+            for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {
+                uint32_t v[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) v[k] = ent[k0 + k];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) s_hint[(k0 + k) * 64u + lane] = (uint8_t)(v[k] >> 24);
+            }
+            epx = ent[64];
+            s_hint[64u * 64u + lane] = (uint8_t)(epx >> 24);
+        }
+        slot = hash_px(epx); alpha = epx >> 24;
+    } else {
+        slot = have ? p.slot_in[q] : 0u; alpha = have ? p.alpha_in[q] : 0u;
+    }
+    const uint32_t alpha_in0 = alpha;
+    // RUN chunks (and null records) store nothing new except as a stream's first chunk (SymState); the refinement rounds
+    // skip the store by writing back the word they read (see dec_summarize)
+    const bool skip_runs = REFINE && j != 0u;
+    for (uint32_t blk = 0; blk < nblk; ++blk) {
+        const u32x4 c0 = n0, c1 = n1;
+        n0 = S.granule(2u * blk + 2u); n1 = S.granule(2u * blk + 3u);
+        const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t rec = rc[u];
+            const uint32_t idx = rec & 63u;
+            const uint32_t tm_rd = symcode_addr(tm_lane, idx);
+            const uint32_t t_c = *(const lds_u32*)(tc_base + (idx << 8));
+            const uint32_t t_m = *(const lds_u8*)tm_rd;
+            uint32_t pc_rel = pc;
+            add_byte0(pc_rel, rec); add_byte1(pc_rel, rec); add_byte2(pc_rel, rec);
+            const bool hi = (int32_t)rec < 0, lo = (int32_t)(rec << 1) < 0;
+            const uint32_t s_rel = slot + __builtin_amdgcn_udot4(rec, 0x00070503u, 0u, false);
+            // alpha an INDEX chunk leaves: the named entry's (hinted where it is still symbolic)
+            const uint32_t th = REFINE ? (uint32_t)s_hint[(t_m < kSymCodeRgb ? t_m : (t_m - kSymCodeRgb) & 0x7Fu) * 64u + lane] : alpha_in0;
+            const uint32_t ta = t_m == kSymCodeAbs ? (t_c >> 24) : th;
+            // two complete bodies: the common one knows nothing of QOI_OP_RGB / QOI_OP_RGBA (no selects on `hi`, no write-back)
+            if (__builtin_expect(lanes_where(hi) != 0, 0)) {
+                const uint32_t rgb = rec & 0x00FFFFFFu;
+                const bool is_stash = hi && !lo && ((rec >> 24) & 63u) == kRecStash;
+                const uint32_t a_new = rec & 0xFFu;
+                const uint32_t pc_rgb = (pc & 0xFF000000u) | rgb, pc_abs = stash | (rec << 24);
+                const uint32_t l_rgb = __builtin_amdgcn_udot4(rgb, 0x00070503u, 0u, false), l_st = __builtin_amdgcn_udot4(stash, 0x00070503u, 0u, false);
+                const uint32_t sb = lo ? l_st + 11u * a_new : l_rgb + 11u * alpha;
+                const uint32_t pb = lo ? pc_abs : pc_rgb;
+                const uint32_t hb = lo ? kSymCodeAbs : (ph < kSymCodeRgb ? ph + kSymCodeRgb : ph);
+                const uint32_t ab = lo ? a_new : alpha;
+                const uint32_t pa = lo ? t_c : pc_rel, ha = lo ? t_m : ph, sa = lo ? idx : s_rel, aa = lo ? ta : alpha;
+                const bool keep = is_stash || (skip_runs && (rec & 0xC0FFFFFFu) == 0u);   // the table stays as it is: the word read goes back
+                if (!is_stash) {
+                    pc = hi ? pb : pa; ph = hi ? hb : ha; slot = (hi ? sb : sa) & 63u; alpha = hi ? ab : aa;
+                } else {
+                    stash = rgb;
+                }
+                const uint32_t wslot = keep ? idx : slot, wc = keep ? t_c : pc, wm = keep ? t_m : ph;
+                *(lds_u32*)(tc_base + (wslot << 8)) = wc;          // index update after every chunk (qoi.h:577)
+                *(lds_u8*)symcode_addr(tm_lane, wslot) = (uint8_t)wm;
+            } else {
+                pc = lo ? t_c : pc_rel; ph = lo ? t_m : ph; slot = (lo ? idx : s_rel) & 63u; alpha = lo ? ta : alpha;
+                if (REFINE) {
+                    const bool keep = skip_runs && (rec & 0xC0FFFFFFu) == 0u;
+                    const uint32_t wslot = keep ? idx : slot, wc = keep ? t_c : pc, wm = keep ? t_m : ph;
+                    *(lds_u32*)(tc_base + (wslot << 8)) = wc;
+                    *(lds_u8*)symcode_addr(tm_lane, wslot) = (uint8_t)wm;
+                } else {
+                    *(lds_u32*)(tc_base + (slot << 8)) = pc;       // index update after every chunk (qoi.h:577)
+                    *(lds_u8*)symcode_addr(tm_lane, slot) = (uint8_t)ph;
+                }
+            }
+        }
+    }
+    if (have) {
+        sym_t* dst = p.summary + (size_t)q * 65u;
+        for (uint32_t k = 0; k < 64u; ++k)
+            dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)sym_code_expand(*(const lds_u8*)symcode_addr(tm_lane, k)) << 32);
+        dst[64] = (sym_t)pc | ((sym_t)sym_code_expand(ph) << 32);
+    }
+}
+
+// Pixel sink of dec_segments_rec: LaneWriter's ring (32 pixels per lane) with a BRANCH-FREE drain.  Once per block of
+// eight steps every lane that holds a complete, 16-pixel aligned group writes it as four (OCH 3: three) back-to-back
+// 16-byte buffer stores; lanes without one aim outside the buffer descriptor and the hardware drops their part.  The
+// instructions are issued whatever the lanes hold, so their number is static - and that is the point: vector memory
+// operations retire in order and a wavefront has one counter for loads and stores (gfx9 family), so the wait for the
+// next block's records is `s_waitcnt vmcnt(4)` - records yes, this block's stores no.  With the stores under
+// data-dependent loops (LaneWriter::drain) the compiler has to wait with vmcnt(0): profiles/r02 - 75 % of the wavefront
+// cycles of the first dec_segments_rec were spent there, waiting for store acknowledgements.
+// Group stores go through a descriptor based at the image of the wavefront's first segment (32-bit offsets); a lane whose
+// image lies 2 GiB or more behind that base (never with sane strides) uses plain stores on a rare path.
+template <int OCH>
+struct BurstWriter : LaneWriter<OCH, 32, 16> {
+    typedef LaneWriter<OCH, 32, 16> Base;
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t boff;         // byte offset of the lane's image in the descriptor; kFar: not addressable through it
+    static constexpr uint32_t kFar = 0xFFFFFFFFu, kNowhere = 0x7FFFFFF0u, kRange = 0x7FFF0000u;
+    __device__ __forceinline__ void init(uint32_t row_addr, uint8_t* wave_base, uint8_t* image, uint32_t image_bytes, uint32_t px_pos) {
+        Base::init(row_addr, image, px_pos);
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)wave_base, 0, (int)kRange, 0x00020000);
+        const unsigned long long d = (unsigned long long)(image - wave_base);
+        boff = d + image_bytes < (unsigned long long)kRange ? (uint32_t)d : kFar;
+    }
+    __device__ __forceinline__ void drain_block() {
+        // head of a segment / after a long run: up to the next group boundary pixel by pixel (LaneWriter::drain's first loop)
+        if (__builtin_expect(lanes_where((this->fpos & 15u) != 0u && this->fpos < this->ppos) != 0, 0)) {
+            while ((this->fpos & 15u) != 0u && this->fpos < this->ppos) {
+                if ((this->fpos & 3u) == 0u && this->fpos + 4u <= this->ppos) { this->store4(this->fpos, this->at(this->fpos), this->at(this->fpos + 1u), this->at(this->fpos + 2u), this->at(this->fpos + 3u)); this->fpos += 4u; }
+                else { this->store_one(this->fpos, this->at(this->fpos)); ++this->fpos; }
+            }
+        }
+        const bool ready = (this->fpos & 15u) == 0u && this->ppos - this->fpos >= 16u;
+        if (__builtin_expect(lanes_where(ready && boff == kFar) != 0, 0)) {           // image out of the descriptor's reach
+            if (ready && boff == kFar) Base::drain();
+        }
+        const bool go = ready && boff != kFar;
+        if (OCH == 4) {
+            // Cooperative: the 64 bytes of an owner's group are written by FOUR ADJACENT LANES, 16 bytes each (lane t: piece t & 3
+            // of owner (t >> 2) + 16 j in instruction j) - 16 contiguous 64-byte lines per instruction instead of 64 scattered
+            // 16-byte pieces.  The address path of the CU was the limit with one piece per lane (~230 CU-cycles per store
+            // instruction, SQ_WAIT_INST_ANY 43 % of the wavefront cycles, profiles/r02).
+            const uint32_t lane = (this->row >> 2) & 63u;
+            const uint32_t A = go ? boff + this->fpos * 4u : kNowhere;            // the group's byte offset in the descriptor
+            const uint32_t rb = this->fpos & 16u;                                  // the group is rows 0..15 or 16..31 of the ring
+            const uint32_t piece = lane & 3u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t owner = (lane >> 2) + 16u * j;
+                const uint32_t Ao = gather_lane(A, owner), rbo = gather_lane(rb, owner);
+                const uint32_t raddr = this->row - lane * 4u + owner * 4u + ((rbo + 4u * piece) << 8);
+                u32x4 w;
+                w.x = *(const lds_u32*)(raddr); w.y = *(const lds_u32*)(raddr + 256u); w.z = *(const lds_u32*)(raddr + 512u); w.w = *(const lds_u32*)(raddr + 768u);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs, Ao + 16u * piece, 0, 0);    // kNowhere + 48 is still outside
+            }
+        } else {
+        const uint32_t rbase = this->row + ((this->fpos & 16u) << 8);                 // the group is rows 0..15 or 16..31 of the ring
+        uint32_t v[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) v[k] = *(const lds_u32*)(rbase + k * 256u);
+        const uint32_t off = go ? boff + this->fpos * (uint32_t)OCH : kNowhere;
+        {                                                                             // 16 pixels -> 12 dwords of packed r,g,b
+            uint32_t d[12];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k += 4u) {
+                const uint32_t a = v[k] & 0xFFFFFFu, b = v[k + 1u] & 0xFFFFFFu, c = v[k + 2u] & 0xFFFFFFu, e = v[k + 3u] & 0xFFFFFFu;
+                d[3u * (k >> 2)] = a | (b << 24); d[3u * (k >> 2) + 1u] = (b >> 8) | (c << 16); d[3u * (k >> 2) + 2u] = (c >> 16) | (e << 8);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 12u; k += 4u) {
+                u32x4 w; w.x = d[k]; w.y = d[k + 1u]; w.z = d[k + 2u]; w.w = d[k + 3u];
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs, off + 4u * k, 0, 0);
+            }
+        }
+        }
+        this->fpos += go ? 16u : 0u;
+    }
+};
+
+// P4 on records: genuine decode of every active segment + exit-state check (lane = segment), see dec_segments.
+// 16 KiB of colour tables + the 4 KiB pixel ring = 20 KiB: eight wavefronts per CU.
+template <int OCH>
+__global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
+    typedef BurstWriter<OCH> Writer;
+    constexpr uint32_t kTabDw = 64u * 64u, kOutDw = Writer::kRing * 64u;
+    static_assert(2u * 8u + Writer::kGroup <= Writer::kRing, "a block of eight steps adds up to 16 pixels to what a drain leaves (< one group)");
+#ifndef QOIMI_SEGREC_PAD_DW
+#define QOIMI_SEGREC_PAD_DW 0
+#endif
+    __shared__ __attribute__((aligned(16384))) uint32_t s_mem[kTabDw + kOutDw + QOIMI_SEGREC_PAD_DW];
+    uint32_t* const s_tab = s_mem;
+    uint32_t* const s_out = s_mem + kTabDw;
+    const uint32_t lane = lane_id();
+    if (QOIMI_SEGREC_PAD_DW && p.total_segs == 0xFFFFFFFFu) s_mem[kTabDw + kOutDw + lane] = 0u;     // keeps the padding (occupancy experiments)
+    const uint32_t q = blockIdx.x * 64u + lane;
+    bool have = q < p.total_segs;
+    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
+    const DecImage im = p.images[img];
+    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
+    have = have && j >= im.start_seg && j < im.n_active;
+    if (!lanes_where(have)) return;
+    const uint32_t limit = im.npx;
+    const uint32_t px_first = have ? p.px_off[q] : 0u;
+    RecSource S; S.init(p, blockIdx.x, lane, have && px_first < limit ? p.rec_gran[q] : 0u);
+    const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);
+    u32x4 n0 = S.granule(0u), n1 = S.granule(1u);
+    Writer W;
+    {   // descriptor base: the image of the wavefront's first segment (its lanes' images follow it in memory)
+        const uint32_t q0 = blockIdx.x * 64u;
+        const uint32_t img0 = find_image(p.images, p.n_images, q0 < p.total_segs ? q0 : 0u);
+        W.init(lds_addr_of(&s_out[lane]), p.pixels + (size_t)img0 * p.pixel_stride, p.pixels + (size_t)img * p.pixel_stride,
+               im.npx * (uint32_t)OCH, px_first);
+    }
+    LdsTab32 tab{&s_tab[lane]};
+    const uint32_t tab_base = lds_addr_of(&s_tab[lane]);
+    const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
+    uint32_t px = 0, stash = 0;
+    if (have) {
+        for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {          // 16 loads in flight, then 16 LDS writes
+            uint32_t v[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) v[k] = ent[k0 + k];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) tab.set(k0 + k, v[k]);
+        }
+        px = ent[64];
+    }
+    constexpr uint32_t kLongRun = 12;
+    // only a wavefront that holds a segment which may reach the image's pixel limit pays for the clipping (see dec_segments)
+    const bool clip_lane = have && (j + 1u >= im.n_active || p.px_off[q + 1u] >= limit);
+    auto run = [&](auto clip_tag) {
+        constexpr bool CLIP = decltype(clip_tag)::value;
+        for (uint32_t blk = 0; blk < nblk; ++blk) {
+            const u32x4 c0 = n0, c1 = n1;                       // the loads issued a block (eight steps) ago
+            n0 = S.granule(2u * blk + 2u); n1 = S.granule(2u * blk + 3u);
+            W.drain_block();                                    // a static number of stores right behind the loads (BurstWriter)
+            const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                const uint32_t rec = rc[u];
+                const uint32_t idx8 = (rec & 63u) << 8;
+                const uint32_t t = *(const lds_u32*)(tab_base + idx8);           // slot an INDEX names
+                uint32_t rel = px;
+                add_byte0(rel, rec); add_byte1(rel, rec); add_byte2(rel, rec);
+                const bool hi = (int32_t)rec < 0, lo = (int32_t)(rec << 1) < 0;
+                uint32_t rem = (rec >> 24) & 63u;                                 // 0: null record
+                const uint32_t a = lo ? t : rel;
+                // two complete bodies: the common one knows nothing of QOI_OP_RGB / QOI_OP_RGBA
+                if (__builtin_expect(lanes_where(hi) != 0, 0)) {   // QOI_OP_RGB keeps the alpha; QOI_OP_RGBA = stash record + alpha record (qoi.h:548-557)
+                    const uint32_t rgb = rec & 0x00FFFFFFu;
+                    const bool is_stash = hi && !lo && rem == kRecStash;
+                    const uint32_t b = lo ? (stash | (rec << 24)) : ((px & 0xFF000000u) | rgb);
+                    uint32_t npxl = is_stash ? px : (hi ? b : a);
+                    stash = is_stash ? rgb : stash;
+                    rem = is_stash ? 0u : rem;
+                    if (CLIP) npxl = W.ppos < limit ? npxl : px;         // at the pixel limit the decoder has stopped (qoi.h:540)
+                    px = npxl;
+                    // index[QOI_COLOR_HASH(px) % 64] = px after every chunk (qoi.h:577); a stash record puts back what it read
+                    const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
+                    const uint32_t waddr = is_stash ? idx8 : ((h & 63u) << 8), wval = is_stash ? t : px;
+                    *(lds_u32*)(tab_base + waddr) = wval;
+                } else {
+                    uint32_t npxl = a;
+                    if (CLIP) npxl = W.ppos < limit ? npxl : px;
+                    px = npxl;
+                    const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
+                    *(lds_u32*)(tab_base + ((h & 63u) << 8)) = px;       // qoi.h:577
+                }
+                if (CLIP) rem = min(rem, limit - W.ppos);                 // over-long run clipped (Appendix B item 8)
+                const uint32_t n2 = min(rem, 2u);
+                W.put2n(px, n2);
+                rem -= n2;
+                if (rem) {                                                 // QOI_OP_RUN of three or more (qoi.h:573-575)
+                    if (rem >= kLongRun) W.splat(px, rem);
+                    while (rem) { W.put(px); --rem; }
+                    if (W.ppos - W.fpos > Writer::kRing - 2u * 8u) W.drain();
+                }
+            }
+        }
+    };
+    if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
+    if (have) {
+        W.finish();
+        if (j + 1u < im.n_active) {
+            // exit state must equal what the next segment was started from
+            const uint32_t* __restrict__ nxt = ent + 65u;
+            bool same = nxt[64] == px;
+            for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {
+                uint32_t v[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) v[k] = nxt[k0 + k];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) same = same && (v[k] == tab.get(k0 + k));
+            }
+            if (!same) {
+                uint32_t* fx = p.fix + (size_t)(q + 1u) * 65u;
+                for (uint32_t k = 0; k < 64u; ++k) fx[k] = tab.get(k);
+                fx[64] = px;
+                atomicMin(&p.first_bad[img], j + 1u);
+            }
+        } else {
+            p.images[img].final_px = px;     // pixel repeated when the stream ends early (qoi.h:544)
+        }
+    }
+}
+
 // Pixels the chunks never reach repeat the last pixel (truncated streams, size==22).
 template <int OCH>
 __global__ __launch_bounds__(256) void dec_fill(DecParams p) {
@@ -1636,7 +2134,8 @@ __global__ __launch_bounds__(64) void dec_prepare_restart(DecParams p) {
 void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
     tm->mark(kT_begin, st);
     if (p.total_segs) {
-        if (p.fine_per_seg) hipLaunchKernelGGL(dec_parse_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+        if (p.fine_per_seg && p.use_rec) hipLaunchKernelGGL(dec_parse_fine<false>, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+        else if (p.fine_per_seg) hipLaunchKernelGGL(dec_parse_fine<true>, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(dec_parse, dim3((p.total_segs + 255u) / 256u), dim3(256), 0, st, p);
         tm->mark(kT_dec_parse, st);
         hipLaunchKernelGGL(dec_chain_parse_l1, dim3(p.total_grps), dim3(64), 0, st, p);
@@ -1652,18 +2151,21 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     const uint32_t b256 = (p.total_segs + 255u) / 256u, b64 = (p.total_segs + 63u) / 64u;
     tm->mark(kT_begin, st);
     if (refine) {
-        if (p.pair & 2u) hipLaunchKernelGGL(dec_summarize_pair<true>, dim3(b64), dim3(128), 0, st, p);
+        if (p.use_rec) hipLaunchKernelGGL(dec_summarize_rec<true>, dim3(b64), dim3(64), 0, st, p);
+        else if (p.pair & 2u) hipLaunchKernelGGL(dec_summarize_pair<true>, dim3(b64), dim3(128), 0, st, p);
         else hipLaunchKernelGGL(dec_summarize<true>, dim3(b64), dim3(64), 0, st, p);
         tm->mark(kT_dec_summarize, st);
     } else {
-    if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_heads_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+    if (p.use_rec) hipLaunchKernelGGL(dec_transcode, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
+    else if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_heads_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(dec_slot_walk, dim3(b256), dim3(256), 0, st, p);
     tm->mark(kT_dec_slot_walk, st);
     hipLaunchKernelGGL(dec_chain_slots_l1, dim3(p.total_grps), dim3(64), 0, st, p);
     hipLaunchKernelGGL(dec_chain_slots_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
     hipLaunchKernelGGL(dec_chain_slots_l3, dim3(p.total_grps), dim3(64), 0, st, p);
     tm->mark(kT_dec_chain_slots, st);
-    if (p.pair & 2u) hipLaunchKernelGGL(dec_summarize_pair<false>, dim3(b64), dim3(128), 0, st, p);
+    if (p.use_rec) hipLaunchKernelGGL(dec_summarize_rec<false>, dim3(b64), dim3(64), 0, st, p);
+    else if (p.pair & 2u) hipLaunchKernelGGL(dec_summarize_pair<false>, dim3(b64), dim3(128), 0, st, p);
     else hipLaunchKernelGGL(dec_summarize<false>, dim3(b64), dim3(64), 0, st, p);
     tm->mark(kT_dec_summarize, st);
     }
@@ -1671,7 +2173,10 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
     hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);
     tm->mark(kT_dec_chain_state, st);
-    if (p.pair & 1u) {
+    if (p.use_rec) {
+        if (out_channels == 4) hipLaunchKernelGGL(dec_segments_rec<4>, dim3(b64), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL(dec_segments_rec<3>, dim3(b64), dim3(64), 0, st, p);
+    } else if (p.pair & 1u) {
         if (out_channels == 4) hipLaunchKernelGGL(dec_segments_pair<4>, dim3(b64), dim3(128), 0, st, p);
         else hipLaunchKernelGGL(dec_segments_pair<3>, dim3(b64), dim3(128), 0, st, p);
     } else if (out_channels == 4) hipLaunchKernelGGL(dec_segments<4>, dim3(b64), dim3(64), 0, st, p);

@@ -522,6 +522,131 @@ QOIMI_HD uint32_t decode_segment_fast(const uint8_t* in, uint32_t pos, uint32_t 
     }
     return px;
 }
+// =====================================================================================
+// Chunk RECORDS (round 2).  The table-bound passes P3 / P4 no longer walk the byte stream: one pass
+// ("transcode", the old P2 walk) turns every chunk into ONE fixed-width 32-bit record, written per segment
+// as a contiguous run of 16-byte granules, and P3 / P4 read records with a wave-uniform stride - no byte
+// cursor, no chunk table, no LUMA expansion in the two passes that are bound by their serial chains.
+//   bits  0..23  payload
+//   bits 24..29  pixels the record produces (0..62; 63 = stash marker, see class 2)
+//   bits 30..31  class: 0 relative   payload = byte-wise (dr,dg,db), LUMA's second byte folded in; RUN: 0 (qoi.h:561-575)
+//                       1 INDEX      payload byte 0 = slot                                           (qoi.h:558-560)
+//                       2 RGB        payload = r,g,b; alpha kept                                    (qoi.h:547-551)
+//                                    with pixels == 63: first half of QOI_OP_RGBA - r,g,b are stashed, NOTHING
+//                                    else happens (no pixel, the table is left exactly as it is)
+//                       3 ALPHA      second half of QOI_OP_RGBA: pixel = stashed r,g,b + payload byte 0 as alpha;
+//                                    one pixel, table updated                                       (qoi.h:552-557)
+// A record of 0 is the null record (padding of a segment's last granule, lanes that are through): relative, delta
+// 0, no pixels - it re-stores the running pixel where it already is (index[hash(px)] == px after every chunk).
+// The stash half must be a true no-op instead: as a stream's FIRST chunk the start pixel {0,0,0,255} is not in the
+// table yet and must not be put there.
+// =====================================================================================
+constexpr uint32_t kRecStash = 63u;
+// Records a segment of B stream bytes can hold, padded to whole granules of 4: one per byte at most (every chunk of one
+// byte) - plus ONE, because a QOI_OP_RGBA chunk that starts on the segment's last byte still leaves both of its records.
+QOIMI_HD uint32_t rec_region_dwords(uint32_t B) { return (B + 1u + 3u) & ~3u; }
+QOIMI_HD uint32_t rec_class(uint32_t r) { return r >> 30; }
+QOIMI_HD uint32_t rec_pixels(uint32_t r) { return (r >> 24) & 63u; }
+QOIMI_HD uint32_t rec_make(uint32_t cls, uint32_t npx, uint32_t payload) { return (cls << 30) | (npx << 24) | (payload & 0x00FFFFFFu); }
+// template of the record of a chunk whose tag byte is b (payload completed by the transcoder for LUMA / RGB / RGBA)
+QOIMI_HD uint32_t rec_template(uint32_t b) {
+    const uint32_t top = b >> 6;
+    if (b == 0xFEu) return rec_make(2u, 1u, 0u);
+    if (b == 0xFFu) return rec_make(2u, kRecStash, 0u);
+    if (top == 0u) return rec_make(1u, 1u, b);
+    if (top == 1u) return rec_make(0u, 1u, diff_delta(b));
+    if (top == 2u) return rec_make(0u, 1u, luma_delta(b, 0u));
+    return rec_make(0u, (b & 0x3Fu) + 1u, 0u);
+}
+// records of the chunk at w (chunk bytes 0..7, little endian): 1, or 2 for QOI_OP_RGBA
+QOIMI_HD uint32_t rec_of_chunk(unsigned long long w, uint32_t out[2]) {
+    const uint32_t b1 = (uint32_t)w & 0xFFu, w32 = (uint32_t)w;
+    uint32_t r = rec_template(b1);
+    if (b1 == 0xFFu) { out[0] = r | ((w32 >> 8) & 0x00FFFFFFu); out[1] = rec_make(3u, 1u, (uint32_t)(w >> 32) & 0xFFu); return 2u; }
+    if (b1 == 0xFEu) { out[0] = r | ((w32 >> 8) & 0x00FFFFFFu); return 1u; }
+    if ((b1 >> 6) == 2u) {                                              // LUMA: + (b2>>4, 0, b2&15) byte-wise
+        const uint32_t b2 = (w32 >> 8) & 0xFFu;
+        const uint32_t ex = (b2 >> 4) | ((b2 & 15u) << 16);
+        r = (r & 0xFF000000u) | (add_bytes(r & 0x00FFFFFFu, ex) & 0x00FFFFFFu);
+    }
+    out[0] = r; return 1u;
+}
+// transcoder of one segment (host rehearsal; the kernel inlines the same walk around its LDS reader): every chunk
+// that starts in [pos, seg_end) -> records, padded with null records to a multiple of 4.  Returns the granule count.
+// Also leaves the speculative slot transfer of the segment (the old P2 walk, same function as slot_walk_segment_fast).
+template <class Lut>
+QOIMI_HD uint32_t transcode_segment(const uint8_t* in, uint32_t pos, uint32_t seg_end, const Lut& lut, uint32_t* recs, SlotRec& sr) {
+    PtrReader R{in};
+    SlotFast s; slotf_init(s);
+    uint32_t n = 0;
+    while (pos < seg_end) {
+        const unsigned long long w = load8(in + pos);
+        uint32_t two[2];
+        const uint32_t k = rec_of_chunk(w, two);
+        recs[n++] = two[0]; if (k == 2u) recs[n++] = two[1];
+        uint32_t w32, b5; R.peek(pos, w32, b5);
+        { const uint32_t info = lut.info[w32 & 0xFFu]; slotf_step_split(s, w32, b5, info, lut_hi(info)); }
+        pos += len_of(w32 & 0xFFu);
+    }
+    while (n & 3u) recs[n++] = 0u;
+    slotf_finish(s, sr);
+    return n >> 2;
+}
+// P3 on records: same function of the chunks as symf_step.  stash: r,g,b of a pending QOI_OP_RGBA.
+template <class Tab, class Hint>
+QOIMI_HD void symr_step(SymState& s, uint32_t& stash, uint32_t rec, sym_t t, Tab& tab, const Hint& hint) {
+    const uint32_t cls = rec_class(rec), idx = rec & 63u;
+    if (cls == 2u && rec_pixels(rec) == kRecStash) { stash = rec & 0x00FFFFFFu; tab.set(idx, t); return; }   // true no-op
+    const bool is_run = (rec & 0xC0FFFFFFu) == 0u;                        // RUN, zero-delta chunk or null record: the pixel stays
+    if (cls == 0u) {
+        s.pc = add_bytes(s.pc, rec & 0x00FFFFFFu);
+        s.slot = (s.slot + lin_hash(rec & 0x00FFFFFFu)) & 63u;
+    } else if (cls == 1u) {
+        s.pc = (uint32_t)t; s.ph = (uint32_t)(t >> 32);
+        s.slot = idx;
+        s.alpha = (sym_abs(t) & 8u) ? (uint32_t)t >> 24 : hint(sym_src(t));
+    } else if (cls == 2u) {
+        s.pc = (s.pc & 0xFF000000u) | (rec & 0x00FFFFFFu); s.ph |= 7u << 8;
+        s.slot = (lin_hash(rec & 0x00FFFFFFu) + 11u * s.alpha) & 63u;
+    } else {
+        const uint32_t a = rec & 0xFFu;
+        s.pc = stash | (a << 24); s.ph = 15u << 8;
+        s.slot = (lin_hash(stash) + 11u * a) & 63u; s.alpha = a;
+    }
+    if (is_run && s.runmask) tab.set(idx, t);                             // store skipped: the word read is written back
+    else tab.set(s.slot, (sym_t)s.pc | ((sym_t)s.ph << 32));              // index update after every chunk (qoi.h:577)
+}
+template <class Tab, class Hint>
+QOIMI_HD sym_t summarize_records(const uint32_t* recs, uint32_t n_gran, uint32_t slot, uint32_t alpha, Tab& tab, const Hint& hint, bool stream_start) {
+    SymState s; sym_init(s, slot, alpha, tab, stream_start);
+    uint32_t stash = 0;
+    for (uint32_t i = 0; i < 4u * n_gran; ++i) symr_step(s, stash, recs[i], tab.get(recs[i] & 63u), tab, hint);
+    return sym_pixel(s);
+}
+// P4 on records: same function of the chunks as pixelf_step / decode_segment_fast
+template <int OCH, class Tab32>
+QOIMI_HD uint32_t decode_records(const uint32_t* recs, uint32_t n_gran, uint32_t px, Tab32& tab, uint8_t* out, uint32_t px_pos, uint32_t px_limit) {
+    uint32_t stash = 0;
+    for (uint32_t i = 0; i < 4u * n_gran; ++i) {
+        const uint32_t rec = recs[i], cls = rec_class(rec), idx = rec & 63u;
+        const uint32_t t = tab.get(idx);
+        if (px_pos >= px_limit) break;                                  // the decoder has stopped (qoi.h:540)
+        if (cls == 2u && rec_pixels(rec) == kRecStash) { stash = rec & 0x00FFFFFFu; continue; }
+        px = cls == 0u ? (add_bytes(px, rec & 0x00FFFFFFu) & 0x00FFFFFFu) | (px & 0xFF000000u)
+           : cls == 1u ? t
+           : cls == 2u ? (px & 0xFF000000u) | (rec & 0x00FFFFFFu)
+                       : stash | ((rec & 0xFFu) << 24);
+        tab.set(hash_px(px), px);
+        uint32_t stop = px_pos + rec_pixels(rec);
+        if (stop > px_limit) stop = px_limit;                            // over-long run clipped (Appendix B item 8)
+        for (; px_pos < stop; ++px_pos) {
+            if (OCH == 4) reinterpret_cast<uint32_t*>(out)[px_pos] = px;
+            else { uint8_t* d = out + (size_t)px_pos * 3u; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
+        }
+    }
+    return px;
+}
+
 // P1 with the single-chain fast path: five chains until they have met, then one cursor
 template <class Lut>
 QOIMI_HD void parse_segment_fast(const uint8_t* in, uint32_t base, uint32_t seg_end, uint32_t B, const Lut& lut, ParseRec& r) {

@@ -81,6 +81,8 @@ struct qoimi_ctx {
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
     int dec_pair = 3;                   // bit 0: P4, bit 1: P3 run as reader / worker wavefront pairs; 0: one wavefront per 64 segments
+    int dec_rec = 1;                    // 1: chunk records (dec_transcode + dec_summarize_rec + dec_segments_rec); 0: the round-1 byte-stream passes
+    size_t dec_rec_cap = (size_t)16 << 30;   // largest record arena: a call whose streams need more is decoded in sub-batches
     KernelTimer timer;                  // optional per-kernel HIP-event timing
     double prof_ms[kT_count] = {0};     // accumulated kernel milliseconds since profiling was (re)enabled
     long long prof_calls[kT_count] = {0};
@@ -123,6 +125,8 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_PAIR")) c->dec_pair = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_REC")) c->dec_rec = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
     if (const char* e = getenv("QOIMI_SEG_BYTES")) {
         long v = atol(e);
         if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v;
@@ -264,13 +268,8 @@ extern "C" int qoimi_encode_status(qoimi_ctx* c, void* stream) {
 // ------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------
-extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t stream_stride,
-                                  const int* sizes, const qoi_desc* descs, int n_images, int channels,
-                                  void* d_pixels, size_t pixel_stride, void* stream) {
-    if (!c || !d_streams || !sizes || !descs || !d_pixels || n_images <= 0) return fail(QOIMI_E_ARG, "NULL/empty argument");
-    if (channels != 0 && channels != 3 && channels != 4) return fail(QOIMI_E_ARG, "channels must be 0, 3 or 4 (qoi.h:499)");
-    int och = 0;
-    std::vector<DecImage> imgs((size_t)n_images);
+// segment size of a decode call (see the cost model below)
+static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, int n_images) {
     uint32_t B = c->seg_bytes;
     if (B == 0) {
         // One lane decodes one segment.  Two costs pull in opposite directions (constants measured on MI355X):
@@ -294,6 +293,15 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
             if (t < best) { best = t; B = cand; }
         }
     }
+    return B;
+}
+
+// one sub-batch: everything of qoimi_decode_batch for images whose record arena fits dec_rec_cap
+static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride,
+                       const int* sizes, const qoi_desc* descs, int n_images, int channels,
+                       void* d_pixels, size_t pixel_stride, void* stream, uint32_t B, bool lone_image, long long stats[3]) {
+    int och = 0;
+    std::vector<DecImage> imgs((size_t)n_images);
     uint64_t total = 0, total_g = 0;
     for (int i = 0; i < n_images; ++i) {
         if (sizes[i] < kHeaderBytes + kTrailerBytes) return fail(QOIMI_E_ARG, "stream shorter than 22 bytes (qoi.h:500)");
@@ -303,7 +311,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
         och = o;
         const size_t npx = (size_t)descs[i].width * descs[i].height;
         if (npx * (size_t)o > pixel_stride) return fail(QOIMI_E_ARG, "pixel_stride smaller than a decoded image");
-        if ((size_t)sizes[i] > stream_stride && n_images > 1) return fail(QOIMI_E_ARG, "stream longer than stream_stride");
+        if ((size_t)sizes[i] > stream_stride && !lone_image) return fail(QOIMI_E_ARG, "stream longer than stream_stride");
         DecImage& im = imgs[(size_t)i];
         memset(&im, 0, sizeof im);
         im.stream_off = (size_t)i * stream_stride;
@@ -325,6 +333,8 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
     p.pair = (uint32_t)c->dec_pair & 3u;
+    p.use_rec = c->dec_rec ? 1u : 0u;
+    p.rec_rows = rec_region_dwords(B) / 4u;
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
     const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
     {   // P1/P2 on 128-byte pieces when a segment is 1, 8, 16, 32 or 64 of them
@@ -350,6 +360,8 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
         p.grp_parse = w.take<ParseRec>(NG); p.grp_phase = w.take<uint8_t>(NG); p.grp_off = w.take<uint32_t>(NG);
         p.grp_slot = w.take<SlotRec>(NG); p.grp_slot_in = w.take<uint8_t>(NG); p.grp_alpha_in = w.take<uint8_t>(NG);
         p.grp_summary = w.take<u64>(NG * 65); p.grp_entry = w.take<uint32_t>(NG * 65);
+        p.rec_gran = w.take<uint32_t>(p.use_rec ? Q : 1);
+        p.recs = w.take<uint32_t>(p.use_rec ? ((Q + 63u) / 64u) * p.rec_rows * 256u : 4);
         if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }
     }
     {   // image table through pinned staging: no synchronisation (every decode call ends with one, so the
@@ -384,9 +396,40 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     }
     HIP_TRY(hipGetLastError());
     timer_collect(c);
-    c->dec_stats[0] = rounds;
-    c->dec_stats[1] = p.total_segs ? c->host_word[1] : 0;
-    c->dec_stats[2] = (long long)total;
+    stats[0] = rounds;
+    stats[1] = p.total_segs ? c->host_word[1] : 0;
+    stats[2] = (long long)total;
+    return QOIMI_OK;
+}
+
+extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t stream_stride,
+                                  const int* sizes, const qoi_desc* descs, int n_images, int channels,
+                                  void* d_pixels, size_t pixel_stride, void* stream) {
+    if (!c || !d_streams || !sizes || !descs || !d_pixels || n_images <= 0) return fail(QOIMI_E_ARG, "NULL/empty argument");
+    if (channels != 0 && channels != 3 && channels != 4) return fail(QOIMI_E_ARG, "channels must be 0, 3 or 4 (qoi.h:499)");
+    for (int i = 1; i < n_images && channels == 0; ++i)
+        if (descs[i].channels != descs[0].channels) return fail(QOIMI_E_ARG, "all images of a batch must share the output channel count");
+    const uint32_t B = choose_seg_bytes(c, sizes, n_images);
+    // The chunk records take four bytes per stream byte (worst case) while a call is in flight.  Calls whose streams would
+    // need more than dec_rec_cap are decoded as consecutive sub-batches of whole images through the same workspace.
+    const uint64_t cap_stream = c->dec_rec ? (uint64_t)(c->dec_rec_cap / 4u) - (uint64_t)(c->dec_rec_cap / 4u) / 64u : ~0ull;
+    long long acc[3] = {0, 0, 0};
+    for (int first = 0; first < n_images;) {
+        uint64_t bytes = 0;
+        int n = 0;
+        while (first + n < n_images) {
+            const uint64_t sz = (uint64_t)(sizes[first + n] > 0 ? sizes[first + n] : 0) + B;
+            if (n > 0 && bytes + sz > cap_stream) break;
+            bytes += sz; ++n;
+        }
+        long long st3[3] = {0, 0, 0};
+        const int rc = decode_some(c, (const uint8_t*)d_streams + (size_t)first * stream_stride, stream_stride, sizes + first, descs + first, n, channels,
+                                   (uint8_t*)d_pixels + (size_t)first * pixel_stride, pixel_stride, stream, B, n_images == 1, st3);
+        if (rc != QOIMI_OK) return rc;
+        acc[0] = st3[0] > acc[0] ? st3[0] : acc[0]; acc[1] += st3[1]; acc[2] += st3[2];
+        first += n;
+    }
+    c->dec_stats[0] = acc[0]; c->dec_stats[1] = acc[1]; c->dec_stats[2] = acc[2];
     return QOIMI_OK;
 }
 

@@ -219,3 +219,33 @@ def decode_cases(encoded: Dict[str, bytes]) -> List[Dict]:
             body = bytes(src)
         add(f"fuzz_{i}", header(w, h, 3 + (i & 1)) + body + END, (0, 3, 4)[i % 3])
     return cases
+
+
+def dense_record_streams():
+    """Streams whose segments are as dense in chunk records as the format allows: one-byte chunks up to the last byte of a
+    B-byte decode segment and a QOI_OP_RGBA that STARTS on that last byte (its five bytes reach into the next segment, both of
+    its records belong to this one) - B + 1 records from B bytes.  Round 2's first record pipeline reserved B and lost pixels on
+    1 frame in 60 of the `uiflat` content at 512-byte segments.  Yields (name, B, stream, width, height)."""
+    import struct
+    for B in (64, 128, 256, 512, 1024, 2048):
+        for lead in (0, 1, 3):                      # the dense segment as segment 0 / after a few other chunks
+            body = bytearray()
+            body += bytes([0xFE, 10, 20, 30])       # an RGB first, so runs and INDEX have something to repeat
+            while (len(body) + lead) % B != B - 1 or len(body) < 2 * B:
+                k = len(body) % 7
+                body.append(0xC0 | (k % 5) if k < 4 else (0x40 | (k * 9 & 0x3F)) if k < 6 else (k * 5 & 0x3F))
+            body = bytearray(bytes([0xC1] * lead)) + body
+            assert len(body) % B == B - 1
+            body += bytes([0xFF, 1, 2, 3, 0x80])    # starts on the last byte of its segment
+            body += bytes([0x6A, 0xC3, 0x15, 0xFF, 9, 8, 7, 6, 0x3F, 0xC0]) * 3
+            npx = 0
+            i = 0
+            while i < len(body):
+                b = body[i]
+                n = 4 if b == 0xFE else 5 if b == 0xFF else 2 if (b >> 6) == 2 else 1
+                npx += (b & 0x3F) + 1 if (b >> 6) == 3 and b < 0xFE else 1
+                i += n
+            w = 64
+            h = (npx + w - 1) // w + 1              # a few pixels past the last chunk: filled with the last pixel (qoi.h:544)
+            stream = b"qoif" + struct.pack(">II", w, h) + bytes([4, 0]) + bytes(body) + bytes([0, 0, 0, 0, 0, 0, 0, 1])
+            yield f"dense_B{B}_lead{lead}", B, stream, w, h

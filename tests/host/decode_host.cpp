@@ -26,16 +26,41 @@ struct Tab32 { uint32_t v[64]; uint32_t get(uint32_t k) const { return v[k]; } v
 
 // returns 0; stats[0] = rounds, stats[1] = segments re-decoded, stats[2] = segments
 // GRP: segments per group of the two-level chains (the kernels use 64)
+// mode 0: readable primitives, 1: lean LUT-driven primitives, 2: chunk records (transcode once, P3 / P4 read records)
 static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
-                    uint8_t* out, long long* stats, bool fast);
+                    uint8_t* out, long long* stats, int mode);
 extern "C" int host_decode_pipeline_g(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
                                       uint8_t* out, long long* stats) {
-    return pipeline(in, size, npx, och, B, GRP, out, stats, false);
+    return pipeline(in, size, npx, och, B, GRP, out, stats, 0);
 }
 // same pipeline on the lean LUT-driven primitives the kernels use
 extern "C" int host_decode_pipeline_fast(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
                                          uint8_t* out, long long* stats) {
-    return pipeline(in, size, npx, och, B, GRP, out, stats, true);
+    return pipeline(in, size, npx, och, B, GRP, out, stats, 1);
+}
+// the pipeline the round-2 kernels run: one transcode pass leaves fixed-width chunk records, P3 / P4 read those
+extern "C" int host_decode_pipeline_rec(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
+                                        uint8_t* out, long long* stats) {
+    return pipeline(in, size, npx, och, B, GRP, out, stats, 2);
+}
+// rec_of_chunk against crack() for every tag byte and a sweep of payloads; returns mismatches
+extern "C" int host_check_records(void) {
+    int bad = 0;
+    for (uint32_t b = 0; b < 256; ++b)
+        for (uint32_t pay = 0; pay < 4096; pay += 37) {
+            const unsigned long long w = (unsigned long long)b | ((unsigned long long)(pay * 0x9E3779B1u) << 8) | ((unsigned long long)(pay & 0xFF) << 40);
+            const Chunk c = crack(w);
+            uint32_t r[2];
+            const uint32_t k = rec_of_chunk(w, r);
+            if (k != (c.is_rgba ? 2u : 1u)) ++bad;
+            if (c.is_rel && (rec_class(r[0]) != 0u || (r[0] & 0xFFFFFFu) != c.delta || rec_pixels(r[0]) != 1u)) ++bad;
+            if (c.is_run && (rec_class(r[0]) != 0u || (r[0] & 0xFFFFFFu) != 0u || rec_pixels(r[0]) != chunk_run(c))) ++bad;
+            if (c.is_index && (rec_class(r[0]) != 1u || (r[0] & 0xFFFFFFu) != c.b1 || rec_pixels(r[0]) != 1u)) ++bad;
+            if (c.is_rgb && (rec_class(r[0]) != 2u || (r[0] & 0xFFFFFFu) != (c.rgba & 0xFFFFFFu) || rec_pixels(r[0]) != 1u)) ++bad;
+            if (c.is_rgba && (rec_class(r[0]) != 2u || rec_pixels(r[0]) != kRecStash || (r[0] & 0xFFFFFFu) != (c.rgba & 0xFFFFFFu) ||
+                              rec_class(r[1]) != 3u || (r[1] & 0xFFu) != (c.rgba >> 24) || rec_pixels(r[1]) != 1u)) ++bad;
+        }
+    return bad;
 }
 extern "C" int host_decode_pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B,
                                     uint8_t* out, long long* stats) {
@@ -53,7 +78,8 @@ extern "C" int host_check_lut(void) {
 }
 
 static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t B, uint32_t GRP,
-                    uint8_t* out, long long* stats, bool fast) {
+                    uint8_t* out, long long* stats, int mode) {
+    const bool fast = mode >= 1, recmode = mode == 2;
     ChunkLutRef lut; lut.build();
     const uint32_t chunks_end = (uint32_t)size - 8u;
     const uint32_t nseg = (chunks_end - 14u + B - 1u) / B;
@@ -100,6 +126,8 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
     std::vector<sym_t> summary((size_t)(nseg + 1) * 65u);
     std::vector<SlotRec> srec(nseg);
     std::vector<uint8_t> slot_in(nseg), alpha_in(nseg);
+    const uint32_t region = rec_region_dwords(B);              // records of one segment, padded to whole granules
+    std::vector<uint32_t> recs(recmode ? (size_t)nseg * region : 0u), rec_gran(nseg, 0u);
     if (nseg) entry[64] = 0xFF000000u;
     uint32_t start = 0, final_px = 0xFF000000u;
     long long rounds = 0, redo = 0;
@@ -117,7 +145,8 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
         if (!refine)
         for (uint32_t j = start; j < n_active; ++j) {
             const uint32_t base = 14u + j * B, end = base + B < chunks_end ? base + B : chunks_end;
-            if (fast) slot_walk_segment_fast(in, base + phase[j], end, lut, srec[j]); else slot_walk_segment(in, base + phase[j], end, srec[j]);
+            if (recmode) rec_gran[j] = transcode_segment(in, base + phase[j], end, lut, &recs[(size_t)j * region], srec[j]);
+            else if (fast) slot_walk_segment_fast(in, base + phase[j], end, lut, srec[j]); else slot_walk_segment(in, base + phase[j], end, srec[j]);
         }
         if (!refine)
         {   // S2, two-level: compose the transfers of each group, chain groups, apply inside groups
@@ -145,7 +174,8 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
             const uint32_t* ent = &entry[(size_t)j * 65u];
             const uint32_t a_in = alpha_in[j];
             auto hint = [&](uint32_t src) -> uint32_t { return refine ? ent[src] >> 24 : a_in; };
-            const sym_t px = fast ? summarize_segment_fast(in, base + phase[j], end, slot_in[j], alpha_in[j], lut, t, hint, j == 0 || !refine)
+            const sym_t px = recmode ? summarize_records(&recs[(size_t)j * region], rec_gran[j], slot_in[j], alpha_in[j], t, hint, j == 0 || !refine)
+                           : fast ? summarize_segment_fast(in, base + phase[j], end, slot_in[j], alpha_in[j], lut, t, hint, j == 0 || !refine)
                                   : summarize_segment(in, base + phase[j], end, slot_in[j], alpha_in[j], t, j == 0 || !refine);
             for (int k = 0; k < 64; ++k) summary[(size_t)j * 65u + k] = t.v[k];
             summary[(size_t)j * 65u + 64u] = px;
@@ -188,7 +218,9 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
             Tab32 t;
             memcpy(t.v, &entry[(size_t)j * 65u], 256);
             uint32_t px = entry[(size_t)j * 65u + 64u];
-            if (fast) px = och == 4 ? decode_segment_fast<4>(in, base + phase[j], end, px, lut, t, out, px_off[j], npx)
+            if (recmode) px = och == 4 ? decode_records<4>(&recs[(size_t)j * region], rec_gran[j], px, t, out, px_off[j], npx)
+                                       : decode_records<3>(&recs[(size_t)j * region], rec_gran[j], px, t, out, px_off[j], npx);
+            else if (fast) px = och == 4 ? decode_segment_fast<4>(in, base + phase[j], end, px, lut, t, out, px_off[j], npx)
                                     : decode_segment_fast<3>(in, base + phase[j], end, px, lut, t, out, px_off[j], npx);
             else px = och == 4 ? decode_segment<4>(in, base + phase[j], end, px, t, out, px_off[j], npx)
                                : decode_segment<3>(in, base + phase[j], end, px, t, out, px_off[j], npx);

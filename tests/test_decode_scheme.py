@@ -25,20 +25,21 @@ def host_lib(tmp_path_factory):
     src = os.path.join(ROOT, "tests", "host", "decode_host.cpp")
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src], check=True)
     lib = ctypes.CDLL(out)
-    for fn in (lib.host_decode_pipeline_g, lib.host_decode_pipeline_fast):
+    for fn in (lib.host_decode_pipeline_g, lib.host_decode_pipeline_fast, lib.host_decode_pipeline_rec):
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32,
                        ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
     return lib
 
 
-def run(lib, stream: bytes, och: int, B: int, grp: int = 64, fast: bool = False):
+def run(lib, stream: bytes, och: int, B: int, grp: int = 64, fast=False):
+    """fast: False = readable primitives, True = lean LUT-driven ones, "rec" = the chunk-record pipeline of the kernels"""
     w, h = struct.unpack(">II", stream[4:12])
     npx = w * h
     buf = np.frombuffer(stream + b"\0" * 8, dtype=np.uint8).copy()
     out = np.full(npx * och + 8, 0xAB, dtype=np.uint8)
     stats = (ctypes.c_longlong * 4)()
-    fn = lib.host_decode_pipeline_fast if fast else lib.host_decode_pipeline_g
+    fn = lib.host_decode_pipeline_rec if fast == "rec" else lib.host_decode_pipeline_fast if fast else lib.host_decode_pipeline_g
     fn(buf.ctypes.data, len(stream), npx, och, B, grp, out.ctypes.data, stats)
     return out[:npx * och], list(stats)
 
@@ -52,7 +53,7 @@ def test_scheme_matches_golden(host_lib, golden, encoded_streams):
         och = c["channels"] if c["channels"] else int(desc[2])
         want = golden[f"dec/{c['name']}/pixels"]
         for B, grp in ((5, 3), (7, 64), (16, 2), (64, 5), (333, 64), (2048, 64)):
-            for fast in (False, True):            # readable primitives and the lean LUT-driven ones the kernels use
+            for fast in (False, True, "rec"):     # readable primitives, the lean LUT-driven ones, the record pipeline of the kernels
                 got, stats = run(host_lib, c["stream"], och, B, grp, fast)
                 assert np.array_equal(got, want), (c["name"], B, grp, fast, stats)
         n += 1
@@ -64,13 +65,18 @@ def test_chunk_lut_matches_grammar(host_lib):
     assert host_lib.host_check_lut() == 0
 
 
+def test_chunk_records_match_grammar(host_lib):
+    """rec_of_chunk (the transcoder's record per chunk) carries exactly what crack() reads from the chunk bytes."""
+    assert host_lib.host_check_records() == 0
+
+
 def test_speculation_holds_on_encoder_streams(host_lib, port):
     """Encoder-made opaque content must verify in ONE round (no restart)."""
     for kind in ("photo", "noise", "constant"):
         w, h = 256, 192
         px = synth.frame_rgba(kind, w, h, 2)
         s = port.encode(px, w, h, 4)
-        for fast in (False, True):
+        for fast in (False, True, "rec"):
             got, stats = run(host_lib, s, 4, 256, 64, fast)
             assert np.array_equal(got, px.reshape(-1))
             assert stats[0] == 1 and stats[1] == 0, (kind, fast, stats)
@@ -80,5 +86,18 @@ def test_uiflat_exact_even_if_restarts(host_lib, port):
     w, h = 400, 300
     px = synth.frame_rgba("uiflat", w, h, 1)
     s = port.encode(px, w, h, 4)
-    got, stats = run(host_lib, s, 4, 64)
-    assert np.array_equal(got, px.reshape(-1))
+    for fast in (False, "rec"):
+        got, stats = run(host_lib, s, 4, 64, 64, fast)
+        assert np.array_equal(got, px.reshape(-1))
+
+
+def test_record_dense_segments(host_lib, port):
+    """B + 1 records from a B-byte segment (cases.dense_record_streams): the record region of a segment must hold them."""
+    n = 0
+    for name, B, stream, w, h in cases.dense_record_streams():
+        want, _ = port.decode(stream, 4)
+        for fast in (True, "rec"):
+            got, stats = run(host_lib, stream, 4, B, 64, fast)
+            assert np.array_equal(got, want), (name, fast, stats)
+        n += 1
+    assert n == 18

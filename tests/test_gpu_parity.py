@@ -101,6 +101,26 @@ def test_decode_small_segments(api, golden, encoded_streams, seg):
         del os.environ["QOIMI_SEG_BYTES"]
 
 
+def test_decode_record_dense_segments(api, oracle):
+    """A QOI_OP_RGBA chunk that starts on the last byte of a decode segment full of one-byte chunks: B + 1 chunk records
+    from B stream bytes (cases.dense_record_streams) - at every segment size the cost model can pick."""
+    import torch
+    for name, B, stream, w, h in cases.dense_record_streams():
+        want, _ = oracle.decode(stream, 4)
+        os.environ["QOIMI_SEG_BYTES"] = str(B)
+        try:
+            c = api.Context(0)
+            d = api.QoiDesc(w, h, 4, 0)
+            s = torch.from_numpy(np.frombuffer(stream + b"\0" * 8, dtype=np.uint8).copy()).cuda()
+            out = torch.full((w * h * 4 + 8,), 0xAB, dtype=torch.uint8, device="cuda")
+            c.decode_batch(s.data_ptr(), s.numel(), [len(stream)], [d], 4, out.data_ptr(), w * h * 4)
+            assert np.array_equal(out[:w * h * 4].cpu().numpy(), want), name
+            assert int(out[w * h * 4]) == 0xAB, "wrote past the image"
+            c.close()
+        finally:
+            del os.environ["QOIMI_SEG_BYTES"]
+
+
 def test_round_trip_random_host_api(api, oracle):
     rng = np.random.default_rng(7)
     for it in range(40):
