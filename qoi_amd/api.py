@@ -233,4 +233,4 @@ class Context:
     def decode_stats(self) -> dict:
         out = (ctypes.c_longlong * 4)()
         self._lib.qoimi_decode_stats(self._h, out)
-        return {"rounds": out[0], "redo_segments": out[1], "segments": out[2]}
+        return {"rounds": out[0], "redo_segments": out[1], "segments": out[2], "sync_fallback_segments": out[3]}

@@ -425,11 +425,16 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     __shared__ uint32_t s_res[4][64][2];          // per (group, entry phase): exit phase, pixels
     __shared__ LdsLut s_lut;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    if (!TAIL && *p.sync_fails == 0u) return;              // record pipeline: nothing to parse (dec_transcode synchronised every segment)
     build_lut(s_lut, threadIdx.x, 256u);
     const uint32_t G = p.fine_per_seg, gs = p.fine_shift;
     const uint32_t F = blockIdx.x * 256u + threadIdx.x;
     const uint32_t q = F >> gs, sub = F & (G - 1u);
-    const bool have = q < p.total_segs;
+    bool have = q < p.total_segs;
+    if (!TAIL) {                                          // only the segments dec_transcode could not synchronise
+        have = have && p.sync_fail[have ? q : 0u] != 0u;
+        if (!lanes_where(have)) return;
+    }
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
@@ -1642,14 +1647,29 @@ typedef LaneReaderT<QOIMI_TR_RD, QOIMI_TR_NP, QOIMI_TR_PERIOD, 8, QOIMI_TR_LINE 
 constexpr uint32_t kTrThreads = 64u * QOIMI_TR_WAVES;
 struct LdsLutT { uint32_t tpl[256], info[256]; };   // record template; chunk-table word with QOI_OP_RGBA's length set to 0 (visited twice)
 
-// P2 + transcode: lane = segment.  Walks every chunk that starts in the segment from its true entry position (S1),
-// writes the chunk records of the segment as 16-byte granules from the start of its region (null-padded) and leaves
-// the speculative slot/alpha transfer (slot_rec, same function as dec_slot_walk).  A QOI_OP_RGBA chunk is visited in
-// two consecutive steps (stash record, alpha record); only the second advances the cursor.
+// Parse + P2 + transcode: lane = segment.  Walks every chunk that starts in the segment, writes the chunk records of the
+// segment as 16-byte granules (row g of the wavefront's block, null-padded), counts the pixels and leaves the speculative
+// slot/alpha transfer (slot_rec, same function as dec_slot_walk).  A QOI_OP_RGBA chunk is visited in two consecutive steps
+// (stash record, alpha record); only the second advances the cursor.
+//
+// MODE 0 - where does the segment's first chunk start?  Chunk length is a function of the first byte (qoi.h:547-575), so
+// parse chains that meet stay together.  The lane starts FIVE chains kSyncBytes before its segment, on five consecutive
+// bytes: a chunk is at most five bytes long, so the stream's true chain stands on one of them.  Once all five have met -
+// in a natural image after a handful of chunks - their common continuation is the true chain whatever the phase was, and
+// the first position at or behind the segment start is the entry position: EXACT, not a guess.  The separate parse pass
+// (dec_parse_fine + its five-phase records) is then not needed: the lane writes a parse record that holds the same for
+// all five phases, and S1 chains those as before (pixel offsets, n_active).  Chains that have not met when they reach
+// the segment (runs of equally long multi-byte chunks: QOI_OP_RGBA noise never meets) flag the segment; flagged segments
+// get the full five-phase parse (dec_parse_fine, which returns at once when there are none) and are transcoded by MODE 1
+// from the entry phase S1 then knows.
+// MODE 1 - segments flagged by MODE 0 (all active ones if DecParams::sync_all), entry phase from S1.
+constexpr uint32_t kSyncBytes = 64;
+template <int MODE>
 __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     __shared__ uint32_t s_ring[QOIMI_TR_WAVES][TransReader::kSlots * 64];
     __shared__ LdsLutT s_lut;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    if (MODE == 1 && !p.sync_all && *p.sync_fails == 0u) return;
     for (uint32_t b = threadIdx.x; b < 256u; b += kTrThreads) {
         uint32_t d, i; lut_entry(b, d, i);
         s_lut.tpl[b] = rec_template(b);
@@ -1661,45 +1681,76 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
-    have = have && j >= im.start_seg && j < im.n_active;
+    if (MODE == 1) have = have && j >= im.start_seg && j < im.n_active && (p.sync_all || p.sync_fail[q] != 0u);
     if (!lanes_where(have)) return;
     const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
-    uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
-    TransReader R;
-    R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
     const uint32_t lut_base = lds_addr_of(&s_lut.tpl[0]);
-    bool active = have && pos < end;
+    TransReader R;
+    uint32_t pos;
+    bool failed = false;
+    if (MODE == 1) {
+        pos = base + (have ? p.entry_phase[q] : 0u);
+        R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
+    } else {
+        // ---- look-back synchronisation ------------------------------------------------------------------------------
+        const bool from_start = base <= (uint32_t)kHeaderBytes + kSyncBytes;      // the stream's first chunk is in reach: one chain from byte 14
+        const uint32_t t0 = from_start ? (uint32_t)kHeaderBytes : base - kSyncBytes;
+        R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, t0, im.chunks_end + kTrailerBytes);
+        ParseState s; parse_init(s, t0);
+        if (from_start) { s.p1 = s.p2 = s.p3 = s.p4 = t0; }
+        uint32_t m = t0;
+        bool merged = from_start;
+        bool going = have && m < base;
+        for (uint32_t it = 0; lanes_where(going); ++it) {
+            if (R.due(it)) R.refill(m);
+            if (going) {
+                uint32_t w32, b5; R.peek(m, w32, b5);
+                const uint32_t b1 = w32 & 0xFFu;
+                if (!merged) {
+                    parse_step(s, m, b1);
+                    m = parse_front(s);
+                    merged = s.p0 == s.p1 && s.p1 == s.p2 && s.p2 == s.p3 && s.p3 == s.p4;
+                } else {
+                    m += len_of(b1);
+                }
+                going = m < base;
+            }
+        }
+        failed = have && !merged;
+        pos = m;                                              // merged: the first chunk start at or behind the segment start
+        // the ring was refilled for the front position; the walk below continues the same byte stream
+        const u64 fails = lanes_where(failed);
+        if (have) p.sync_fail[q] = failed ? 1 : 0;
+        if (fails != 0 && lane == (uint32_t)__builtin_ctzll(fails)) atomicAdd(p.sync_fails, (uint32_t)__builtin_popcountll(fails));
+        R.refill(pos);                                        // lands what the last period asked for, asks from the entry position on
+    }
+    bool active = have && !failed && pos < end;
     uint32_t w32, b5; R.peek(pos, w32, b5);
     uint32_t tpl, info;
     {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); tpl = lq[0]; info = lq[256]; }
     SlotFast st; slotf_init(st);
     uint32_t pend = 0u;                          // 1: the stash record of the QOI_OP_RGBA chunk under the cursor is out
     bool any_pend = false;
-    uint32_t ngran = 0u;
+    uint32_t ngran = 0u, npix = 0u;
     // granule row g of this wavefront's 64 segments: one contiguous KiB
     u32x4* dst = reinterpret_cast<u32x4*>(p.recs + (size_t)(blockIdx.x * QOIMI_TR_WAVES + wave) * p.rec_rows * 256u) + lane;
     while (lanes_where(active)) {
         R.land(); R.issue(pos);
 #pragma unroll
-            for (uint32_t g = 0; g < TransReader::kPeriod / 4u; ++g) {
+        for (uint32_t g = 0; g < TransReader::kPeriod / 4u; ++g) {
             const bool live = active;                                    // the granule holds at least one record of this lane
             uint32_t rr[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) {
                 const uint32_t c_info = active ? info : 0u;
                 uint32_t rec = active ? tpl : 0u;                        // null record once the lane is through
-#ifdef QOIMI_TR_LEN_ARITH
-                // chunk length by arithmetic on the tag byte: keeps the chunk table's LDS round trip out of the cursor's chain
-                uint32_t adv = active ? len_of(w32 & 0xFFu) : 0u;
-                adv = (w32 & 0xFFu) == 0xFFu ? 0u : adv;             // QOI_OP_RGBA: first visit, see below
-#else
                 uint32_t adv = lut_len(c_info);
-#endif
                 // byte-wise delta of a relative chunk: table part + the second byte of a LUMA chunk (qoi.h:566-571)
                 const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)c_info, 28, 1);      // all ones for LUMA
                 const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
                 add_byte0(rec, er); add_byte2_from0(rec, eb);
+                uint32_t cnt = (rec >> 24) & 63u;                        // pixels of the chunk (qoi.h:573-575); the stash marker is set right below
                 // speculative slot/alpha transfer (slotf_step_split): QOI_COLOR_HASH is linear mod 64, so a relative chunk
                 // shifts the slot by the hash of its delta; QOI_OP_INDEX names it
                 const bool lo = lut_lo(c_info);
@@ -1713,6 +1764,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                     const uint32_t rec_hi = second ? rec_make(3u, 1u, b5) : (rec | rgb);      // rec still is the class-2 template here
                     rec = hi ? rec_hi : rec;
                     adv = second ? 5u : adv;
+                    cnt = first ? 0u : (second ? 1u : cnt);
                     const bool a_abs = (st.fl & 4u) != 0u;
                     const uint32_t lrgb = __builtin_amdgcn_udot4(rgb, 0x00070503u, 0u, false);
                     const uint32_t hb = lrgb + (lo ? 11u * b5 : (a_abs ? 11u * st.ac : 0u));
@@ -1724,6 +1776,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                     any_pend = lanes_where(pend != 0u) != 0;
                 }
                 st.hc = hc & 63u; st.fl = fl;
+                npix += cnt;
                 const uint32_t npos = pos + adv;
                 uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
                 const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
@@ -1735,9 +1788,21 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
             if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; dst[(size_t)ngran * 64u] = v; ++ngran; }
         }
     }
-    if (have) {
+    if (have && !failed) {
         p.rec_gran[q] = ngran;
         SlotRec r; slotf_finish(st, r); p.slot_rec[q] = r;
+        if (MODE == 0) {
+            // parse record for S1: the same whatever entry phase S1 asks for - it only ever asks for the true one
+            const uint32_t nominal = base + p.seg_bytes;
+            const uint32_t e = pos > nominal ? pos - nominal : 0u;      // bytes the last chunk reaches into the next segment
+            ParseRec pr;
+            pr.exit_phase = e * (1u | (1u << 3) | (1u << 6) | (1u << 9) | (1u << 12));
+#pragma unroll
+            for (int k = 0; k < 5; ++k) pr.pixels[k] = npix;
+            p.parse[q] = pr;
+        }
+    } else if (have && MODE == 0) {
+        p.rec_gran[q] = 0u;
     }
 }
 
@@ -2134,8 +2199,12 @@ __global__ __launch_bounds__(64) void dec_prepare_restart(DecParams p) {
 void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
     tm->mark(kT_begin, st);
     if (p.total_segs) {
-        if (p.fine_per_seg && p.use_rec) hipLaunchKernelGGL(dec_parse_fine<false>, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
-        else if (p.fine_per_seg) hipLaunchKernelGGL(dec_parse_fine<true>, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+        if (p.use_rec && !p.sync_all) {
+            // parse + transcode in one walk (dec_transcode<0>); the five-phase parse only for the segments it flags
+            hipLaunchKernelGGL(dec_transcode<0>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
+            tm->mark(kT_dec_slot_walk, st);
+            hipLaunchKernelGGL(dec_parse_fine<false>, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+        } else if (p.fine_per_seg) hipLaunchKernelGGL(dec_parse_fine<true>, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(dec_parse, dim3((p.total_segs + 255u) / 256u), dim3(256), 0, st, p);
         tm->mark(kT_dec_parse, st);
         hipLaunchKernelGGL(dec_chain_parse_l1, dim3(p.total_grps), dim3(64), 0, st, p);
@@ -2156,7 +2225,7 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
         else hipLaunchKernelGGL(dec_summarize<true>, dim3(b64), dim3(64), 0, st, p);
         tm->mark(kT_dec_summarize, st);
     } else {
-    if (p.use_rec) hipLaunchKernelGGL(dec_transcode, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
+    if (p.use_rec) hipLaunchKernelGGL(dec_transcode<1>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
     else if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_heads_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(dec_slot_walk, dim3(b256), dim3(256), 0, st, p);
     tm->mark(kT_dec_slot_walk, st);

@@ -182,7 +182,7 @@ extern "C" int qoimi_get_profile(qoimi_ctx* c, void* stream, double* ms, long lo
 
 extern "C" const char* qoimi_kernel_name(int i) {
     static const char* names[kT_count] = {"", "enc_slab_summary", "enc_scan_groups", "enc_scan_images", "enc_slabs", "enc_slabs_generic", "enc_offsets", "enc_compact",
-        "dec_parse", "dec_chain_parse", "dec_slot_walk", "dec_chain_slots", "dec_summarize", "dec_chain_state",
+        "dec_parse", "dec_chain_parse", "dec_transcode", "dec_chain_slots", "dec_summarize", "dec_chain_state",
         "dec_segments", "dec_prepare_restart", "dec_fill"};
     return (i >= 0 && i < kT_count) ? names[i] : "";
 }
@@ -299,7 +299,7 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, int n_ima
 // one sub-batch: everything of qoimi_decode_batch for images whose record arena fits dec_rec_cap
 static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride,
                        const int* sizes, const qoi_desc* descs, int n_images, int channels,
-                       void* d_pixels, size_t pixel_stride, void* stream, uint32_t B, bool lone_image, long long stats[3]) {
+                       void* d_pixels, size_t pixel_stride, void* stream, uint32_t B, bool lone_image, long long stats[4]) {
     int och = 0;
     std::vector<DecImage> imgs((size_t)n_images);
     uint64_t total = 0, total_g = 0;
@@ -335,6 +335,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.pair = (uint32_t)c->dec_pair & 3u;
     p.use_rec = c->dec_rec ? 1u : 0u;
     p.rec_rows = rec_region_dwords(B) / 4u;
+    p.sync_all = 0;
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
     const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
     {   // P1/P2 on 128-byte pieces when a segment is 1, 8, 16, 32 or 64 of them
@@ -344,10 +345,11 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.fine_shift = 0;
         while (ok && (1u << p.fine_shift) < g) ++p.fine_shift;
         if ((uint64_t)total * (p.fine_per_seg ? p.fine_per_seg : 1u) > 0xFFFFFF00ull) return fail(QOIMI_E_ARG, "batch too large (piece index overflows 32 bits)");
+        p.sync_all = (p.use_rec && !p.fine_per_seg) ? 1u : 0u;     // no piece parse for this segment size: full parse, then transcode from S1's phases
     }
     for (int pass = 0; pass < 2; ++pass) {
         Carver w(pass ? c->dec_ws.base : nullptr);
-        p.pending = w.take<uint32_t>(2); p.redo_segs = p.pending ? p.pending + 1 : nullptr;
+        p.pending = w.take<uint32_t>(4); p.redo_segs = p.pending ? p.pending + 1 : nullptr; p.sync_fails = p.pending ? p.pending + 2 : nullptr;
         p.images = w.take<DecImage>((size_t)n_images);
         p.first_bad = w.take<uint32_t>((size_t)n_images);
         p.fine_exit = w.take<uint16_t>(p.fine_per_seg ? Q * p.fine_per_seg : 1);
@@ -361,6 +363,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.grp_slot = w.take<SlotRec>(NG); p.grp_slot_in = w.take<uint8_t>(NG); p.grp_alpha_in = w.take<uint8_t>(NG);
         p.grp_summary = w.take<u64>(NG * 65); p.grp_entry = w.take<uint32_t>(NG * 65);
         p.rec_gran = w.take<uint32_t>(p.use_rec ? Q : 1);
+        p.sync_fail = w.take<uint8_t>(p.use_rec ? Q : 1);
         p.recs = w.take<uint32_t>(p.use_rec ? ((Q + 63u) / 64u) * p.rec_rows * 256u : 4);
         if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }
     }
@@ -376,7 +379,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         memcpy(c->pin_buf, imgs.data(), bytes);
         HIP_TRY(hipMemcpyAsync(p.images, c->pin_buf, bytes, hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(hipMemsetAsync(p.redo_segs, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(p.redo_segs, 0, 2 * sizeof(uint32_t), st));       // redo_segs, sync_fails
 
     launch_decode_parse(p, st, &c->timer);
     long long rounds = 0;
@@ -388,7 +391,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         // so that the one synchronisation per round also ends the call
         launch_decode_fill(p, och, st, &c->timer);
         if (!p.total_segs) { HIP_TRY(hipStreamSynchronize(st)); break; }
-        HIP_TRY(hipMemcpyAsync(c->host_word, p.pending, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(c->host_word, p.pending, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         timer_collect(c);
         if (c->host_word[0] == 0) break;
@@ -399,6 +402,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     stats[0] = rounds;
     stats[1] = p.total_segs ? c->host_word[1] : 0;
     stats[2] = (long long)total;
+    stats[3] = p.total_segs ? c->host_word[2] : 0;
     return QOIMI_OK;
 }
 
@@ -413,7 +417,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     // The chunk records take four bytes per stream byte (worst case) while a call is in flight.  Calls whose streams would
     // need more than dec_rec_cap are decoded as consecutive sub-batches of whole images through the same workspace.
     const uint64_t cap_stream = c->dec_rec ? (uint64_t)(c->dec_rec_cap / 4u) - (uint64_t)(c->dec_rec_cap / 4u) / 64u : ~0ull;
-    long long acc[3] = {0, 0, 0};
+    long long acc[4] = {0, 0, 0, 0};
     for (int first = 0; first < n_images;) {
         uint64_t bytes = 0;
         int n = 0;
@@ -422,14 +426,14 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
             if (n > 0 && bytes + sz > cap_stream) break;
             bytes += sz; ++n;
         }
-        long long st3[3] = {0, 0, 0};
+        long long st3[4] = {0, 0, 0, 0};
         const int rc = decode_some(c, (const uint8_t*)d_streams + (size_t)first * stream_stride, stream_stride, sizes + first, descs + first, n, channels,
                                    (uint8_t*)d_pixels + (size_t)first * pixel_stride, pixel_stride, stream, B, n_images == 1, st3);
         if (rc != QOIMI_OK) return rc;
-        acc[0] = st3[0] > acc[0] ? st3[0] : acc[0]; acc[1] += st3[1]; acc[2] += st3[2];
+        acc[0] = st3[0] > acc[0] ? st3[0] : acc[0]; acc[1] += st3[1]; acc[2] += st3[2]; acc[3] += st3[3];
         first += n;
     }
-    c->dec_stats[0] = acc[0]; c->dec_stats[1] = acc[1]; c->dec_stats[2] = acc[2];
+    c->dec_stats[0] = acc[0]; c->dec_stats[1] = acc[1]; c->dec_stats[2] = acc[2]; c->dec_stats[3] = acc[3];
     return QOIMI_OK;
 }
 

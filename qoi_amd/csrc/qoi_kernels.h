@@ -122,6 +122,9 @@ struct DecParams {
     uint32_t* first_bad;       // [n_images] min failing segment, 0xFFFFFFFF: none
     uint32_t* pending;         // [1] images that need another round
     uint32_t* redo_segs;       // [1] statistics
+    uint32_t sync_all;         // 1: no look-back synchronisation - every segment takes the full parse (segment sizes the 128-byte piece parse does not cover)
+    uint32_t* sync_fails;      // [1] segments whose look-back synchronisation failed in dec_transcode (they take the full parse)
+    uint8_t*  sync_fail;       // [total_segs + 1] 1: the segment's entry position is not known yet (dec_transcode<0>)
 };
 
 void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm);
