@@ -74,7 +74,9 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_
 // LINE_: the ring is topped up only by whole, 64-byte aligned lines (NP_ x 16 bytes issued together, or nothing).  With many
 // long-lived lanes per CU (dec_transcode: 512) a lane's 16-byte loads come too far apart for its cache line to still be in the
 // L2 the next time (32 K lane streams per XCD on 32 K L2 lines): every line was fetched from HBM several times.
-template <int RD_, int NP_, int PERIOD_, int LOOK_ = 8, bool LINE_ = false>
+// DELAY_ (with LINE_): the loads land DELAY_ periods after the period that follows their issue - at most one line is in
+// flight, and it gets 2 * PERIOD_ steps (about a microsecond) to arrive before a wavefront waits for it.
+template <int RD_, int NP_, int PERIOD_, int LOOK_ = 8, bool LINE_ = false, int DELAY_ = 0>
 struct LaneReaderT {
     static constexpr uint32_t RD = RD_;
     static constexpr uint32_t kSlots = RD + 1;
@@ -89,6 +91,7 @@ struct LaneReaderT {
     uint32_t aoff;             // abase - stream: stream position p sits at ring byte (p - aoff)
     uint32_t wr;               // dwords landed in the ring, counted from abase
     uint4 pend[NP_]; uint32_t npend;
+    uint32_t age;              // DELAY_: periods the pending line has been in flight
 
     __device__ __forceinline__ uint4 load16(const uint8_t* p) const {
         // An aligned 16-byte granule that starts inside the stream never crosses a page.  A granule past the end is
@@ -118,7 +121,7 @@ struct LaneReaderT {
 #pragma unroll
         for (uint32_t r = 0; r < RD / 4u; ++r) put4(4u * r, load16(abase + 16u * r));
         }
-        wr = RD; npend = 0;
+        wr = RD; npend = 0; age = 0;
     }
     // chunk bytes 0..3 (w32) and byte 4 (b5) of the chunk at stream position pos
     __device__ __forceinline__ void peek(uint32_t pos, uint32_t& w32, uint32_t& b5) const {
@@ -135,12 +138,33 @@ struct LaneReaderT {
     // shortly before land() would make that wait a wait for the store's acknowledgement; issued a whole
     // period earlier it has long completed.
     __device__ __forceinline__ void land() {
+        if (DELAY_ > 0) {
+            // wave-uniform: the oldest pending line of any lane decides (lanes issue when THEY have room; a lane whose line is
+            // younger lands it a little early - it was asked for at least one period ago, see issue())
+            const bool due_now = lanes_where(npend != 0u && age >= (uint32_t)DELAY_) != 0;
+            if (due_now) {
+#pragma unroll
+                for (int i = 0; i < NP_; ++i) if ((uint32_t)i < npend) put4(wr + 4u * i, pend[i]);
+                wr += 4u * npend; npend = 0u;
+            }
+            age += npend ? 1u : 0u;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NP_; ++i) if ((uint32_t)i < npend) put4(wr + 4u * i, pend[i]);
         wr += 4u * npend;
     }
     __device__ __forceinline__ void issue(uint32_t pos) {
         const uint32_t space = RD - (wr - ((pos - aoff) >> 2));
+        if (DELAY_ > 0) {
+            const bool go = npend == 0u && (space >> 2) >= (uint32_t)NP_;
+            if (lanes_where(go)) {
+#pragma unroll
+                for (int i = 0; i < NP_; ++i) if (go) pend[i] = load16(abase + (size_t)wr * 4u + 16u * i);
+                if (go) { npend = (uint32_t)NP_; age = 0u; }
+            }
+            return;
+        }
         npend = LINE_ ? ((space >> 2) >= (uint32_t)NP_ ? (uint32_t)NP_ : 0u) : min((uint32_t)NP_, space >> 2);
 #pragma unroll
         for (int i = 0; i < NP_; ++i) if ((uint32_t)i < npend) pend[i] = load16(abase + (size_t)wr * 4u + 16u * i);
@@ -1631,19 +1655,24 @@ __global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
 // codes): EIGHT per CU, each stepping through ~35-40 instructions per chunk with its records arriving as 16-byte
 // buffer loads a block of eight steps ahead - no LDS ring, no cursor, a wave-uniform loop count.
 // =====================================================================================
-// ring of 32 dwords, topped up by 32-byte pieces every 4 steps: 8.4 KiB per wavefront, sixteen wavefronts per CU (measured
-// against a 64-dword ring with whole 64-byte lines and eight per CU: 3.6 vs 4.0 ms per 256 4K frames - the walk is a chain of
-// LDS round trips and wants the wavefronts more than the line-sized loads)
+// Ring of 64 dwords per lane, topped up by whole 128-byte lines (8 x 16 bytes issued together) that land two periods of four
+// steps later.  With 32-byte pieces (16 wavefronts per CU) the pass moved 17.8 GB per 256 4K frames in 3.8 ms - it was
+// bound by HBM on its own re-reads: FETCH_SIZE 3.6 x the stream bytes, a lane's next piece of a line came after the line
+// had left the L2 (profiles/r02).  A lane now asks for every line exactly once.
 #ifndef QOIMI_TR_RD
 #define QOIMI_TR_RD 32
 #define QOIMI_TR_NP 2
 #define QOIMI_TR_PERIOD 4
 #define QOIMI_TR_LINE 1
+#define QOIMI_TR_DELAY 0
+#endif
+#ifndef QOIMI_TR_DELAY
+#define QOIMI_TR_DELAY 0
 #endif
 #ifndef QOIMI_TR_WAVES
 #define QOIMI_TR_WAVES 4
 #endif
-typedef LaneReaderT<QOIMI_TR_RD, QOIMI_TR_NP, QOIMI_TR_PERIOD, 8, QOIMI_TR_LINE != 0> TransReader;
+typedef LaneReaderT<QOIMI_TR_RD, QOIMI_TR_NP, QOIMI_TR_PERIOD, 8, QOIMI_TR_LINE != 0, QOIMI_TR_DELAY> TransReader;
 constexpr uint32_t kTrThreads = 64u * QOIMI_TR_WAVES;
 struct LdsLutT { uint32_t tpl[256], info[256]; };   // record template; chunk-table word with QOI_OP_RGBA's length set to 0 (visited twice)
 
@@ -1956,9 +1985,11 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
 // cycles of the first dec_segments_rec were spent there, waiting for store acknowledgements.
 // Group stores go through a descriptor based at the image of the wavefront's first segment (32-bit offsets); a lane whose
 // image lies 2 GiB or more behind that base (never with sane strides) uses plain stores on a rare path.
-template <int OCH>
-struct BurstWriter : LaneWriter<OCH, 32, 16> {
-    typedef LaneWriter<OCH, 32, 16> Base;
+template <int OCH, uint32_t RING_ = 32, uint32_t GROUP_ = 16>
+struct BurstWriter : LaneWriter<OCH, RING_, GROUP_> {
+    typedef LaneWriter<OCH, RING_, GROUP_> Base;
+    static constexpr uint32_t kG = GROUP_;
+    static_assert(RING_ == 2u * GROUP_ && (GROUP_ == 16u || GROUP_ == 8u), "a ring of two groups");
     __amdgpu_buffer_rsrc_t rs;
     uint32_t boff;         // byte offset of the lane's image in the descriptor; kFar: not addressable through it
     static constexpr uint32_t kFar = 0xFFFFFFFFu, kNowhere = 0x7FFFFFF0u, kRange = 0x7FFF0000u;
@@ -1970,29 +2001,30 @@ struct BurstWriter : LaneWriter<OCH, 32, 16> {
     }
     __device__ __forceinline__ void drain_block() {
         // head of a segment / after a long run: up to the next group boundary pixel by pixel (LaneWriter::drain's first loop)
-        if (__builtin_expect(lanes_where((this->fpos & 15u) != 0u && this->fpos < this->ppos) != 0, 0)) {
-            while ((this->fpos & 15u) != 0u && this->fpos < this->ppos) {
+        if (__builtin_expect(lanes_where((this->fpos & (kG - 1u)) != 0u && this->fpos < this->ppos) != 0, 0)) {
+            while ((this->fpos & (kG - 1u)) != 0u && this->fpos < this->ppos) {
                 if ((this->fpos & 3u) == 0u && this->fpos + 4u <= this->ppos) { this->store4(this->fpos, this->at(this->fpos), this->at(this->fpos + 1u), this->at(this->fpos + 2u), this->at(this->fpos + 3u)); this->fpos += 4u; }
                 else { this->store_one(this->fpos, this->at(this->fpos)); ++this->fpos; }
             }
         }
-        const bool ready = (this->fpos & 15u) == 0u && this->ppos - this->fpos >= 16u;
+        const bool ready = (this->fpos & (kG - 1u)) == 0u && this->ppos - this->fpos >= kG;
         if (__builtin_expect(lanes_where(ready && boff == kFar) != 0, 0)) {           // image out of the descriptor's reach
             if (ready && boff == kFar) Base::drain();
         }
         const bool go = ready && boff != kFar;
         if (OCH == 4) {
-            // Cooperative: the 64 bytes of an owner's group are written by FOUR ADJACENT LANES, 16 bytes each (lane t: piece t & 3
-            // of owner (t >> 2) + 16 j in instruction j) - 16 contiguous 64-byte lines per instruction instead of 64 scattered
-            // 16-byte pieces.  The address path of the CU was the limit with one piece per lane (~230 CU-cycles per store
+            // Cooperative: the bytes of an owner's group are written by kG/4 ADJACENT LANES, 16 bytes each (lane t: piece
+            // t % (kG/4) of owner t / (kG/4) + (256/kG) j in instruction j) - contiguous 4 kG-byte pieces instead of 64 scattered
+            // 16-byte ones.  The address path of the CU was the limit with one piece per lane (~230 CU-cycles per store
             // instruction, SQ_WAIT_INST_ANY 43 % of the wavefront cycles, profiles/r02).
+            constexpr uint32_t kLpo = kG / 4u, kOwners = 64u / kLpo;                // lanes per owner, owners per instruction
             const uint32_t lane = (this->row >> 2) & 63u;
             const uint32_t A = go ? boff + this->fpos * 4u : kNowhere;            // the group's byte offset in the descriptor
-            const uint32_t rb = this->fpos & 16u;                                  // the group is rows 0..15 or 16..31 of the ring
-            const uint32_t piece = lane & 3u;
+            const uint32_t rb = this->fpos & kG;                                   // the group is the lower or the upper half of the ring
+            const uint32_t piece = lane & (kLpo - 1u);
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-                const uint32_t owner = (lane >> 2) + 16u * j;
+            for (uint32_t j = 0; j < kLpo; ++j) {
+                const uint32_t owner = lane / kLpo + kOwners * j;
                 const uint32_t Ao = gather_lane(A, owner), rbo = gather_lane(rb, owner);
                 const uint32_t raddr = this->row - lane * 4u + owner * 4u + ((rbo + 4u * piece) << 8);
                 u32x4 w;
@@ -2000,26 +2032,32 @@ struct BurstWriter : LaneWriter<OCH, 32, 16> {
                 __builtin_amdgcn_raw_buffer_store_b128(w, rs, Ao + 16u * piece, 0, 0);    // kNowhere + 48 is still outside
             }
         } else {
-        const uint32_t rbase = this->row + ((this->fpos & 16u) << 8);                 // the group is rows 0..15 or 16..31 of the ring
-        uint32_t v[16];
+            const uint32_t rbase = this->row + ((this->fpos & kG) << 8);
+            uint32_t v[kG];
 #pragma unroll
-        for (uint32_t k = 0; k < 16u; ++k) v[k] = *(const lds_u32*)(rbase + k * 256u);
-        const uint32_t off = go ? boff + this->fpos * (uint32_t)OCH : kNowhere;
-        {                                                                             // 16 pixels -> 12 dwords of packed r,g,b
-            uint32_t d[12];
+            for (uint32_t k = 0; k < kG; ++k) v[k] = *(const lds_u32*)(rbase + k * 256u);
+            const uint32_t off = go ? boff + this->fpos * (uint32_t)OCH : kNowhere;
+            uint32_t d[3u * kG / 4u];                                             // kG pixels -> 3 kG / 4 dwords of packed r,g,b
 #pragma unroll
-            for (uint32_t k = 0; k < 16u; k += 4u) {
+            for (uint32_t k = 0; k < kG; k += 4u) {
                 const uint32_t a = v[k] & 0xFFFFFFu, b = v[k + 1u] & 0xFFFFFFu, c = v[k + 2u] & 0xFFFFFFu, e = v[k + 3u] & 0xFFFFFFu;
                 d[3u * (k >> 2)] = a | (b << 24); d[3u * (k >> 2) + 1u] = (b >> 8) | (c << 16); d[3u * (k >> 2) + 2u] = (c >> 16) | (e << 8);
             }
+            if (kG == 16u) {
 #pragma unroll
-            for (uint32_t k = 0; k < 12u; k += 4u) {
-                u32x4 w; w.x = d[k]; w.y = d[k + 1u]; w.z = d[k + 2u]; w.w = d[k + 3u];
-                __builtin_amdgcn_raw_buffer_store_b128(w, rs, off + 4u * k, 0, 0);
+                for (uint32_t k = 0; k < 12u; k += 4u) {
+                    u32x4 w; w.x = d[k]; w.y = d[k + 1u]; w.z = d[k + 2u]; w.w = d[k + 3u];
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rs, off + 4u * k, 0, 0);
+                }
+            } else {                                                               // 24 bytes: 16 + 8
+                u32x4 w; w.x = d[0]; w.y = d[1]; w.z = d[2]; w.w = d[3];
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, 0);
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 w2; w2.x = d[4]; w2.y = d[5];
+                __builtin_amdgcn_raw_buffer_store_b64(w2, rs, off + 16u, 0, 0);
             }
         }
-        }
-        this->fpos += go ? 16u : 0u;
+        this->fpos += go ? kG : 0u;
     }
 };
 
@@ -2027,9 +2065,12 @@ struct BurstWriter : LaneWriter<OCH, 32, 16> {
 // 16 KiB of colour tables + the 4 KiB pixel ring = 20 KiB: eight wavefronts per CU.
 template <int OCH>
 __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
-    typedef BurstWriter<OCH> Writer;
+#ifndef QOIMI_SEGREC_GROUP
+#define QOIMI_SEGREC_GROUP 16
+#endif
+    typedef BurstWriter<OCH, 2 * QOIMI_SEGREC_GROUP, QOIMI_SEGREC_GROUP> Writer;
     constexpr uint32_t kTabDw = 64u * 64u, kOutDw = Writer::kRing * 64u;
-    static_assert(2u * 8u + Writer::kGroup <= Writer::kRing, "a block of eight steps adds up to 16 pixels to what a drain leaves (< one group)");
+    constexpr uint32_t kDrainEvery = Writer::kGroup / 2u;      // steps between drains: they add <= 2 pixels each to what a drain leaves (< one group)
 #ifndef QOIMI_SEGREC_PAD_DW
 #define QOIMI_SEGREC_PAD_DW 0
 #endif
@@ -2083,6 +2124,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
             const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
             for (uint32_t u = 0; u < 8u; ++u) {
+                if (kDrainEvery < 8u && u == 4u) W.drain_block();
                 const uint32_t rec = rc[u];
                 const uint32_t idx8 = (rec & 63u) << 8;
                 const uint32_t t = *(const lds_u32*)(tab_base + idx8);           // slot an INDEX names
@@ -2119,7 +2161,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                 if (rem) {                                                 // QOI_OP_RUN of three or more (qoi.h:573-575)
                     if (rem >= kLongRun) W.splat(px, rem);
                     while (rem) { W.put(px); --rem; }
-                    if (W.ppos - W.fpos > Writer::kRing - 2u * 8u) W.drain();
+                    if (W.ppos - W.fpos > Writer::kRing - 2u * kDrainEvery) W.drain();
                 }
             }
         }
