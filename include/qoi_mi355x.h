@@ -69,17 +69,24 @@ typedef struct qoimi_ctx qoimi_ctx;
 enum {
     QOIMI_OK            =  0,
     QOIMI_E_ARG         = -1,   /* argument rejected by the same rules as qoi.h:364-372 / 497-521 */
-    QOIMI_E_NO_GPU      = -2,   /* no gfx950 device / HIP runtime error */
+    QOIMI_E_NO_GPU      = -2,   /* no usable gfx950 device (none present, wrong architecture, driver missing) */
     QOIMI_E_NOMEM       = -3,
-    QOIMI_E_INTERNAL    = -4    /* a device-side liveness bound tripped (never expected) */
+    QOIMI_E_INTERNAL    = -4    /* any other HIP runtime error (e.g. a rejected launch), or a device-side liveness bound tripped */
 };
 
 /* Synthetic content classes (qoi_amd/synth.py states the exact per-pixel function). */
 enum { QOIMI_NOISE = 0, QOIMI_PHOTO = 1, QOIMI_UIFLAT = 2, QOIMI_CONSTANT = 3 };
 
 /* Create / destroy a context bound to one GPU.  A context owns a growable device
- * workspace, so steady-state calls do no hipMalloc/hipFree.  Calls on ONE context are
- * serialised by the caller (or use one context per thread). */
+ * workspace, so steady-state calls do no hipMalloc/hipFree.  ONE call at a time per
+ * context: the workspace (scratch, flags, staging) belongs to the call in flight, so a
+ * second qoimi_encode_batch / qoimi_decode_batch on the same context must not start -
+ * on any stream - before the first one's work has completed (qoimi_decode_batch returns
+ * complete; after qoimi_encode_batch synchronise the stream or call qoimi_encode_status).
+ * Use one context per thread / per concurrent stream.  The drop-in functions above do
+ * exactly that internally: every calling thread gets its own context and stream, so they
+ * are re-entrant like the reference (qoi.h:339,357-362,489-495).  Entry points leave the
+ * calling thread's current HIP device as they found it. */
 int  qoimi_ctx_create(int device, qoimi_ctx **out);
 void qoimi_ctx_destroy(qoimi_ctx *ctx);
 
@@ -128,7 +135,8 @@ int qoimi_synth_frames(qoimi_ctx *ctx, int kind, unsigned seed, unsigned first_f
                        void *d_pixels, size_t pixel_stride, void *stream);
 
 /* Counters of the last decode on this context: [0] speculation rounds, [1] segments
- * re-decoded after a failed check, [2] total segments, [3] reserved. */
+ * re-decoded after a failed check, [2] total segments, [3] segments whose entry position
+ * needed the full five-phase parse (look-back synchronisation did not settle). */
 void qoimi_decode_stats(qoimi_ctx *ctx, long long out[4]);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (what bench.py's roofline

@@ -2192,14 +2192,17 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     }
 }
 
-// Pixels the chunks never reach repeat the last pixel (truncated streams, size==22).
+// Pixels the chunks never reach repeat the last pixel (truncated streams, size==22).  One block per (image, slice): the
+// image index travels in blockIdx.x (gridDim.y stops at 65535 - a batch may hold more images than that).
+constexpr uint32_t kFillSlices = 64;
 template <int OCH>
 __global__ __launch_bounds__(256) void dec_fill(DecParams p) {
-    const uint32_t img = blockIdx.y;
+    const uint32_t img = blockIdx.x / kFillSlices, slice = blockIdx.x % kFillSlices;
     const DecImage im = p.images[img];
+    if (im.total_px >= im.npx) return;
     const uint32_t px = im.n_active ? im.final_px : kInitPx;
     uint8_t* out = p.pixels + (size_t)img * p.pixel_stride;
-    for (uint32_t i = im.total_px + blockIdx.x * 256u + threadIdx.x; i < im.npx; i += gridDim.x * 256u) {
+    for (uint32_t i = im.total_px + slice * 256u + threadIdx.x; i < im.npx; i += kFillSlices * 256u) {
         if (OCH == 4) reinterpret_cast<uint32_t*>(out)[i] = px;
         else { uint8_t* d = out + (size_t)i * 3u; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
     }
@@ -2298,7 +2301,7 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
 }
 
 void launch_decode_fill(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm) {
-    const dim3 grid(256, p.n_images);
+    const dim3 grid(p.n_images * kFillSlices);
     tm->mark(kT_begin, st);
     if (out_channels == 4) hipLaunchKernelGGL(dec_fill<4>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(dec_fill<3>, grid, dim3(256), 0, st, p);

@@ -31,11 +31,24 @@ static int fail(int code, const std::string& msg) { t_error = msg; return code; 
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
         if (e_ != hipSuccess)                                                                \
-            return fail(e_ == hipErrorOutOfMemory ? QOIMI_E_NOMEM : QOIMI_E_NO_GPU,          \
+            return fail(e_ == hipErrorOutOfMemory ? QOIMI_E_NOMEM                             \
+                        : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver) ? QOIMI_E_NO_GPU \
+                        : QOIMI_E_INTERNAL,                                                    \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                  \
     } while (0)
 
 extern "C" const char* qoimi_last_error(void) { return t_error.c_str(); }
+
+// Every entry point works on its context's device and leaves the calling thread's current device as it found it
+// (a caller may hold several GPUs, e.g. under torch).
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+        else if (prev < 0) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 extern "C" const char* qoimi_version(void) { return "qoi_mi355x 0.1 gfx950"; }
 
 // ------------------------------------------------------------------------------------
@@ -70,7 +83,8 @@ struct qoimi_ctx {
     int device = 0;
     Arena enc_ws, dec_ws;       // kernel workspaces
     Arena io_a, io_b, io_c;     // staging for the host-pointer (drop-in) path
-    uint32_t* host_word = nullptr;   // pinned word for read-backs
+    uint32_t* host_word = nullptr;   // pinned words for read-backs
+    hipStream_t own_stream = nullptr; // private non-blocking stream: self-test at creation, the drop-in entry points' work
     void* pin_buf = nullptr; size_t pin_cap = 0;   // pinned staging for small host->device tables
     long long dec_stats[4] = {0, 0, 0, 0};
     uint32_t seg_bytes = 0;     // decode segment size; 0: chosen per call from the batch's stream bytes
@@ -106,16 +120,21 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(QOIMI_E_NO_GPU, "no such GPU device");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(QOIMI_E_NO_GPU, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     qoimi_ctx* c = new qoimi_ctx();
     c->device = device;
-    if (hipHostMalloc((void**)&c->host_word, 64) != hipSuccess) { delete c; return fail(QOIMI_E_NOMEM, "hipHostMalloc failed"); }
+    if (hipHostMalloc((void**)&c->host_word, 256) != hipSuccess) { delete c; return fail(QOIMI_E_NOMEM, "hipHostMalloc failed"); }
     // Measure (do not assume) the LDS conflict order the fast colour-table probe relies on.
-    c->xchg_ordered = run_lds_order_selftest(0) == 0;
+    {
+        hipStream_t pst = nullptr;
+        if (hipStreamCreateWithFlags(&pst, hipStreamNonBlocking) != hipSuccess) { (void)hipHostFree(c->host_word); delete c; return fail(QOIMI_E_NO_GPU, "hipStreamCreate failed"); }
+        c->own_stream = pst;           // also the stream of the drop-in entry points (one context per calling thread)
+        c->xchg_ordered = run_lds_order_selftest(pst) == 0;
+    }
     if (const char* e = getenv("QOIMI_ENC_PROBE")) { if (atoi(e) == 0) c->xchg_ordered = false; }
     if (const char* e = getenv("QOIMI_ENC_ABLATE")) c->enc_ablate = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_TICKET")) c->enc_ticket = atoi(e);
@@ -137,7 +156,8 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
 
 extern "C" void qoimi_ctx_destroy(qoimi_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     c->enc_ws.release(); c->dec_ws.release(); c->io_a.release(); c->io_b.release(); c->io_c.release();
     if (c->host_word) (void)hipHostFree(c->host_word);
     if (c->pin_buf) (void)hipHostFree(c->pin_buf);
@@ -147,7 +167,7 @@ extern "C" void qoimi_ctx_destroy(qoimi_ctx* c) {
 // Per-kernel timing with HIP events on the launch stream.  on=1 resets the accumulators.
 extern "C" int qoimi_set_profiling(qoimi_ctx* c, int on) {
     if (!c) return fail(QOIMI_E_ARG, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     if (on && !c->timer.created) {
         for (int i = 0; i < KernelTimer::kMax; ++i) HIP_TRY(hipEventCreate(&c->timer.ev[i]));
         c->timer.created = true;
@@ -173,7 +193,7 @@ static void timer_collect(qoimi_ctx* c) {
 // (index = position in qoimi_kernel_name).  Returns the number of kernels.
 extern "C" int qoimi_get_profile(qoimi_ctx* c, void* stream, double* ms, long long* calls, int cap) {
     if (!c) return fail(QOIMI_E_ARG, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     timer_collect(c);
     for (int i = 0; i < kT_count && i < cap; ++i) { if (ms) ms[i] = c->prof_ms[i]; if (calls) calls[i] = c->prof_calls[i]; }
@@ -203,7 +223,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     const size_t npx = (size_t)desc->width * desc->height;
     if (pixel_stride < npx * desc->channels) return fail(QOIMI_E_ARG, "pixel_stride smaller than one image");
     if (stream_stride < qoimi_encode_bound(desc)) return fail(QOIMI_E_ARG, "stream_stride smaller than qoimi_encode_bound");
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
 
     EncParams p;
@@ -256,7 +276,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
 // call must be discarded.
 extern "C" int qoimi_encode_status(qoimi_ctx* c, void* stream) {
     if (!c) return fail(QOIMI_E_ARG, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (!c->last_enc_err) return QOIMI_OK;
     uint32_t err = 0;
@@ -325,7 +345,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         total_g += im.ngrp;
     }
     if (total > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (segment index overflows 32 bits)");
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
 
     DecParams p;
@@ -447,7 +467,7 @@ extern "C" int qoimi_synth_frames(qoimi_ctx* c, int kind, unsigned seed, unsigne
         return fail(QOIMI_E_ARG, "bad argument");
     const size_t npx = (size_t)width * height;
     if (npx >= kPixelCap || pixel_stride < npx * 4 || n_frames > 65535) return fail(QOIMI_E_ARG, "bad frame geometry");
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     SynthParams p;
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride; p.npx = (uint32_t)npx; p.width = width;
     p.n_frames = (uint32_t)n_frames; p.first_frame = first_frame; p.seed = seed; p.kind = kind;
@@ -459,44 +479,60 @@ extern "C" int qoimi_synth_frames(qoimi_ctx* c, int kind, unsigned seed, unsigne
 // ------------------------------------------------------------------------------------
 // Part 1 — drop-in entry points on host pointers
 // ------------------------------------------------------------------------------------
-static std::mutex g_mutex;
-static qoimi_ctx* g_ctx = nullptr;
+// One context per CALLING THREAD (qoi.h:339,357-362,489-495: the reference keeps no state between calls and is callable
+// from any number of threads at once).  Round 1 serialised every call on one global context behind a mutex; now a thread's
+// calls run on its own context - own workspace, own non-blocking stream - so concurrent callers overlap their copies and
+// kernels on the GPU.  A thread's context goes away with the thread.
+struct ThreadCtx {
+    qoimi_ctx* c = nullptr;
+    bool tried = false;
+    ~ThreadCtx() { if (c) qoimi_ctx_destroy(c); }
+};
+static thread_local ThreadCtx t_ctx;
+static std::mutex g_mutex;                 // guards the one-time warning only
 
-static qoimi_ctx* global_ctx() {   // caller holds g_mutex
-    if (!g_ctx) {
+static qoimi_ctx* thread_ctx() {
+    if (!t_ctx.c && !t_ctx.tried) {
+        t_ctx.tried = true;
         int dev = 0;
         if (const char* e = getenv("QOIMI_DEVICE")) dev = atoi(e);
-        if (qoimi_ctx_create(dev, &g_ctx) != QOIMI_OK) {
+        if (qoimi_ctx_create(dev, &t_ctx.c) != QOIMI_OK) {
+            std::lock_guard<std::mutex> lock(g_mutex);
             fprintf(stderr, "qoi_mi355x: no usable MI355X (%s); there is no CPU fallback\n", t_error.c_str());
-            g_ctx = nullptr;
+            t_ctx.c = nullptr;
         }
     }
-    return g_ctx;
+    return t_ctx.c;
 }
 
 extern "C" void* qoi_encode(const void* data, const qoi_desc* desc, int* out_len) {
     if (!data || !out_len || !desc_ok(desc)) return NULL;                 // qoi.h:364-372
-    std::lock_guard<std::mutex> lock(g_mutex);
-    qoimi_ctx* c = global_ctx();
+    qoimi_ctx* c = thread_ctx();
     if (!c) return NULL;
+    DeviceGuard guard(c->device);
+    hipStream_t st = c->own_stream;
     const size_t npx = (size_t)desc->width * desc->height;
     const size_t in_bytes = npx * desc->channels;
     const size_t bound = qoimi_encode_bound(desc);                        // qoi.h:374-376
     if (c->io_a.reserve(in_bytes + 16) || c->io_b.reserve(bound + 16) || c->io_c.reserve(256)) return NULL;
     void* result = NULL;
     do {
-        if (hipMemcpy(c->io_a.base, data, in_bytes, hipMemcpyHostToDevice) != hipSuccess) break;
-        if (qoimi_encode_batch(c, c->io_a.base, in_bytes, desc, 1, c->io_b.base, bound, (int*)c->io_c.base, 0) != QOIMI_OK) break;
-        int len = 0;
-        if (hipMemcpy(&len, c->io_c.base, sizeof len, hipMemcpyDeviceToHost) != hipSuccess) break;
-        const uint32_t err = qoimi_encode_status(c, 0) == QOIMI_OK ? 0u : 1u;
-        if (err != 0 || len < kHeaderBytes + kTrailerBytes || (size_t)len > bound) {
+        // pixels in (the copy engine reads pageable memory at the link's rate on this platform, tools/ubench/host_copy.cpp),
+        // kernels, then ONE read-back of length + liveness flag through pinned words, then exactly `len` bytes out
+        if (hipMemcpyAsync(c->io_a.base, data, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) break;
+        if (qoimi_encode_batch(c, c->io_a.base, in_bytes, desc, 1, c->io_b.base, bound, (int*)c->io_c.base, st) != QOIMI_OK) break;
+        if (hipMemcpyAsync(&c->host_word[4], c->io_c.base, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) break;
+        if (hipMemcpyAsync(&c->host_word[5], c->last_enc_err, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) break;
+        if (hipStreamSynchronize(st) != hipSuccess) break;
+        const int len = (int)c->host_word[4];
+        if (c->host_word[5] != 0 || len < kHeaderBytes + kTrailerBytes || (size_t)len > bound) {
             t_error = "encode kernel reported a liveness failure";
             break;
         }
         uint8_t* bytes = (uint8_t*)malloc(bound);                          // worst case, as qoi.h:379
         if (!bytes) break;
-        if (hipMemcpy(bytes, c->io_b.base, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) { free(bytes); break; }
+        if (hipMemcpyAsync(bytes, c->io_b.base, (size_t)len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { free(bytes); break; }
         *out_len = len;
         result = bytes;
     } while (0);
@@ -518,16 +554,17 @@ extern "C" void* qoi_decode(const void* data, int size, qoi_desc* desc, int chan
     const int och = channels ? channels : desc->channels;                 // qoi.h:523-525
     const size_t out_bytes = (size_t)desc->width * desc->height * (size_t)och;
 
-    std::lock_guard<std::mutex> lock(g_mutex);
-    qoimi_ctx* c = global_ctx();
+    qoimi_ctx* c = thread_ctx();
     if (!c) return NULL;
+    DeviceGuard guard(c->device);
+    hipStream_t st = c->own_stream;
     if (c->io_a.reserve((size_t)size + 16) || c->io_b.reserve(out_bytes + 16)) return NULL;
-    if (hipMemcpy(c->io_a.base, data, (size_t)size, hipMemcpyHostToDevice) != hipSuccess) return NULL;
-    if (qoimi_decode_batch(c, c->io_a.base, (size_t)size, &size, desc, 1, channels, c->io_b.base, out_bytes, 0) != QOIMI_OK)
-        return NULL;
     uint8_t* pixels = (uint8_t*)malloc(out_bytes);                        // qoi.h:527-531
     if (!pixels) return NULL;
-    if (hipMemcpy(pixels, c->io_b.base, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) { free(pixels); return NULL; }
+    if (hipMemcpyAsync(c->io_a.base, data, (size_t)size, hipMemcpyHostToDevice, st) != hipSuccess ||
+        qoimi_decode_batch(c, c->io_a.base, (size_t)size, &size, desc, 1, channels, c->io_b.base, out_bytes, st) != QOIMI_OK ||
+        hipMemcpyAsync(pixels, c->io_b.base, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { free(pixels); return NULL; }
     return pixels;
 }
 

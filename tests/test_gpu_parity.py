@@ -223,6 +223,28 @@ def test_16k_frame_round_trip(api, ctx):
     # covered at 4K; here the whole-image property is the check.
 
 
+def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
+    """BASELINE config 4 against the reference ENCODER: the 16384 x 16384 stream (335 MB) equals what qoi.h:356 writes for
+    the same pixels, byte for byte (the reference takes a few seconds for it on one host core)."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    if ref is None:
+        pytest.skip("oracle/_ref/libqoiref.so not built")
+    w = h = 16384
+    b = DeviceBatch(ctx, w, h, 4, 1)
+    ctx.synth_frames(synth.KIND_ID["photo"], synth.DEFAULT_SEED, 2, 1, w, h, b.pixels.data_ptr(), b.pixel_stride, b.stream)
+    lens = b.encode()
+    n = int(lens[0])
+    host_px = b.pixels[:w * h * 4].cpu().numpy()
+    want = ref.encode(host_px, w, h, 4)
+    assert len(want) == n
+    got = b.streams[:n].cpu().numpy()
+    assert np.array_equal(got, np.frombuffer(want, dtype=np.uint8))
+    del want, got, host_px
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("env", [
     {"QOIMI_ENC_WARM": "0"},                              # entry states from per-slab summaries + scans for every image
     {"QOIMI_ENC_LOOKBACK": "1"},                          # single-pass decoupled look-back instead of scratch + compaction
@@ -234,6 +256,10 @@ def test_16k_frame_round_trip(api, ctx):
     {"QOIMI_SEG_BYTES": "128"},                           # the piece is the segment (single-frame calls choose this)
     {"QOIMI_SEG_BYTES": "512"},                           # lane-per-segment P1/P2 (4 pieces: no piece path)
     {"QOIMI_DEC_REFINE": "0", "QOIMI_SEG_BYTES": "2048"},  # repair rounds without alpha hints
+    {"QOIMI_DEC_REC": "0"},                               # round-1 byte-stream passes instead of the chunk-record pipeline
+    {"QOIMI_DEC_REC": "0", "QOIMI_SEG_BYTES": "2048"},
+    {"QOIMI_DEC_REC_CAP_MB": "1"},                        # record arena capped at 1 MiB: the batch is decoded in sub-batches
+    {"QOIMI_SEG_BYTES": "320"},                           # a segment size without the 128-byte piece parse: full parse, transcode from S1's phases
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
@@ -334,6 +360,39 @@ def test_decode_batch_many_small_images(api, ctx, oracle):
             want, _ = oracle.decode(s, och)
             assert np.array_equal(got_all[i * pstride:i * pstride + want.size], want), (och, i, descs[i].width, descs[i].height)
             assert got_all[i * pstride + want.size] == 0xCD or want.size == pstride, "wrote past the image"
+
+
+def test_decode_batch_over_65535_images(api, ctx, oracle):
+    """70 000 tiny images in one decode call (a grid dimension of round 1 stopped at 65 535), a third of them truncated so
+    that the tail fill (qoi.h:544) runs for them."""
+    import torch
+    rng = np.random.default_rng(11)
+    protos = []
+    for k in range(7):
+        px = rng.integers(0, 256, size=(3, 3, 4), dtype=np.uint8)
+        if k % 2:
+            px[:, :, 3] = 255
+        s = oracle.encode(np.ascontiguousarray(px), 3, 3, 4)
+        if k % 3 == 0:
+            s = s[:14 + (len(s) - 22) // 2] + s[-8:]                    # half of the chunks, then the end marker
+        protos.append((s, oracle.decode(s, 4)[0]))
+    n = 70000
+    sstride = 256
+    host = np.zeros(n * sstride, dtype=np.uint8)
+    sizes = []
+    for i in range(n):
+        s = protos[i % 7][0]
+        host[i * sstride:i * sstride + len(s)] = np.frombuffer(s, dtype=np.uint8)
+        sizes.append(len(s))
+    buf = torch.from_numpy(host).cuda()
+    descs = [api.QoiDesc(3, 3, 4, 0)] * n
+    pstride = 256
+    out = torch.full((n * pstride,), 0xCD, dtype=torch.uint8, device="cuda")
+    ctx.decode_batch(buf.data_ptr(), sstride, sizes, descs, 4, out.data_ptr(), pstride)
+    got = out.cpu().numpy().reshape(n, pstride)
+    for k in range(7):
+        assert (got[k::7, :36] == protos[k][1][None, :]).all(), k
+    assert (got[:, 36:] == 0xCD).all(), "wrote past an image"
 
 
 @pytest.mark.parametrize("shape", [(1, 1), (7, 3), (63, 65), (1024, 1), (1, 1025), (257, 129)])

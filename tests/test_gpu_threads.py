@@ -1,0 +1,46 @@
+"""Re-entrancy of the drop-in entry points (qoi.h:339,357-362,489-495: no state between calls, callable from any thread):
+several threads encode and decode different images at the same time through the C-ABI (ctypes releases the GIL for the
+duration of a call); every result must equal the oracle's."""
+import threading
+
+import numpy as np
+import pytest
+
+from qoi_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_encode_decode(ref, port):
+    import torch  # noqa: F401
+    from qoi_amd import api
+    oracle = ref or port
+    kinds = ("photo", "noise", "uiflat", "constant")
+    jobs = []
+    for t in range(8):
+        w, h = 320 + 37 * t, 200 + 11 * t
+        px = synth.frame_rgba(kinds[t % 4], w, h, t)
+        jobs.append((w, h, px, oracle.encode(px, w, h, 4)))
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def work(i):
+        w, h, px, want = jobs[i]
+        try:
+            start.wait()
+            for it in range(6):
+                s = api.qoi_encode(px, api.QoiDesc(w, h, 4, 0))
+                if s != want:
+                    errors.append((i, it, "encode"))
+                got, d = api.qoi_decode(want, 4 if it % 2 else 0)
+                if got is None or not np.array_equal(got, px.reshape(-1)) or (d.width, d.height) != (w, h):
+                    errors.append((i, it, "decode"))
+        except Exception as e:                      # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -4,6 +4,9 @@ import importlib.util
 import os
 import re
 
+import numpy as np
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -48,3 +51,29 @@ def test_onlytotals_and_flags(tmp_path):
     rows = [l for l in lines if l.startswith("qoi-ref:")]
     assert len(rows) == 2                                 # directory total + grand total only
     assert all(float(r.split()[2]) == 0.0 for r in rows)  # --noencode: encode ms column stays 0
+
+
+@pytest.mark.gpu
+def test_gpu_rows_on_a_512_png(tmp_path):
+    """BASELINE configs[0] on the GPU rows: one 512 x 512 RGBA PNG, qoibench.c's verification (:408-417) and table
+    (:335-360) with the MI355X library in the `qoi` rows - drop-in (host pointers) and device-resident - and the reference
+    CPU build beside them.  Sizes must agree between the rows: the GPU stream is the reference's stream."""
+    import torch  # noqa: F401
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import png_io
+    from qoi_amd import synth
+    m = _load()
+    px = synth.frame_rgba("photo", 512, 512, 3).reshape(512, 512, 4)
+    (tmp_path / "plumbing_512.png").write_bytes(png_io.write_png(px))
+    px3 = np.ascontiguousarray(synth.frame_rgba("uiflat", 200, 120, 1).reshape(120, 200, 4)[:, :, :3])
+    (tmp_path / "rgb_200x120.png").write_bytes(png_io.write_png(px3))
+    lines = []
+    rc = m.main(["3", str(tmp_path)], out=lambda s="": lines.extend(str(s).split("\n")), ref=_ref(m), use_gpu=True)
+    assert rc == 0
+    rows = {k: [l for l in lines if l.startswith(k)] for k in ("qoi-mi355x:", "qoi-dev:", "qoi-ref:")}
+    assert all(len(v) == 2 + 2 for v in rows.values()), {k: len(v) for k, v in rows.items()}     # two images, directory total, grand total
+    for a, b, c in zip(rows["qoi-mi355x:"], rows["qoi-dev:"], rows["qoi-ref:"]):
+        assert a.split()[-2:] == c.split()[-2:] == b.split()[-2:], (a, b, c)      # size kb and rate: byte-identical streams
+        for r in (a, b, c):
+            assert float(r.split()[3]) > 0 and float(r.split()[4]) > 0           # decode mpps, encode mpps measured (the ms columns print 0.0 below 50 us)
