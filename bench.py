@@ -8,18 +8,30 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 
 A STEP = one pass of the hot path over one batch: every rank encodes its F resident
 3840x2160 RGBA frames (qoimi_encode_batch) and decodes the streams back
-(qoimi_decode_batch); F = 256 by default (8.5 GB of pixels; 1024 = the per-GPU shard of BASELINE
-configs[4] also fits, 176 GB with workspaces).  Frames are synthetic (`photo` class of qoi_amd/synth.py),
-generated on the device, distinct per frame and rank, F*33 MB >> the 256 MiB Infinity Cache, and
+(qoimi_decode_batch); F = 1024 by default = one GPU's shard of BASELINE configs[4] (8192 frames over
+8 GPUs; 34 GB of pixels, about 190 GB with streams, output and workspaces).  Frames are synthetic
+(`photo` class of qoi_amd/synth.py), generated on the device, distinct per frame and rank, and
 already resident in HBM when the timed region starts.  value = pixels round-tripped per
-second over all ranks.  The round trip is verified bit-exact after the timed region.
+second over all ranks.  After the timed region the round trip is verified bit-exact on the whole
+batch and four of its streams are checked against the REFERENCE codec (byte-identical to its
+encoder's, decoded by its decoder to the source pixels).
 
-Extra objects on the JSON line:
-  roofline      dominant kernel enc_slabs: algorithmic bytes (4 B read per pixel,
-                SURVEY.md §8d) / its mean launch duration measured with HIP events on the
-                launch stream during the timed steps, against the 8 TB/s HBM peak.
-  cpu_baseline  the unmodified reference (oracle/_ref, else our C port) timed on this
-                host with qoibench.c's BENCHMARK_FN semantics on a bounded sample.
+--scaling weak (default): F frames per GPU whatever N is.  --scaling strong: the 8192 frames of
+configs[4] in total, 8192/N per GPU, processed as passes over at most F resident frames.
+`--gpus N` without a torch.distributed.run environment starts the N ranks itself.
+
+Extra objects on the JSON line (rank 0, N = 1 unless noted):
+  roofline             enc_slabs, the kernel the north star's 50 % target is stated on: algorithmic bytes
+                       (4 B read per pixel) / its mean launch duration measured with HIP
+                       events on the launch stream during the timed steps, against the 8 TB/s HBM peak
+  roofline_dominant    the same for the kernel that takes the largest share of the step (dec_segments_rec)
+  roofline_encode_total / roofline_decode_total   whole qoimi_encode_batch / qoimi_decode_batch calls
+  single_frame         BASELINE configs[1], with its own encode roofline
+  encode_1080p_batch   BASELINE configs[2]: 1024 x 1920x1080, encode only
+  single_16k           BASELINE configs[3]: one 16384 x 16384 image, encode + decode
+  other_content        the batch with noise / constant / uiflat content
+  cpu_baseline         the unmodified reference (oracle/_ref, else our C port) timed on this
+                       host with qoibench.c's BENCHMARK_FN semantics on a bounded sample.
 """
 from __future__ import annotations
 
@@ -51,7 +63,7 @@ def _latest_traffic_file() -> str:
 TRAFFIC_FILE = _latest_traffic_file()
 
 
-def measured_traffic(kernel_prefix: str, grid_threads: int):
+def measured_traffic(kernel_prefix: str, grid_threads: int, scale: float = 1.0):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
     (tools/gpu_session.sh: separate FETCH_SIZE / WRITE_SIZE runs; the counters cannot be collected from inside
     the process).  Returned only when the profiled launch had the same grid, i.e. the same workload; FETCH_SIZE
@@ -62,8 +74,9 @@ def measured_traffic(kernel_prefix: str, grid_threads: int):
         return None, None
     for name, k in doc["kernels"].items():
         if name.startswith(kernel_prefix) and grid_threads in (k.get("grid"), -1) and "FETCH_SIZE_KB" in k and "WRITE_SIZE_KB" in k:
-            nbytes = (k["FETCH_SIZE_KB"] * doc["read_correction"] + k["WRITE_SIZE_KB"]) * 1024.0
-            return nbytes, f"profiles/{os.path.basename(TRAFFIC_FILE)}: {name} (2 x FETCH_SIZE + WRITE_SIZE)"
+            nbytes = (k["FETCH_SIZE_KB"] * doc["read_correction"] + k["WRITE_SIZE_KB"]) * 1024.0 * scale
+            note = "" if scale == 1.0 else f", x {scale:g}: the PMC passes ran {doc.get('frames', '?')} frames per launch"
+            return nbytes, f"profiles/{os.path.basename(TRAFFIC_FILE)}: {name} (2 x FETCH_SIZE + WRITE_SIZE{note})"
     return None, None
 
 
@@ -126,6 +139,46 @@ def cpu_baseline_all_cores(kind: str, w: int, h: int, budget_s: float) -> dict:
             "sample": f"{done} worker processes x {budget_s:.0f} s of {w}x{h} {kind} frames, encode+decode, malloc/free timed"}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks (one per GPU, RCCL over 127.0.0.1)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def check_against_reference(torch, pixels, pstride, streams, sstride, sizes, w, h, frames) -> dict:
+    """The north star's criterion on streams of the benchmark batch itself, outside the timed region: the REFERENCE
+    decoder turns our stream back into the source pixels, and (stronger) the stream equals the reference encoder's."""
+    from oracle import oracle_py
+    lib = oracle_py.load_ref()
+    kind = "reference"
+    if lib is None:
+        lib, kind = oracle_py.load_port(), "port"
+    npx = w * h
+    ident = rt = True
+    for f in frames:
+        px = pixels[f * pstride:f * pstride + npx * 4].cpu().numpy()
+        mine = streams[f * sstride:f * sstride + sizes[f]].cpu().numpy().tobytes()
+        ident = ident and mine == lib.encode(px, w, h, 4)
+        back, _ = lib.decode(mine, 4)
+        rt = rt and back is not None and np.array_equal(back, px)
+    return {"checker": kind, "frames": list(frames), "streams_byte_identical": bool(ident), "reference_decoder_round_trips": bool(rt)}
+
+
+def equal_batches(torch, a, b, F, stride, nbytes) -> bool:
+    """decoded == source over the first nbytes of every frame, 64 frames at a time (no batch-sized temporaries)."""
+    av, bv = a.view(F, stride), b.view(F, stride)
+    for lo in range(0, F, 64):
+        if not bool(torch.equal(av[lo:lo + 64, :nbytes], bv[lo:lo + 64, :nbytes])):
+            return False
+    return True
+
+
 def main() -> None:
     if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":            # one core's share of cpu_baseline_all_cores
         print(json.dumps(cpu_baseline(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))))
@@ -134,7 +187,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=256, help="4K frames resident per GPU (= per step); BASELINE configs[4] is 1024 per GPU")
+    ap.add_argument("--frames", type=int, default=1024, help="4K frames resident per GPU (= per step when scaling is weak); 1024 = one GPU's shard of BASELINE configs[4]")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="strong: 8192 frames in total (configs[4]), 8192/N per GPU in passes over <= --frames resident frames")
+    ap.add_argument("--total-frames", type=int, default=8192, help="frames of the whole job under --scaling strong")
     ap.add_argument("--kind", default="photo", choices=["photo", "noise", "uiflat", "constant"])
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -143,45 +198,56 @@ def main() -> None:
     ap.add_argument("--encode-only", action="store_true", help="diagnostics: time the encoder alone (no decode, no check)")
     ap.add_argument("--no-others", action="store_true", help="skip the noise / constant / uiflat side figures")
     ap.add_argument("--no-single", action="store_true", help="skip the single-frame figure (profiling runs: keeps every launch batch-sized)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2] / configs[3] side figures")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     from qoi_amd import api, synth
     from qoi_amd import dist as qdist
 
     rank, world, local = qdist.env_world()
-    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     qdist.init("nccl", dev)          # RCCL; only counters ever cross GPUs
     ctx = api.Context(local)
     stream = torch.cuda.current_stream().cuda_stream
 
-    w, h, F = args.width, args.height, args.frames
+    w, h = args.width, args.height
     npx = w * h
+    strong = args.scaling == "strong"
+    if strong:
+        mine = qdist.shard_range(args.total_frames, rank, world)       # this rank's frames of the job
+        F = min(args.frames, len(mine))                                 # resident at a time
+        passes = (len(mine) + F - 1) // F
+        first_frame = mine.start
+    else:
+        F, passes, first_frame = args.frames, 1, rank * args.frames    # weak scaling: F distinct frames per GPU
     desc = api.QoiDesc(w, h, 4, api.QOI_SRGB)
     pstride = (npx * 4 + 255) // 256 * 256
     sstride = (api.encode_bound(w, h, 4) + 255) // 256 * 256
     pixels = torch.empty(F * pstride, dtype=torch.uint8, device=dev)
     streams = torch.empty(F * sstride, dtype=torch.uint8, device=dev)
     decoded = torch.empty(F * pstride, dtype=torch.uint8, device=dev)
-    lens = torch.zeros(F, dtype=torch.int32, device=dev)
-    my_frames = qdist.shard_frames(rank, world, F)      # weak scaling: F distinct frames per GPU
-    ctx.synth_frames(synth.KIND_ID[args.kind], synth.DEFAULT_SEED, my_frames[0], F, w, h,
-                     pixels.data_ptr(), pstride, stream)
+    lens = torch.zeros(max(F, 1024), dtype=torch.int32, device=dev)
+    ctx.synth_frames(synth.KIND_ID[args.kind], synth.DEFAULT_SEED, first_frame, F, w, h, pixels.data_ptr(), pstride, stream)
     torch.cuda.synchronize()
 
     # stream lengths are data-dependent; they are constant across steps, read them once
     ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
     ctx.encode_status(stream)
-    sizes = [int(x) for x in lens.cpu().numpy()]
+    sizes = [int(x) for x in lens[:F].cpu().numpy()]
     descs = [desc] * F
 
     def step():
-        ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
-        if args.encode_only:
-            return
-        ctx.decode_batch(streams.data_ptr(), sstride, sizes, descs, 4, decoded.data_ptr(), pstride, stream)
+        for _ in range(passes):        # strong scaling: the rank's share in passes over the resident frames
+            ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+            if not args.encode_only:
+                ctx.decode_batch(streams.data_ptr(), sstride, sizes, descs, 4, decoded.data_ptr(), pstride, stream)
 
     def barrier():
         qdist.barrier()
@@ -199,29 +265,43 @@ def main() -> None:
     prof = ctx.get_profile(stream)
     ctx.set_profiling(False)
     ctx.encode_status(stream)
+    launches = args.steps * passes
+
+    # bit-exact round trip (qoibench.c:408-417) on the whole batch, and four of its streams against the reference codec
+    ok = args.encode_only or equal_batches(torch, decoded, pixels, F, pstride, npx * 4)
+    dstats = ctx.decode_stats()
+    refcheck = None
+    if rank == 0 and not args.encode_only:
+        refcheck = check_against_reference(torch, pixels, pstride, streams, sstride, sizes, w, h, sorted({0, 1, F // 2, F - 1}))
+        ok = ok and refcheck["streams_byte_identical"] and refcheck["reference_decoder_round_trips"]
+
+    def timed(fn, reps):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
 
     # BASELINE configs[1]: ONE 4K frame, encode + decode, device-resident (33 MB: served by the 256 MiB Infinity
     # Cache on repeat runs and bound by launch latency, not by HBM - reported next to the batch figure, never as it)
     single = None
     if not args.encode_only and not args.no_single and rank == 0:
         one = [sizes[0]]
+        enc1 = lambda: ctx.encode_batch(pixels.data_ptr(), pstride, desc, 1, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+        dec1 = lambda: ctx.decode_batch(streams.data_ptr(), sstride, one, [desc], 4, decoded.data_ptr(), pstride, stream)
         for _ in range(3):
-            ctx.encode_batch(pixels.data_ptr(), pstride, desc, 1, streams.data_ptr(), sstride, lens.data_ptr(), stream)
-            ctx.decode_batch(streams.data_ptr(), sstride, one, [desc], 4, decoded.data_ptr(), pstride, stream)
-        torch.cuda.synchronize()
-        reps = 20
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            ctx.encode_batch(pixels.data_ptr(), pstride, desc, 1, streams.data_ptr(), sstride, lens.data_ptr(), stream)
-            ctx.decode_batch(streams.data_ptr(), sstride, one, [desc], 4, decoded.data_ptr(), pstride, stream)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / reps
-        single = {"workload": f"1 x {w}x{h} RGBA frame, encode + decode, device-resident, wall clock incl. launches",
-                  "ms": round(dt * 1e3, 4), "mpixels_per_s": round(npx / dt / 1e6, 1)}
-
-    # bit-exact round trip (qoibench.c:408-417) checked outside the timed region
-    ok = args.encode_only or bool(torch.equal(decoded.view(F, -1)[:, :npx * 4], pixels.view(F, -1)[:, :npx * 4]))
-    dstats = ctx.decode_stats()
+            enc1(); dec1()
+        dt = timed(lambda: (enc1(), dec1()), 20)
+        dt_e = timed(enc1, 20)
+        dt_d = timed(dec1, 20)
+        single = {"workload": f"1 x {w}x{h} RGBA frame, encode + decode, device-resident, wall clock incl. launches (Infinity-Cache resident on repeat runs)",
+                  "ms": round(dt * 1e3, 4), "mpixels_per_s": round(npx / dt / 1e6, 1),
+                  "encode_ms": round(dt_e * 1e3, 4), "decode_ms": round(dt_d * 1e3, 4),
+                  "roofline": {"bound": "hbm", "kernel": "whole single-frame encode (all launches)", "achieved": round(npx * 4 / dt_e / 1e9, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(npx * 4 / dt_e / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                               "algorithmic_bytes_per_launch": npx * 4, "ms_per_launch": round(dt_e * 1e3, 4),
+                               "target": "BASELINE.md: 50 % of the roofline = 8.3 us per 4K frame"}}
 
     # next to the headline content always report `noise` (5 B/px written: most stream traffic) and
     # `constant` (longest runs) - same batch, 3 timed steps each, rank 0 of a single-GPU run only
@@ -234,71 +314,138 @@ def main() -> None:
             ctx.synth_frames(synth.KIND_ID[kind], synth.DEFAULT_SEED, 0, F, w, h, pixels.data_ptr(), pstride, stream)
             ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
             ctx.encode_status(stream)
-            ksizes = [int(x) for x in lens.cpu().numpy()]
+            ksizes = [int(x) for x in lens[:F].cpu().numpy()]
             ctx.decode_batch(streams.data_ptr(), sstride, ksizes, descs, 4, decoded.data_ptr(), pstride, stream)   # warm-up
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for _ in range(3):
+
+            def both():
                 ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
                 ctx.decode_batch(streams.data_ptr(), sstride, ksizes, descs, 4, decoded.data_ptr(), pstride, stream)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t2) / 3
-            kok = bool(torch.equal(decoded.view(F, -1)[:, :npx * 4], pixels.view(F, -1)[:, :npx * 4]))
+            dt = timed(both, 3)
+            kok = equal_batches(torch, decoded, pixels, F, pstride, npx * 4)
             other[kind] = {"mpixels_per_s": round(F * npx / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                            "stream_bytes_per_px": round(sum(ksizes) / (F * npx), 4), "decode_rounds": ctx.decode_stats()["rounds"],
                            "verified_bit_exact": kok}
 
+    # BASELINE configs[2]: 1024 x 1920x1080 RGBA, encode only (the HBM-bound roofline run) and configs[3]: one 16384 x 16384
+    # image, encode + decode - in the buffers of the main batch where they fit
+    cfg2 = cfg3 = None
+    if world == 1 and rank == 0 and not args.no_configs and not args.encode_only:
+        w2, h2, F2 = 1920, 1080, 1024
+        n2 = w2 * h2
+        ps2, ss2 = (n2 * 4 + 255) // 256 * 256, (api.encode_bound(w2, h2, 4) + 255) // 256 * 256
+        if F2 * ps2 <= pixels.numel() and F2 * ss2 <= streams.numel():
+            d2 = api.QoiDesc(w2, h2, 4, api.QOI_SRGB)
+            ctx.synth_frames(synth.KIND_ID["photo"], synth.DEFAULT_SEED, 20000, F2, w2, h2, pixels.data_ptr(), ps2, stream)
+            e2 = lambda: ctx.encode_batch(pixels.data_ptr(), ps2, d2, F2, streams.data_ptr(), ss2, lens.data_ptr(), stream)
+            e2(); e2()
+            ctx.set_profiling(True)
+            dt = timed(e2, 10)
+            p2 = ctx.get_profile(stream)
+            ctx.set_profiling(False)
+            ctx.encode_status(stream)
+            s2 = [int(x) for x in lens[:F2].cpu().numpy()]
+            chk = check_against_reference(torch, pixels, ps2, streams, ss2, s2, w2, h2, [0, F2 - 1])
+            slabs_ms = sum(p2[k][0] for k in ("enc_slabs", "enc_slabs_generic", "enc_slab_summary", "enc_scan_groups", "enc_scan_images") if k in p2) / 10
+            tot_ms = p2["encode_total"][0] / 10 if p2.get("encode_total", (0, 0))[1] else dt * 1e3
+            cfg2 = {"workload": f"BASELINE configs[2]: {F2} x {w2}x{h2} RGBA frames (photo), encode only, HBM-resident ({F2 * n2 * 4 / 1e9:.2f} GB of pixels per launch)",
+                    "ms_per_step": round(dt * 1e3, 4), "mpixels_per_s": round(F2 * n2 / dt / 1e6, 1),
+                    "stream_bytes_per_px": round(sum(s2) / (F2 * n2), 4), "reference_check": chk,
+                    "roofline": {"bound": "hbm", "kernel": "enc_slabs (+ entry-state passes)", "achieved": round(F2 * n2 * 4 / (slabs_ms * 1e-3) / 1e9, 1),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(F2 * n2 * 4 / (slabs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "traffic": None, "algorithmic_bytes_per_launch": F2 * n2 * 4, "ms_per_launch": round(slabs_ms, 4)},
+                    "roofline_encode_total": {"bound": "hbm", "kernel": "whole qoimi_encode_batch (all kernels)", "achieved": round(F2 * n2 * 4 / (tot_ms * 1e-3) / 1e9, 1),
+                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(F2 * n2 * 4 / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                              "algorithmic_bytes_per_launch": F2 * n2 * 4, "ms_per_launch": round(tot_ms, 4)}}
+        w3 = h3 = 16384
+        n3 = w3 * h3
+        ps3, ss3 = n3 * 4, (api.encode_bound(w3, h3, 4) + 255) // 256 * 256
+        if ps3 <= pixels.numel() and ss3 <= streams.numel():
+            d3 = api.QoiDesc(w3, h3, 4, api.QOI_SRGB)
+            ctx.synth_frames(synth.KIND_ID["photo"], synth.DEFAULT_SEED, 30000, 1, w3, h3, pixels.data_ptr(), ps3, stream)
+            e3 = lambda: ctx.encode_batch(pixels.data_ptr(), ps3, d3, 1, streams.data_ptr(), ss3, lens.data_ptr(), stream)
+            e3()
+            ctx.encode_status(stream)
+            s3 = [int(lens[0].item())]
+            g3 = lambda: ctx.decode_batch(streams.data_ptr(), ss3, s3, [d3], 4, decoded.data_ptr(), ps3, stream)
+            g3()
+            dte, dtd = timed(e3, 5), timed(g3, 5)
+            ok3 = bool(torch.equal(decoded[:ps3], pixels[:ps3]))
+            cfg3 = {"workload": f"BASELINE configs[3]: one {w3}x{h3} RGBA image (photo, {n3 / 1e6:.0f} Mpx), encode + decode, device-resident, wall clock incl. launches",
+                    "encode_ms": round(dte * 1e3, 3), "decode_ms": round(dtd * 1e3, 3), "mpixels_per_s": round(n3 / (dte + dtd) / 1e6, 1),
+                    "encode_mpixels_per_s": round(n3 / dte / 1e6, 1), "decode_mpixels_per_s": round(n3 / dtd / 1e6, 1),
+                    "stream_bytes_per_px": round(s3[0] / n3, 4), "decode_rounds": ctx.decode_stats()["rounds"], "verified_bit_exact": ok3,
+                    "roofline_encode_total": {"bound": "hbm", "kernel": "whole qoimi_encode_batch (all kernels, wall clock)", "achieved": round(n3 * 4 / dte / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                              "unit": "GB/s", "frac": round(n3 * 4 / dte / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": n3 * 4, "ms_per_launch": round(dte * 1e3, 3)}}
+
     # RCCL: counters only (max elapsed; summed pixels / stream bytes / verified ranks)
     elapsed, (total_px, total_stream_bytes, n_ok) = qdist.reduce_counters(
-        elapsed, [float(F * npx * args.steps), float(sum(sizes)) * args.steps, float(ok)], dev)
+        elapsed, [float(F * npx * launches), float(sum(sizes)) * launches, float(ok)], dev)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = total_px / elapsed / 1e6
-        enc_ms = sum(prof[k][0] for k in prof if k.startswith("enc_"))
-        dec_ms = sum(prof[k][0] for k in prof if k.startswith("dec_"))
+        # whole calls on the launch stream
+        enc_ms = prof["encode_total"][0] if prof.get("encode_total", (0, 0))[1] else sum(prof[k][0] for k in prof if k.startswith("enc_"))
+        dec_ms = prof["decode_total"][0] if prof.get("decode_total", (0, 0))[1] else sum(prof[k][0] for k in prof if k.startswith("dec_"))
         # The encode kernel of the roofline: enc_slabs plus the entry-state passes that run before its second launch
         # for images the first launch could not finish on its own (flat content) - every kernel that reads pixels.
         slabs_calls = prof["enc_slabs"][1]
         slabs_ms = sum(prof[k][0] for k in ("enc_slabs", "enc_slabs_generic", "enc_slab_summary", "enc_scan_groups", "enc_scan_images") if k in prof)
         per_launch_ms = slabs_ms / max(1, slabs_calls)
         alg_bytes = F * npx * 4                           # 4 B read per pixel
-        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        # the largest kernel of the step by time, for the record: stream bytes read + 4 B written per pixel
-        seg_ms = prof["dec_segments"][0] / max(1, args.steps) if "dec_segments" in prof else 0.0
-        dec_bytes = F * npx * 4 + total_stream_bytes / max(1, args.steps) / world
-        dec_achieved = dec_bytes / (seg_ms * 1e-3) / 1e9 if seg_ms > 0 else 0.0
+        stream_bytes = total_stream_bytes / max(1, launches) / world          # per launch of this rank
+        gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        achieved = gbs(alg_bytes, per_launch_ms)
+        # the kernel with the largest share of the step.  A decode call may run as several sub-batches (record arena cap):
+        # bytes and duration are both per LAUNCH (the call's bytes / its launches of this kernel).
+        seg_calls = prof["dec_segments"][1] if "dec_segments" in prof else 0
+        seg_ms = prof["dec_segments"][0] / max(1, seg_calls) if seg_calls else 0.0
+        seg_per_call = seg_calls / max(1, launches) if seg_calls else 1.0
+        dec_bytes = alg_bytes + stream_bytes               # stream read + 4 B written per pixel (whole decode)
+        enc_tot_ms, dec_tot_ms = enc_ms / max(1, launches), dec_ms / max(1, launches)
 
         slabs = (npx + 1023) // 1024
-        traffic, traffic_src = measured_traffic("qoimi::enc_slabs<4, 16, 1, 0, 1>", ((slabs + 3) // 4) * F * 256)
-        # the committed PMC run is this workload iff its enc_slabs launch had this grid (same frames, same shape)
-        dec_traffic, dec_traffic_src = measured_traffic("qoimi::dec_segments", -1) if traffic is not None and args.kind == "photo" else (None, None)
+        grid = ((slabs + 3) // 4) * F * 256
+        traffic, traffic_src = measured_traffic("qoimi::enc_slabs<4, 16, 1, 0, 1>", grid)
+        if traffic is None and args.kind == "photo" and (w, h) == (3840, 2160):        # PMC passes of a smaller batch of the same frames: per-frame traffic scales
+            for f_prof in (256, 64):
+                traffic, traffic_src = measured_traffic("qoimi::enc_slabs<4, 16, 1, 0, 1>", ((slabs + 3) // 4) * f_prof * 256, F / f_prof)
+                if traffic is not None:
+                    break
+        roof = lambda kernel, nbytes, ms, **kw: dict({"bound": "hbm", "kernel": kernel, "achieved": round(gbs(nbytes, ms), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                      "frac": round(gbs(nbytes, ms) / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 4)}, **kw)
         out = {
             "metric": "Mpixels/s encode+decode, 4K RGBA", "value": round(value, 1), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"batch of {F} x {w}x{h} RGBA frames per GPU per step (BASELINE configs[4]: 8192 such frames "
-                                   f"over 8 GPUs = 1024 per GPU; --frames 1024 runs that shard, the default keeps a quarter of it "
-                                   f"resident), encode + decode, content={args.kind}, HBM-resident, bit-exact round trip verified",
-                       "frames_per_gpu": F, "width": w, "height": h, "content": args.kind,
+            "config": {"workload": (f"batch of {F} x {w}x{h} RGBA frames per GPU per step = one GPU's shard of BASELINE configs[4] (8192 frames over 8 GPUs)"
+                                    if not strong else
+                                    f"BASELINE configs[4] strong scaling: {args.total_frames} x {w}x{h} RGBA frames in total, {args.total_frames // world} per GPU per step "
+                                    f"in {passes} pass(es) over {F} resident frames") +
+                                   f", encode + decode, content={args.kind}, HBM-resident, bit-exact round trip verified",
+                       "frames_per_gpu": F * passes, "frames_resident": F, "width": w, "height": h, "content": args.kind,
                        "stream_bytes_per_px": round(total_stream_bytes / total_px, 4), "parallelism": f"frames sharded x{world}"},
-            "verified_bit_exact": n_ok == world,
-            "encode_mpps_kernels": round(F * npx * args.steps / (enc_ms * 1e3), 1) if enc_ms else None,
-            "decode_mpps_kernels": round(F * npx * args.steps / (dec_ms * 1e3), 1) if dec_ms else None,
-            "decode_rounds": dstats["rounds"], "decode_redo_segments": dstats["redo_segments"],
+            "verified_bit_exact": n_ok == world, "reference_check": refcheck,
+            "encode_mpps_kernels": round(F * npx * launches / (enc_ms * 1e3), 1) if enc_ms else None,
+            "decode_mpps_kernels": round(F * npx * launches / (dec_ms * 1e3), 1) if dec_ms else None,
+            "decode_rounds": dstats["rounds"], "decode_redo_segments": dstats["redo_segments"], "decode_sync_fallback_segments": dstats.get("sync_fallback_segments"),
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
-            "roofline": {"bound": "hbm", "kernel": "enc_slabs (+ entry-state passes)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": round(per_launch_ms, 4)},
-            "roofline_decode": {"bound": "hbm", "kernel": "dec_segments_pair", "achieved": round(dec_achieved, 1), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(dec_achieved / HBM_PEAK_GBS, 4), "traffic": dec_traffic,
-                                "traffic_source": dec_traffic_src, "algorithmic_bytes_per_launch": int(dec_bytes),
-                                "ms_per_launch": round(seg_ms, 4),
-                                "note": "bound by resident lanes x instructions per chunk (LDS colour tables), not by HBM: DESIGN.md sections 2 and 4"},
+            "roofline": roof("enc_slabs (+ entry-state passes)", alg_bytes, per_launch_ms, traffic=traffic, traffic_source=traffic_src,
+                             note="the kernel of the north star's 4K-encode roofline target; the kernel with the largest share of the step is in roofline_dominant"),
         }
+        if not args.encode_only:
+            out["roofline_dominant"] = roof("dec_segments_rec", dec_bytes / seg_per_call, seg_ms, traffic=None, launches_per_decode_call=round(seg_per_call, 2),
+                                            note="largest share of the step; algorithmic bytes as SURVEY.md 8d defines them for decode (stream bytes + 4 B written per pixel) - "
+                                                 "the kernel itself reads one 4-byte chunk record per chunk instead of the stream (DESIGN.md section 4)")
+            out["roofline_decode_total"] = roof("whole qoimi_decode_batch (all kernels)", dec_bytes, dec_tot_ms, note="SURVEY.md 8d: stream bytes read + 4 B written per pixel")
+        out["roofline_encode_total"] = roof("whole qoimi_encode_batch (all kernels)", alg_bytes, enc_tot_ms, note="SURVEY.md 8d: 4 B read per pixel")
         if single:
             out["single_frame"] = single
+        if cfg2:
+            out["encode_1080p_batch"] = cfg2
+        if cfg3:
+            out["single_16k"] = cfg3
         if other:
             out["other_content"] = other
         if args.encode_only:

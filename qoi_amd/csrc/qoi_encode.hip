@@ -823,7 +823,7 @@ __global__ __launch_bounds__(64) void lds_order_selftest(uint32_t* out) {
 // host-side launcher
 // ---------------------------------------------------------------------------------
 template <int CH, int K, int PROBE, int ABL>
-static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm) {
+static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int phases) {
     const uint32_t total = p.n_images * p.spi;
     const uint32_t blocks = (total + 3u) / 4u;
     const uint32_t quads_per_image = (p.spi + 3u) / 4u;
@@ -832,6 +832,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm) {
     const bool warm = p.warm && PROBE == 1 && p.scratch;
     uint32_t small = 2048u;                                  // grid of the passes that usually have nothing to do
     tm->mark(kT_begin, st);
+    if (phases & kEncSlabs) {
     if (warm) {
         p.only_flagged = 0;
         hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL, 1>), dim3(p.n_units), dim3(256), 0, st, p);
@@ -849,7 +850,8 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm) {
     tm->mark(kT_enc_scan_images, st);
     hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL, 0>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
     tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
-    if (p.scratch) {
+    }
+    if (p.scratch && (phases & kEncPlace)) {
         hipLaunchKernelGGL(enc_offsets, dim3(p.n_images), dim3(1024), 0, st, p);
         tm->mark(kT_enc_offsets, st);
         hipLaunchKernelGGL(enc_compact, dim3(blocks), dim3(256), 0, st, p);
@@ -857,13 +859,13 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm) {
     }
 }
 
-void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm) {
+void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phases) {
     if (p.channels == 3) {
-        if (p.probe_xchg) launch_encode_t<3, kEncSteps, 1, 0>(p, st, tm); else launch_encode_t<3, kEncSteps, 0, 0>(p, st, tm);
+        if (p.probe_xchg) launch_encode_t<3, kEncSteps, 1, 0>(p, st, tm, phases); else launch_encode_t<3, kEncSteps, 0, 0>(p, st, tm, phases);
         return;
     }
-    if (!p.probe_xchg) { launch_encode_t<4, kEncSteps, 0, 0>(p, st, tm); return; }
-    launch_encode_t<4, kEncSteps, 1, 0>(p, st, tm);
+    if (!p.probe_xchg) { launch_encode_t<4, kEncSteps, 0, 0>(p, st, tm, phases); return; }
+    launch_encode_t<4, kEncSteps, 1, 0>(p, st, tm, phases);
 }
 
 // returns the number of mismatching patterns of the LDS exchange-order self-test (0 = ordered)

@@ -15,7 +15,9 @@ constexpr int kHeaderBytes = 14, kTrailerBytes = 8;   // qoi.h:326, qoi.h:339
 enum KernelTag { kT_begin = 0,
                  kT_enc_summary, kT_enc_scan_groups, kT_enc_scan_images, kT_enc_slabs, kT_enc_slabs_generic, kT_enc_offsets, kT_enc_compact,
                  kT_dec_parse, kT_dec_chain_parse, kT_dec_slot_walk, kT_dec_chain_slots, kT_dec_summarize,
-                 kT_dec_chain_state, kT_dec_segments, kT_dec_restart, kT_dec_fill, kT_count };
+                 kT_dec_chain_state, kT_dec_segments, kT_dec_restart, kT_dec_fill,
+                 kT_enc_total, kT_dec_total,    // a whole qoimi_encode_batch / qoimi_decode_batch on the caller's stream (kernels of a call may overlap)
+                 kT_count };
 struct KernelTimer {
     static constexpr int kMax = 512;
     hipEvent_t ev[kMax]; int tag[kMax]; int n = 0; bool on = false; bool created = false;
@@ -64,7 +66,10 @@ struct EncParams {
     uint8_t* out; size_t out_stride; int* out_len;
 };
 
-void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm);
+// what of an encode a call launches: the slab passes (pixels -> parked slab bytes + sizes), the placement passes
+// (exclusive scan of the sizes + compaction), or both back to back
+enum EncPhase { kEncSlabs = 1, kEncPlace = 2, kEncAll = 3 };
+void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phases = kEncAll);
 int run_lds_order_selftest(hipStream_t st);
 
 // ---- decode ------------------------------------------------------------------------

@@ -10,7 +10,7 @@ for rep in $(seq 1 ${REPS:-1}); do
 for a in "${AS[@]}"; do
   name=${a%%:*}; envs=${a#*:}
   for kind in ${KINDS:-photo}; do
-    env $envs timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu --no-others --kind $kind ${BENCH_ARGS:-} > $OUT/${name}_${kind}_$rep.log 2>&1; echo "rc=$?" >> $OUT/${name}_${kind}_$rep.log
+    env $envs timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu --no-others --no-configs --frames ${FRAMES:-256} --kind $kind ${BENCH_ARGS:-} > $OUT/${name}_${kind}_$rep.log 2>&1; echo "rc=$?" >> $OUT/${name}_${kind}_$rep.log
     python - $OUT/${name}_${kind}_$rep.log $name <<'PY'
 import json,sys
 ok=False
@@ -18,7 +18,7 @@ for l in open(sys.argv[1]):
     if l.startswith('{'):
         ok=True
         d=json.loads(l); k=d['kernel_ms_per_step']
-        enc=sum(v for x,v in k.items() if x.startswith('enc_')); dec=sum(v for x,v in k.items() if x.startswith('dec_'))
+        enc=k.get('encode_total') or sum(v for x,v in k.items() if x.startswith('enc_')); dec=k.get('decode_total') or sum(v for x,v in k.items() if x.startswith('dec_'))
         print(sys.argv[2], d['config']['content'], 'value', d['value'], 'ms', d['ms_per_step'], 'exact', d['verified_bit_exact'], 'rounds', d.get('decode_rounds'), 'enc_ms', round(enc,3), 'dec_ms', round(dec,3), 'single', (d.get('single_frame') or {}).get('ms'))
         print('   ', {x:k[x] for x in k if k[x]>0.02})
 if not ok:
