@@ -2208,6 +2208,52 @@ __global__ __launch_bounds__(256) void dec_fill(DecParams p) {
     }
 }
 
+// Last resort of the repair loop.  Every round verifies at least one more segment per image, so the loop terminates - but a
+// stream built to defeat the speculation (say, QOI_OP_INDEX on slots whose content does not hash there, segment after
+// segment) could ask for as many rounds as it has segments, each a relaunch over all of them: quadratic.  After
+// kMaxSpecRounds rounds the images that are still open are finished here instead: ONE lane per image walks the remaining
+// chunk records in order from the last verified state - a plain qoi.h:540-587 decode, linear in the stream whatever it
+// holds (about the speed of one CPU core; encoder-made content never gets here).
+template <int OCH>
+__global__ __launch_bounds__(64) void dec_sequential(DecParams p) {
+    __shared__ uint32_t s_tab[64];
+    const uint32_t img = blockIdx.x, lane = lane_id();
+    const DecImage im = p.images[img];
+    if (im.start_seg >= im.n_active) return;                           // verified already
+    const size_t q0 = (size_t)im.seg_base + im.start_seg;
+    s_tab[lane] = p.entry[q0 * 65u + lane];                           // the TRUE state at start_seg (dec_prepare_restart)
+    uint32_t px = p.entry[q0 * 65u + 64u];
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0u) return;
+    uint8_t* out = p.pixels + (size_t)img * p.pixel_stride;
+    uint32_t pos = p.px_off[q0], stash = 0u;
+    const uint32_t limit = im.npx;
+    for (uint32_t j = im.start_seg; j < im.n_active && pos < limit; ++j) {
+        const uint32_t q = im.seg_base + j;
+        const uint32_t* col = p.recs + ((size_t)(q >> 6) * p.rec_rows * 64u + (q & 63u)) * 4u;      // granule g of this segment at col + g*256
+        const uint32_t n = p.rec_gran[q];
+        for (uint32_t g = 0; g < n && pos < limit; ++g) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(col + (size_t)g * 256u);
+            const uint32_t rr[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t k = 0; k < 4u && pos < limit; ++k) {
+                const uint32_t rec = rr[k], cls = rec_class(rec);
+                if (cls == 2u && rec_pixels(rec) == kRecStash) { stash = rec & 0x00FFFFFFu; continue; }
+                const uint32_t t = s_tab[rec & 63u];
+                px = cls == 0u ? add_bytes(px, rec & 0x00FFFFFFu) : cls == 1u ? t : cls == 2u ? (px & 0xFF000000u) | (rec & 0x00FFFFFFu) : stash | ((rec & 0xFFu) << 24);
+                s_tab[hash_px(px)] = px;                                // qoi.h:577
+                uint32_t stop = pos + rec_pixels(rec);
+                if (stop > limit) stop = limit;                         // over-long run clipped (Appendix B item 8)
+                for (; pos < stop; ++pos) {
+                    if (OCH == 4) reinterpret_cast<uint32_t*>(out)[pos] = px;
+                    else { uint8_t* d = out + (size_t)pos * 3u; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
+                }
+            }
+        }
+    }
+    p.images[img].final_px = px;
+    p.images[img].start_seg = im.n_active;
+}
+
 // Concrete start state of every image: {0,0,0,255} and a zeroed table (qoi.h:533-537).
 __global__ __launch_bounds__(64) void dec_init_state(DecParams p) {
     const uint32_t img = blockIdx.x, lane = lane_id();
@@ -2298,6 +2344,13 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     tm->mark(kT_dec_segments, st);
     hipLaunchKernelGGL(dec_prepare_restart, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_dec_restart, st);
+}
+
+void launch_decode_sequential(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm) {
+    tm->mark(kT_begin, st);
+    if (out_channels == 4) hipLaunchKernelGGL(dec_sequential<4>, dim3(p.n_images), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(dec_sequential<3>, dim3(p.n_images), dim3(64), 0, st, p);
+    tm->mark(kT_dec_segments, st);
 }
 
 void launch_decode_fill(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm) {

@@ -95,6 +95,8 @@ struct qoimi_ctx {
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
     int dec_pair = 3;                   // bit 0: P4, bit 1: P3 run as reader / worker wavefront pairs; 0: one wavefront per 64 segments
+    int dec_max_rounds = kMaxSpecRounds;   // speculation rounds before the sequential last resort (env QOIMI_DEC_MAX_ROUNDS, tests)
+    long long dec_seq_images = 0;       // images finished by dec_sequential since the context was created
     int dec_rec = 1;                    // 1: chunk records (dec_transcode + dec_summarize_rec + dec_segments_rec); 0: the round-1 byte-stream passes
     size_t dec_rec_cap = (size_t)16 << 30;   // largest record arena: a call whose streams need more is decoded in sub-batches
     KernelTimer timer;                  // optional per-kernel HIP-event timing
@@ -145,6 +147,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_PAIR")) c->dec_pair = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_REC")) c->dec_rec = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
     if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
     if (const char* e = getenv("QOIMI_SEG_BYTES")) {
         long v = atol(e);
@@ -414,7 +417,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     HIP_TRY(hipMemsetAsync(p.redo_segs, 0, 2 * sizeof(uint32_t), st));       // redo_segs, sync_fails
 
     launch_decode_parse(p, st, &c->timer);
-    long long rounds = 0;
+    long long rounds = 0, stats_seq = 0;
     for (;;) {
         HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
         launch_decode_round(p, och, rounds > 0 && c->dec_refine, st, &c->timer);
@@ -428,6 +431,15 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         HIP_TRY(hipStreamSynchronize(st));
         timer_collect(c);
         if (c->host_word[0] == 0) break;
+        if (p.use_rec && rounds >= c->dec_max_rounds) {
+            // bounded: whatever is still open is finished by the linear sequential pass (see dec_sequential)
+            launch_decode_sequential(p, och, st, &c->timer);
+            launch_decode_fill(p, och, st, &c->timer);
+            c->timer.mark(kT_dec_total, st);
+            HIP_TRY(hipStreamSynchronize(st));
+            stats_seq = (long long)c->host_word[0];
+            break;
+        }
         if (rounds > (long long)total + 2) return fail(QOIMI_E_INTERNAL, "decode repair loop did not converge");
     }
     HIP_TRY(hipGetLastError());
@@ -436,6 +448,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     stats[1] = p.total_segs ? c->host_word[1] : 0;
     stats[2] = (long long)total;
     stats[3] = p.total_segs ? c->host_word[2] : 0;
+    c->dec_seq_images += stats_seq;
     return QOIMI_OK;
 }
 

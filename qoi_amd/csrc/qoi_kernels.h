@@ -135,6 +135,8 @@ struct DecParams {
 void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm);
 void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipStream_t st, KernelTimer* tm);
 void launch_decode_fill(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);
+void launch_decode_sequential(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);   // record pipeline only
+constexpr int kMaxSpecRounds = 24;   // speculation rounds before the images still open are finished sequentially
 
 // ---- synthetic frames --------------------------------------------------------------
 struct SynthParams {

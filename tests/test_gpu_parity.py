@@ -362,6 +362,65 @@ def test_decode_batch_many_small_images(api, ctx, oracle):
             assert got_all[i * pstride + want.size] == 0xCD or want.size == pstride, "wrote past the image"
 
 
+def _hostile_stream(n_chunks, w, h):
+    """QOI_OP_INDEX on slots whose content does not hash there (never-written slots hold {0,0,0,0}, which hashes to 0), mixed
+    with relative chunks: every segment's slot speculation is wrong, the repair loop would verify one segment per round."""
+    import struct
+    body = bytearray()
+    for i in range(n_chunks):
+        k = i % 11
+        body.append((5 + 3 * (i % 7)) if k in (0, 3, 7) else 0x6A + (i % 5) if k in (1, 4, 8) else 0xC0 + (i % 3) if k == 5 else (0x20 + i % 13))
+    return b"qoif" + struct.pack(">II", w, h) + bytes([4, 0]) + bytes(body) + bytes([0, 0, 0, 0, 0, 0, 0, 1])
+
+
+@pytest.mark.parametrize("rounds", ["1", "3"])
+def test_decode_repair_loop_is_bounded(api, oracle, rounds):
+    """a stream that defeats the speculation in every segment must not cost a round per segment.  With the round
+    limit forced down the sequential last resort (dec_sequential) finishes the image - bit-exact like everything else."""
+    import torch
+    from qoi_amd import synth
+    os.environ["QOIMI_DEC_MAX_ROUNDS"] = rounds
+    os.environ["QOIMI_SEG_BYTES"] = "128"
+    try:
+        c = api.Context(0)
+        w, h = 512, 300
+        streams = [_hostile_stream(60000, w, h), oracle.encode(synth.frame_rgba("uiflat", w, h, 101), w, h, 4),
+                   oracle.encode(synth.frame_rgba("photo", w, h, 5), w, h, 4)]
+        sstride = (max(len(s) for s in streams) + 8 + 255) // 256 * 256
+        host = np.zeros(len(streams) * sstride, dtype=np.uint8)
+        for i, s in enumerate(streams):
+            host[i * sstride:i * sstride + len(s)] = np.frombuffer(s, dtype=np.uint8)
+        buf = torch.from_numpy(host).cuda()
+        for och in (4, 3):
+            pstride = (w * h * och + 255) // 256 * 256
+            out = torch.full((len(streams) * pstride,), 0xCD, dtype=torch.uint8, device="cuda")
+            c.decode_batch(buf.data_ptr(), sstride, [len(s) for s in streams], [api.QoiDesc(w, h, 4, 0)] * len(streams), och, out.data_ptr(), pstride)
+            st = c.decode_stats()
+            assert st["rounds"] <= int(rounds), st
+            got = out.cpu().numpy()
+            for i, s in enumerate(streams):
+                want, _ = oracle.decode(s, och)
+                assert np.array_equal(got[i * pstride:i * pstride + want.size], want), (och, i)
+        c.close()
+    finally:
+        del os.environ["QOIMI_DEC_MAX_ROUNDS"]
+        del os.environ["QOIMI_SEG_BYTES"]
+
+
+def test_hostile_stream_finishes_in_bounded_rounds(api, ctx, oracle):
+    """The same hostile stream with the default limits: the number of rounds stays below the limit of the library however
+    many segments mis-speculate (round 1 would have taken one round per segment: thousands)."""
+    import torch
+    w, h = 1024, 600
+    s = _hostile_stream(500000, w, h)
+    buf = torch.from_numpy(np.frombuffer(s + b"\0" * 8, dtype=np.uint8).copy()).cuda()
+    out = torch.full((w * h * 4 + 8,), 0xCD, dtype=torch.uint8, device="cuda")
+    ctx.decode_batch(buf.data_ptr(), buf.numel(), [len(s)], [api.QoiDesc(w, h, 4, 0)], 4, out.data_ptr(), w * h * 4)
+    assert ctx.decode_stats()["rounds"] <= 24
+    want, _ = oracle.decode(s, 4)
+    assert np.array_equal(out[:w * h * 4].cpu().numpy(), want)
+
+
 def test_decode_batch_over_65535_images(api, ctx, oracle):
     """70 000 tiny images in one decode call (a grid dimension of round 1 stopped at 65 535), a third of them truncated so
     that the tail fill (qoi.h:544) runs for them."""
