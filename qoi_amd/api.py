@@ -123,6 +123,10 @@ def qoi_encode(data, desc: QoiDesc) -> Optional[bytes]:
     lib = load_library()
     arr = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray))
                                else np.asarray(data, dtype=np.uint8))
+    # the C function cannot know how long `data` is (qoi.h:278 trusts width*height*channels); this wrapper can: a short
+    # buffer would make the copy engine read past the allocation
+    if _desc_plausible(desc) and arr.size < desc.width * desc.height * desc.channels:
+        return None
     n = ctypes.c_int(0)
     p = lib.qoi_encode(arr.ctypes.data, ctypes.byref(desc), ctypes.byref(n))
     if not p:
@@ -131,6 +135,12 @@ def qoi_encode(data, desc: QoiDesc) -> Optional[bytes]:
         return ctypes.string_at(p, n.value)
     finally:
         _libc_free(p)
+
+
+def _desc_plausible(desc: QoiDesc) -> bool:
+    """qoi.h:364-372's rules - only where they hold does width*height*channels say how many bytes the codec will read."""
+    return (desc.width > 0 and desc.height > 0 and desc.channels in (3, 4) and desc.colorspace <= 1
+            and desc.height < 400000000 // desc.width)
 
 
 def qoi_decode(data: bytes, channels: int = 0, size: Optional[int] = None
@@ -152,6 +162,8 @@ def qoi_decode(data: bytes, channels: int = 0, size: Optional[int] = None
 def qoi_write(filename: str, data, desc: QoiDesc) -> int:
     """``qoi_write`` (qoi.h:252): returns bytes written, 0 on failure."""
     arr = np.ascontiguousarray(np.asarray(data, dtype=np.uint8))
+    if _desc_plausible(desc) and arr.size < desc.width * desc.height * desc.channels:
+        return 0                                     # short pixel buffer: as a failed qoi_write (qoi.h:259-263)
     return int(load_library().qoi_write(filename.encode(), arr.ctypes.data, ctypes.byref(desc)))
 
 
@@ -210,6 +222,10 @@ class Context:
     def decode_batch(self, d_streams: int, stream_stride: int, sizes: Sequence[int], descs: Sequence[QoiDesc],
                      channels: int, d_pixels: int, pixel_stride: int, stream: int = 0) -> None:
         n = len(sizes)
+        if len(descs) != n:
+            raise QoiError(f"decode_batch: {n} sizes but {len(descs)} descriptors")
+        if n > 1 and any(int(sz) > stream_stride for sz in sizes):
+            raise QoiError("decode_batch: a stream is longer than stream_stride")
         c_sizes = (ctypes.c_int * n)(*[int(s) for s in sizes])
         c_descs = (QoiDesc * n)(*descs)
         self._check(self._lib.qoimi_decode_batch(self._h, d_streams, stream_stride, c_sizes, c_descs, n, channels,
@@ -225,9 +241,9 @@ class Context:
 
     def get_profile(self, stream: int = 0) -> dict:
         """kernel name -> (accumulated ms, launches) since profiling was enabled (syncs stream)."""
-        ms = (ctypes.c_double * 32)()
-        calls = (ctypes.c_longlong * 32)()
-        n = self._lib.qoimi_get_profile(self._h, stream, ms, calls, 32)
+        ms = (ctypes.c_double * 64)()
+        calls = (ctypes.c_longlong * 64)()
+        n = min(64, self._lib.qoimi_get_profile(self._h, stream, ms, calls, 64))
         return {self._lib.qoimi_kernel_name(i).decode(): (ms[i], calls[i]) for i in range(1, n)}
 
     def decode_stats(self) -> dict:

@@ -778,11 +778,20 @@ __global__ __launch_bounds__(256) void enc_compact(EncParams p) {
 
 // Measures whether one ds_wrxchg_rtn_b32 serves same-address lanes in ascending lane order
 // (see PROBE above).  out[0] = number of mismatching patterns (0: PROBE 1 is usable).
-__global__ __launch_bounds__(64) void lds_order_selftest(uint32_t* out) {
-    __shared__ uint32_t tab[64];
+// What PROBE 1 rests on is a measured property, not a documented one, so it is measured where it matters: alone and under
+// contention at context creation, and again every 256 encode calls of a context while it runs (qoi_host.hip; the result is
+// read at the following call: a failure switches the context to the order-free probe and reports the call as failed).
+// (An in-kernel cross-check of one slab in 64 against the order-free rule was tried in round 2: its extra instantiation
+// cost the whole kernel 28 bytes of scratch per lane and 5 % of its time.)
+// WAVES wavefronts per workgroup run the test at the same time, each on its own 64 words: with WAVES = 4 and a grid that
+// fills every CU sixteen of them hammer one LDS at once (the stress variant the round-1 review asked for).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void lds_order_selftest(uint32_t* out) {
+    __shared__ uint32_t tabs[WAVES][64];
+    uint32_t* tab = tabs[threadIdx.x >> 6];
     const uint32_t lane = lane_id();
     uint32_t bad = 0;
-    uint32_t rng = 0x9E3779B9u * (blockIdx.x + 1u) + lane * 0x85EBCA6Bu;
+    uint32_t rng = 0x9E3779B9u * (blockIdx.x * WAVES + (threadIdx.x >> 6) + 1u) + lane * 0x85EBCA6Bu;
     for (int it = 0; it < 256; ++it) {
         rng = rng * 1664525u + 1013904223u;
         const uint32_t nb = 1u << ((it % 7));                          // 1..64 distinct slots
@@ -869,11 +878,19 @@ void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phas
 }
 
 // returns the number of mismatching patterns of the LDS exchange-order self-test (0 = ordered)
+// asynchronous form: zeroes *d_out and launches both variants on st; *d_out != 0 afterwards = the order does not hold
+void launch_lds_order_selftest(uint32_t* d_out, hipStream_t st) {
+    (void)hipMemsetAsync(d_out, 0, sizeof(uint32_t), st);
+    hipLaunchKernelGGL(lds_order_selftest<1>, dim3(256), dim3(64), 0, st, d_out);
+    hipLaunchKernelGGL(lds_order_selftest<4>, dim3(1024), dim3(256), 0, st, d_out);
+}
+
 int run_lds_order_selftest(hipStream_t st) {
     uint32_t* d = nullptr;
     if (hipMalloc((void**)&d, sizeof(uint32_t)) != hipSuccess) return -1;
     (void)hipMemsetAsync(d, 0, sizeof(uint32_t), st);
-    hipLaunchKernelGGL(lds_order_selftest, dim3(512), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(lds_order_selftest<1>, dim3(512), dim3(64), 0, st, d);          // one wavefront per workgroup
+    hipLaunchKernelGGL(lds_order_selftest<4>, dim3(2048), dim3(256), 0, st, d);        // sixteen per CU at once
     uint32_t h = 1;
     if (hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) h = 0xFFFFFFFFu;
     (void)hipFree(d);

@@ -90,6 +90,8 @@ struct qoimi_ctx {
     uint32_t seg_bytes = 0;     // decode segment size; 0: chosen per call from the batch's stream bytes
     uint32_t* last_enc_err = nullptr;   // device flag of the most recent encode launch
     bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
+    long long enc_calls = 0;            // encode calls so far: the self-test is repeated every 256 of them
+    bool recheck_pending = false;       // a repeated self-test is in flight on own_stream, result in host_word[8]
     int enc_ablate = 0, enc_ticket = 1, enc_quads = 0, enc_warm = 1;   // tuning / profiling knobs (env QOIMI_ENC_*)
     int enc_lookback = 0;               // 1: single-pass decoupled look-back instead of scratch + compaction
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
@@ -244,6 +246,20 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.spi = (uint32_t)((npx + kEncSlabPx - 1) / kEncSlabPx);
     p.gpi = (p.spi + 63u) / 64u;
     p.width = desc->width; p.height = desc->height; p.channels = desc->channels; p.colorspace = desc->colorspace;
+    // The ordered-exchange probe rests on a measured hardware property (qoi_encode.hip): measure it again as the context
+    // lives on.  The repeat runs on the context's private stream; its result is looked at by the next call.
+    if (c->recheck_pending && hipStreamQuery(c->own_stream) == hipSuccess) {
+        c->recheck_pending = false;
+        if (c->host_word[8] != 0u) {
+            c->xchg_ordered = false;
+            return fail(QOIMI_E_INTERNAL, "the LDS exchange-order self-test failed on repetition: streams encoded since the last check are suspect; this context now uses the order-free probe");
+        }
+    }
+    if (c->xchg_ordered && !c->recheck_pending && (++c->enc_calls & 255) == 0 && c->io_c.reserve(256) == QOIMI_OK) {
+        uint32_t* d_flag = (uint32_t*)c->io_c.base + 32;
+        launch_lds_order_selftest(d_flag, c->own_stream);
+        if (hipMemcpyAsync(&c->host_word[8], d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->own_stream) == hipSuccess) c->recheck_pending = true;
+    }
     p.probe_xchg = c->xchg_ordered ? 1 : 0;
     p.use_ticket = c->enc_ticket ? 1 : 0;
     p.ablate = (uint8_t)c->enc_ablate;

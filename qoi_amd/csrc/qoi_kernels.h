@@ -71,6 +71,7 @@ struct EncParams {
 enum EncPhase { kEncSlabs = 1, kEncPlace = 2, kEncAll = 3 };
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phases = kEncAll);
 int run_lds_order_selftest(hipStream_t st);
+void launch_lds_order_selftest(uint32_t* d_out, hipStream_t st);
 
 // ---- decode ------------------------------------------------------------------------
 struct ParseRec; struct SlotRec;

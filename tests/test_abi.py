@@ -67,3 +67,13 @@ def test_no_cpu_fallback_without_gpu(lib):
     assert api.qoi_encode(px, api.QoiDesc(4, 4, 4, 0)) is None
     with pytest.raises(api.QoiError):
         api.Context(0)
+
+
+def test_python_wrapper_rejects_short_buffers():
+    """qoi_amd.api.qoi_encode / qoi_write check what the C functions cannot: that the pixel buffer is as long as the
+    descriptor says.  No GPU is touched: the check comes first."""
+    import numpy as np
+    from qoi_amd import api
+    short = np.zeros(100, dtype=np.uint8)
+    assert api.qoi_encode(short, api.QoiDesc(64, 64, 4, 0)) is None
+    assert api.qoi_write("/tmp/qoi_mi355x_never_written.qoi", short, api.QoiDesc(64, 64, 3, 0)) == 0
