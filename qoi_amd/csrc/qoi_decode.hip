@@ -1655,24 +1655,79 @@ __global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
 // codes): EIGHT per CU, each stepping through ~35-40 instructions per chunk with its records arriving as 16-byte
 // buffer loads a block of eight steps ahead - no LDS ring, no cursor, a wave-uniform loop count.
 // =====================================================================================
-// Ring of 64 dwords per lane, topped up by whole 128-byte lines (8 x 16 bytes issued together) that land two periods of four
-// steps later.  With 32-byte pieces (16 wavefronts per CU) the pass moved 17.8 GB per 256 4K frames in 3.8 ms - it was
-// bound by HBM on its own re-reads: FETCH_SIZE 3.6 x the stream bytes, a lane's next piece of a line came after the line
-// had left the L2 (profiles/r02).  A lane now asks for every line exactly once.
-#ifndef QOIMI_TR_RD
-#define QOIMI_TR_RD 32
-#define QOIMI_TR_NP 2
-#define QOIMI_TR_PERIOD 4
-#define QOIMI_TR_LINE 1
-#define QOIMI_TR_DELAY 0
+// PipeReader: the byte source of dec_transcode.  Same LDS ring as LaneReaderT (32 dwords per lane + mirror, [dword][lane]), but
+// the refill is a STATIC pipeline three periods deep: every period of four steps every lane issues one 32-byte request (two
+// 16-byte loads; lanes whose ring has no room read a dummy line all lanes share) into one of three register sets, and lands
+// the set it issued three periods earlier.  The number of loads per period does not depend on the data, so the wait before
+// landing is `s_waitcnt vmcnt(N)`: the line asked for twelve steps ago, not the ones asked for since.  With LaneReaderT's
+// land-next-period scheme a wavefront waited for HBM almost every period (some lane of 64 always has a fresh request out):
+// SQ_WAIT_ANY 55 % of the wavefront cycles (profiles/r02), whatever the ring size or the occupancy.
+// Worst case (every chunk five bytes): a period consumes 20 bytes (+ 13 of look-ahead); with 128 bytes of ring, 32-byte
+// requests and up to three in flight the unread part never falls below 40 bytes (simulated over all phases).
+struct PipeReader {
+    static constexpr uint32_t RD = 32, kSlots = RD + 1, kPeriod = 4;
+    uint32_t ring;             // LDS byte address of ring[0][lane]
+    const uint8_t* abase;      // 32-byte aligned start of the fetched range
+    const uint8_t* alast;      // last 16-byte granule that starts before stream + size
+    const uint8_t* dummy;      // 16 readable bytes every idle lane loads instead (one line for the whole wavefront)
+    uint32_t aoff;             // abase - stream
+    uint32_t wr;               // dwords landed, counted from abase
+    uint32_t req;              // dwords requested (landed + in flight)
+    uint4 set[3][2];
+    bool valid[3];
+    __device__ __forceinline__ uint4 load16(const uint8_t* p, bool go) const {
+        const uint8_t* q = p < alast ? p : alast;                 // a granule past the end is replaced by the last one inside
+        return load_global16(go ? q : dummy);
+    }
+    __device__ __forceinline__ void put4(uint32_t at, const uint4& v) {
+        const uint32_t a = ring + (at & (RD - 1u)) * 256u;
+        lds_u32* q = (lds_u32*)a;
+        q[0] = v.x; q[64] = v.y; q[128] = v.z; q[192] = v.w;
+        if ((at & (RD - 1u)) == 0u) ((lds_u32*)ring)[RD * 64u] = v.x;         // mirror of slot 0
+    }
+    __device__ __forceinline__ void init(uint32_t ring_addr, const uint8_t* stream, uint32_t pos0, uint32_t size, const uint8_t* dummy16) {
+        ring = ring_addr; dummy = dummy16;
+        const uint8_t* p = stream + pos0;
+        abase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)31);
+        alast = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(stream + size - 1u) & ~(uintptr_t)15);
+        aoff = pos0 - (uint32_t)(p - abase);
+        uint4 v[RD / 4u];
+#pragma unroll
+        for (uint32_t r = 0; r < RD / 4u; ++r) v[r] = load16(abase + 16u * r, true);
+#pragma unroll
+        for (uint32_t r = 0; r < RD / 4u; ++r) put4(4u * r, v[r]);
+        wr = req = RD;
+        valid[0] = valid[1] = valid[2] = false;
+    }
+    __device__ __forceinline__ void peek(uint32_t pos, uint32_t& w32, uint32_t& b5) const {
+        const uint32_t rp = pos - aoff;
+        const lds_u32* q = (const lds_u32*)(ring + ((rp >> 2) & (RD - 1u)) * 256u);
+        const uint32_t d0 = q[0], d1 = q[64];
+        const uint32_t sh = (rp & 3u) * 8u;
+        w32 = __builtin_amdgcn_alignbit(d1, d0, sh);
+        b5 = (d1 >> sh) & 0xFFu;
+    }
+    // one period's memory work for register set S (compile-time 0..2): land what S holds (asked for three periods ago), ask again
+    template <int S>
+    __device__ __forceinline__ void turn(uint32_t pos) {
+        if (valid[S]) { put4(wr, set[S][0]); put4(wr + 4u, set[S][1]); wr += 8u; }
+        const uint32_t space = RD - (req - ((pos - aoff) >> 2));      // dwords neither unread nor on their way
+#ifdef QOIMI_TR_ABL_NOLOAD
+        const bool go = space >= 8u && pos == 0xFFFFFFFFu;            // ablation: never a real request
+#else
+        const bool go = space >= 8u;
 #endif
-#ifndef QOIMI_TR_DELAY
-#define QOIMI_TR_DELAY 0
-#endif
+        set[S][0] = load16(abase + (size_t)req * 4u, go);
+        set[S][1] = load16(abase + (size_t)req * 4u + 16u, go);
+        valid[S] = go;
+        req += go ? 8u : 0u;
+    }
+};
+
 #ifndef QOIMI_TR_WAVES
 #define QOIMI_TR_WAVES 4
 #endif
-typedef LaneReaderT<QOIMI_TR_RD, QOIMI_TR_NP, QOIMI_TR_PERIOD, 8, QOIMI_TR_LINE != 0, QOIMI_TR_DELAY> TransReader;
+typedef PipeReader TransReader;
 constexpr uint32_t kTrThreads = 64u * QOIMI_TR_WAVES;
 struct LdsLutT { uint32_t tpl[256], info[256]; };   // record template; chunk-table word with QOI_OP_RGBA's length set to 0 (visited twice)
 
@@ -1718,21 +1773,23 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     TransReader R;
     uint32_t pos;
     bool failed = false;
+    const uint8_t* dummy16 = reinterpret_cast<const uint8_t*>(p.images);        // any 16 readable bytes: what lanes without a request load
     if (MODE == 1) {
         pos = base + (have ? p.entry_phase[q] : 0u);
-        R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
+        R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes, dummy16);
     } else {
         // ---- look-back synchronisation ------------------------------------------------------------------------------
         const bool from_start = base <= (uint32_t)kHeaderBytes + kSyncBytes;      // the stream's first chunk is in reach: one chain from byte 14
         const uint32_t t0 = from_start ? (uint32_t)kHeaderBytes : base - kSyncBytes;
-        R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, t0, im.chunks_end + kTrailerBytes);
+        R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, t0, im.chunks_end + kTrailerBytes, dummy16);
         ParseState s; parse_init(s, t0);
         if (from_start) { s.p1 = s.p2 = s.p3 = s.p4 = t0; }
         uint32_t m = t0;
         bool merged = from_start;
         bool going = have && m < base;
-        for (uint32_t it = 0; lanes_where(going); ++it) {
-            if (R.due(it)) R.refill(m);
+        auto sync_steps = [&]() {
+#pragma unroll
+          for (uint32_t u = 0; u < TransReader::kPeriod; ++u) {
             if (going) {
                 uint32_t w32, b5; R.peek(m, w32, b5);
                 const uint32_t b1 = w32 & 0xFFu;
@@ -1745,6 +1802,12 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                 }
                 going = m < base;
             }
+          }
+        };
+        while (lanes_where(going)) {                              // three periods per turn of the register sets (PipeReader)
+            R.turn<0>(m); sync_steps();
+            R.turn<1>(m); sync_steps();
+            R.turn<2>(m); sync_steps();
         }
         failed = have && !merged;
         pos = m;                                              // merged: the first chunk start at or behind the segment start
@@ -1752,22 +1815,19 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         const u64 fails = lanes_where(failed);
         if (have) p.sync_fail[q] = failed ? 1 : 0;
         if (fails != 0 && lane == (uint32_t)__builtin_ctzll(fails)) atomicAdd(p.sync_fails, (uint32_t)__builtin_popcountll(fails));
-        R.refill(pos);                                        // lands what the last period asked for, asks from the entry position on
     }
     bool active = have && !failed && pos < end;
     uint32_t w32, b5; R.peek(pos, w32, b5);
     uint32_t tpl, info;
     {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); tpl = lq[0]; info = lq[256]; }
-    SlotFast st; slotf_init(st);
+    uint32_t a_abs = 0u, a_last = 0u;            // a QOI_OP_RGBA occurred in the segment / the alpha of the last one (for dec_slot_tails)
     uint32_t pend = 0u;                          // 1: the stash record of the QOI_OP_RGBA chunk under the cursor is out
     bool any_pend = false;
     uint32_t ngran = 0u, npix = 0u;
     // granule row g of this wavefront's 64 segments: one contiguous KiB
     u32x4* dst = reinterpret_cast<u32x4*>(p.recs + (size_t)(blockIdx.x * QOIMI_TR_WAVES + wave) * p.rec_rows * 256u) + lane;
-    while (lanes_where(active)) {
-        R.land(); R.issue(pos);
-#pragma unroll
-        for (uint32_t g = 0; g < TransReader::kPeriod / 4u; ++g) {
+    auto granule_steps = [&]() {
+        {
             const bool live = active;                                    // the granule holds at least one record of this lane
             uint32_t rr[4];
 #pragma unroll
@@ -1780,31 +1840,19 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                 const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
                 add_byte0(rec, er); add_byte2_from0(rec, eb);
                 uint32_t cnt = (rec >> 24) & 63u;                        // pixels of the chunk (qoi.h:573-575); the stash marker is set right below
-                // speculative slot/alpha transfer (slotf_step_split): QOI_COLOR_HASH is linear mod 64, so a relative chunk
-                // shifts the slot by the hash of its delta; QOI_OP_INDEX names it
-                const bool lo = lut_lo(c_info);
-                const uint32_t rel = st.hc + __builtin_amdgcn_udot4(rec, 0x00070503u, 0u, false);
-                uint32_t hc = lo ? (w32 & 0xFFu) : rel;
-                uint32_t fl = lo ? (st.fl & 4u) : st.fl;
                 if (lanes_where(lut_hi(c_info)) != 0 || any_pend) {     // QOI_OP_RGB / QOI_OP_RGBA somewhere in the wavefront (rare in natural images)
-                    const bool hi = lut_hi(c_info);
+                    const bool hi = lut_hi(c_info), lo = lut_lo(c_info);
                     const bool rgba = hi && lo, second = rgba && pend != 0u, first = rgba && pend == 0u;
                     const uint32_t rgb = (w32 >> 8) & 0x00FFFFFFu;
                     const uint32_t rec_hi = second ? rec_make(3u, 1u, b5) : (rec | rgb);      // rec still is the class-2 template here
                     rec = hi ? rec_hi : rec;
                     adv = second ? 5u : adv;
                     cnt = first ? 0u : (second ? 1u : cnt);
-                    const bool a_abs = (st.fl & 4u) != 0u;
-                    const uint32_t lrgb = __builtin_amdgcn_udot4(rgb, 0x00070503u, 0u, false);
-                    const uint32_t hb = lrgb + (lo ? 11u * b5 : (a_abs ? 11u * st.ac : 0u));
-                    const uint32_t fb = lo ? 4u : ((st.fl & 4u) | (a_abs ? 0u : 2u));
-                    hc = hi ? (first ? st.hc : hb) : hc;
-                    fl = hi ? (first ? st.fl : fb) : fl;
-                    st.ac = second ? b5 : st.ac;
+                    a_abs = second ? 1u : a_abs;
+                    a_last = second ? b5 : a_last;
                     pend = first ? 1u : 0u;
                     any_pend = lanes_where(pend != 0u) != 0;
                 }
-                st.hc = hc & 63u; st.fl = fl;
                 npix += cnt;
                 const uint32_t npos = pos + adv;
                 uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
@@ -1814,12 +1862,22 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                 pos = npos; w32 = nw32; b5 = nb5; tpl = ntpl; info = ninfo;
                 active = active && pos < end;
             }
+#ifdef QOIMI_TR_ABL_NOSTORE
+            if (live) { if ((rr[0] ^ rr[1] ^ rr[2] ^ rr[3]) == 0x12345678u) dst[(size_t)ngran * 64u] = u32x4{rr[0], rr[1], rr[2], rr[3]}; ++ngran; }
+#else
             if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; dst[(size_t)ngran * 64u] = v; ++ngran; }
+#endif
         }
+    };
+    while (lanes_where(active)) {                                 // a period = one granule of four steps; three periods per turn of the register sets
+        R.turn<0>(pos); granule_steps();
+        R.turn<1>(pos); granule_steps();
+        R.turn<2>(pos); granule_steps();
     }
     if (have && !failed) {
         p.rec_gran[q] = ngran;
-        SlotRec r; slotf_finish(st, r); p.slot_rec[q] = r;
+        SlotRec r; r.hc = 0; r.h_rel = 0; r.h_alpha = 0; r.a_abs = (uint8_t)a_abs; r.ac = (uint8_t)a_last;      // dec_slot_tails completes it
+        p.slot_rec[q] = r;
         if (MODE == 0) {
             // parse record for S1: the same whatever entry phase S1 asks for - it only ever asks for the true one
             const uint32_t nominal = base + p.seg_bytes;
@@ -1855,6 +1913,33 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o); v = t > v ? t : v; }
     return __builtin_amdgcn_readfirstlane(v);
+}
+
+// P2 on records: the slot/alpha transfer of every segment from the TAIL of its records (tail_step, qoi_decode_core.h).
+// One wavefront per 64 segments reads their granule rows from the last one backwards until every lane has met a chunk that
+// names a slot absolutely - two or three rows in natural images.
+__global__ __launch_bounds__(64) void dec_slot_tails(DecParams p) {
+    const uint32_t lane = lane_id();
+    const uint32_t q = blockIdx.x * 64u + lane;
+    bool have = q < p.total_segs;
+    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
+    const DecImage im = p.images[img];
+    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
+    have = have && j >= im.start_seg && j < im.n_active;
+    if (!lanes_where(have)) return;
+    const SlotRec in = have ? p.slot_rec[q] : SlotRec{0, 0, 0, 0, 0};
+    RecSource S; S.init(p, blockIdx.x, lane, have ? p.rec_gran[q] : 0u);
+    TailState t; tail_init(t);
+    t.found = (have && S.n_gran != 0u) ? 0u : 1u;                         // nothing to scan: the identity transfer (h_rel = 1, hc = 0)
+    const bool empty = have && S.n_gran == 0u;
+    // rows from the wavefront's last one down; a lane joins when the walk reaches ITS last row, and the walk goes on while any
+    // lane has not met its anchor
+    for (uint32_t g = wave_max_u32(S.n_gran); g-- > 0u && lanes_where(t.found == 0u) != 0;) {
+        const u32x4 v = S.granule(g);                                     // zeros for lanes that have no row g
+        if (g < S.n_gran) { tail_step(t, v.w, in.a_abs, in.ac); tail_step(t, v.z, in.a_abs, in.ac); tail_step(t, v.y, in.a_abs, in.ac); tail_step(t, v.x, in.a_abs, in.ac); }
+    }
+    if (empty) t.found = 0u;
+    if (have) p.slot_rec[q] = tail_finish(t, in.a_abs, in.ac);
 }
 
 // Source / mask codes of the symbolic table as BYTES, laid out so that a wavefront's access to 64 different rows is free
@@ -2316,8 +2401,10 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
         else hipLaunchKernelGGL(dec_summarize<true>, dim3(b64), dim3(64), 0, st, p);
         tm->mark(kT_dec_summarize, st);
     } else {
-    if (p.use_rec) hipLaunchKernelGGL(dec_transcode<1>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
-    else if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_heads_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+    if (p.use_rec) {
+        hipLaunchKernelGGL(dec_transcode<1>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
+        hipLaunchKernelGGL(dec_slot_tails, dim3(b64), dim3(64), 0, st, p);
+    } else if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_heads_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(dec_slot_walk, dim3(b256), dim3(256), 0, st, p);
     tm->mark(kT_dec_slot_walk, st);
     hipLaunchKernelGGL(dec_chain_slots_l1, dim3(p.total_grps), dim3(64), 0, st, p);

@@ -571,11 +571,47 @@ QOIMI_HD uint32_t rec_of_chunk(unsigned long long w, uint32_t out[2]) {
     }
     out[0] = r; return 1u;
 }
+// The speculative slot/alpha transfer of a segment (SlotRec, the old P2 walk) read off its RECORDS, last record first.
+// QOI_COLOR_HASH is linear mod 64, so the slot the segment leaves is "what the last chunk that names a slot absolutely
+// left + the hash shifts of the relative chunks behind it": scanning backwards, shifts add up until an INDEX, an RGB or
+// the alpha half of an RGBA is met - a handful of records in natural images (every fifth chunk is an INDEX), all of them
+// only where a segment holds no such chunk.  The forward walk cost the transcoder eleven instructions per chunk.
+//   a_abs / ac   whether a QOI_OP_RGBA occurred in the segment and the alpha of the last one (kept by the transcoder: those
+//                chunks take its rare path anyway)
+struct TailState { uint32_t sum, hc, h_alpha, found, want_stash, alpha; };
+QOIMI_HD void tail_init(TailState& t) { t.sum = 0; t.hc = 0; t.h_alpha = 0; t.found = 0; t.want_stash = 0; t.alpha = 0; }
+QOIMI_HD void tail_step(TailState& t, uint32_t rec, uint32_t a_abs, uint32_t ac) {
+    if (t.found) return;
+    const uint32_t cls = rec_class(rec), pay = rec & 0x00FFFFFFu;
+    if (t.want_stash) {                                  // the stash half in front of the alpha half just seen: QOI_OP_RGBA names slot and alpha
+        t.hc = lin_hash(pay) + 11u * t.alpha + t.sum; t.h_alpha = 0; t.found = 1;
+    } else if (cls == 0u) {
+        t.sum += lin_hash(pay);
+    } else if (cls == 1u) {                              // INDEX k: taken to leave slot k (qoi_decode_core.h "P2")
+        t.hc = (rec & 63u) + t.sum; t.h_alpha = 0; t.found = 1;
+    } else if (cls == 2u) {                              // RGB (a stash half is only ever met through want_stash): alpha as the segment's RGBAs left it
+        t.hc = lin_hash(pay) + t.sum + (a_abs ? 11u * ac : 0u); t.h_alpha = a_abs ? 0u : 1u; t.found = 1;
+    } else {
+        t.want_stash = 1; t.alpha = rec & 0xFFu;
+    }
+}
+QOIMI_HD SlotRec tail_finish(const TailState& t, uint32_t a_abs, uint32_t ac) {
+    SlotRec r;
+    r.hc = (uint8_t)((t.found ? t.hc : t.sum) & 63u); r.h_rel = (uint8_t)(t.found ? 0u : 1u); r.h_alpha = (uint8_t)t.h_alpha;
+    r.a_abs = (uint8_t)(a_abs ? 1u : 0u); r.ac = (uint8_t)ac;
+    return r;
+}
+QOIMI_HD SlotRec slot_rec_from_records(const uint32_t* recs, uint32_t n_gran, uint32_t a_abs, uint32_t ac) {
+    TailState t; tail_init(t);
+    for (uint32_t i = 4u * n_gran; i-- > 0u && !t.found;) tail_step(t, recs[i], a_abs, ac);
+    return tail_finish(t, a_abs, ac);
+}
+
 // transcoder of one segment (host rehearsal; the kernel inlines the same walk around its LDS reader): every chunk
 // that starts in [pos, seg_end) -> records, padded with null records to a multiple of 4.  Returns the granule count.
 // Also leaves the speculative slot transfer of the segment (the old P2 walk, same function as slot_walk_segment_fast).
 template <class Lut>
-QOIMI_HD uint32_t transcode_segment(const uint8_t* in, uint32_t pos, uint32_t seg_end, const Lut& lut, uint32_t* recs, SlotRec& sr) {
+QOIMI_HD uint32_t transcode_segment(const uint8_t* in, uint32_t pos, uint32_t seg_end, const Lut& lut, uint32_t* recs, SlotRec& sr, long long* mismatch = nullptr) {
     PtrReader R{in};
     SlotFast s; slotf_init(s);
     uint32_t n = 0;
@@ -589,7 +625,9 @@ QOIMI_HD uint32_t transcode_segment(const uint8_t* in, uint32_t pos, uint32_t se
         pos += len_of(w32 & 0xFFu);
     }
     while (n & 3u) recs[n++] = 0u;
-    slotf_finish(s, sr);
+    SlotRec fwd; slotf_finish(s, fwd);                          // forward walk (round 1's P2): kept here as the cross-check
+    sr = slot_rec_from_records(recs, n >> 2, fwd.a_abs, fwd.ac);   // what the kernels do: the tail of the records
+    if (mismatch && (sr.hc != fwd.hc || sr.h_rel != fwd.h_rel || sr.h_alpha != fwd.h_alpha || sr.a_abs != fwd.a_abs || (fwd.a_abs && sr.ac != fwd.ac))) ++*mismatch;
     return n >> 2;
 }
 // P3 on records: same function of the chunks as symf_step.  stash: r,g,b of a pending QOI_OP_RGBA.

@@ -792,7 +792,7 @@ __global__ __launch_bounds__(64 * WAVES) void lds_order_selftest(uint32_t* out) 
     const uint32_t lane = lane_id();
     uint32_t bad = 0;
     uint32_t rng = 0x9E3779B9u * (blockIdx.x * WAVES + (threadIdx.x >> 6) + 1u) + lane * 0x85EBCA6Bu;
-    for (int it = 0; it < 256; ++it) {
+    for (int it = 0; it < (WAVES == 1 ? 256 : 48); ++it) {
         rng = rng * 1664525u + 1013904223u;
         const uint32_t nb = 1u << ((it % 7));                          // 1..64 distinct slots
         const uint32_t slot = ((rng >> 16) % nb) * (64u / nb);
@@ -881,8 +881,8 @@ void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phas
 // asynchronous form: zeroes *d_out and launches both variants on st; *d_out != 0 afterwards = the order does not hold
 void launch_lds_order_selftest(uint32_t* d_out, hipStream_t st) {
     (void)hipMemsetAsync(d_out, 0, sizeof(uint32_t), st);
-    hipLaunchKernelGGL(lds_order_selftest<1>, dim3(256), dim3(64), 0, st, d_out);
-    hipLaunchKernelGGL(lds_order_selftest<4>, dim3(1024), dim3(256), 0, st, d_out);
+    hipLaunchKernelGGL(lds_order_selftest<1>, dim3(128), dim3(64), 0, st, d_out);
+    hipLaunchKernelGGL(lds_order_selftest<4>, dim3(1024), dim3(256), 0, st, d_out);     // 48 patterns per wavefront: a few hundred microseconds
 }
 
 int run_lds_order_selftest(hipStream_t st) {
@@ -890,7 +890,7 @@ int run_lds_order_selftest(hipStream_t st) {
     if (hipMalloc((void**)&d, sizeof(uint32_t)) != hipSuccess) return -1;
     (void)hipMemsetAsync(d, 0, sizeof(uint32_t), st);
     hipLaunchKernelGGL(lds_order_selftest<1>, dim3(512), dim3(64), 0, st, d);          // one wavefront per workgroup
-    hipLaunchKernelGGL(lds_order_selftest<4>, dim3(2048), dim3(256), 0, st, d);        // sixteen per CU at once
+    hipLaunchKernelGGL(lds_order_selftest<4>, dim3(2048), dim3(256), 0, st, d);        // sixteen per CU at once (48 patterns each)
     uint32_t h = 1;
     if (hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) h = 0xFFFFFFFFu;
     (void)hipFree(d);

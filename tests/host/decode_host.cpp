@@ -130,7 +130,7 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
     std::vector<uint32_t> recs(recmode ? (size_t)nseg * region : 0u), rec_gran(nseg, 0u);
     if (nseg) entry[64] = 0xFF000000u;
     uint32_t start = 0, final_px = 0xFF000000u;
-    long long rounds = 0, redo = 0;
+    long long rounds = 0, redo = 0, tail_mismatch = 0;
     while (start < n_active) {
         ++rounds;
         const bool refine = fast && rounds > 1;       // later rounds: entry states of the previous round serve as hints
@@ -145,7 +145,7 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
         if (!refine)
         for (uint32_t j = start; j < n_active; ++j) {
             const uint32_t base = 14u + j * B, end = base + B < chunks_end ? base + B : chunks_end;
-            if (recmode) rec_gran[j] = transcode_segment(in, base + phase[j], end, lut, &recs[(size_t)j * region], srec[j]);
+            if (recmode) rec_gran[j] = transcode_segment(in, base + phase[j], end, lut, &recs[(size_t)j * region], srec[j], &tail_mismatch);
             else if (fast) slot_walk_segment_fast(in, base + phase[j], end, lut, srec[j]); else slot_walk_segment(in, base + phase[j], end, srec[j]);
         }
         if (!refine)
@@ -247,6 +247,6 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
         if (och == 4) reinterpret_cast<uint32_t*>(out)[i] = fpx;
         else { out[(size_t)i * 3] = (uint8_t)fpx; out[(size_t)i * 3 + 1] = (uint8_t)(fpx >> 8); out[(size_t)i * 3 + 2] = (uint8_t)(fpx >> 16); }
     }
-    if (stats) { stats[0] = rounds; stats[1] = redo; stats[2] = nseg; }
+    if (stats) { stats[0] = rounds; stats[1] = redo; stats[2] = nseg; stats[3] = tail_mismatch; }
     return 0;
 }

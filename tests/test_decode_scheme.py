@@ -56,6 +56,7 @@ def test_scheme_matches_golden(host_lib, golden, encoded_streams):
             for fast in (False, True, "rec"):     # readable primitives, the lean LUT-driven ones, the record pipeline of the kernels
                 got, stats = run(host_lib, c["stream"], och, B, grp, fast)
                 assert np.array_equal(got, want), (c["name"], B, grp, fast, stats)
+                assert stats[3] == 0, ("slot transfer from the record tail differs from the forward walk", c["name"], B)
         n += 1
     assert n > 100
 
