@@ -1954,11 +1954,28 @@ __device__ __forceinline__ uint32_t symcode_addr(uint32_t lane_base, uint32_t ro
 
 // P3 on records.  One wavefront per 64 segments; 20 KiB of LDS (24 in the refinement rounds): eight per CU.
 // Same step as dec_summarize / symr_step (qoi_decode_core.h).
+#ifdef QOIMI_P3_ABL_HOT
+#define P3ROW(g) ((g) & 3u)      // timing experiment: every fetch hits the same four rows (results are wrong)
+#else
+#define P3ROW(g) (g)
+#endif
+// (a & m) | b as ONE instruction whatever else the compiler could share the parts with
+__device__ __forceinline__ uint32_t and_or_b32(uint32_t a, uint32_t m, uint32_t b) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(b));
+    return r;
+}
+// code byte of the plain form (dec_summarize_rec): source 0..64, bit 7 = r,g,b absolute -> the general form's code
+__device__ __forceinline__ uint32_t plain_code_general(uint32_t c) { return (c & 0x80u) ? (c & 0x7Fu) + kSymCodeRgb : c; }
 template <bool REFINE>
 __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     __shared__ __attribute__((aligned(16384))) uint32_t s_tabc[64 * 64];
     __shared__ __attribute__((aligned(4096))) uint8_t s_tabm[64 * 64];
     __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 4];
+#ifdef QOIMI_P3_PAD_KB
+    __shared__ uint32_t s_pad[QOIMI_P3_PAD_KB * 256];      // occupancy experiment
+    if (p.total_segs == 0xFFFFFFFFu) s_pad[threadIdx.x] = 0u;
+#endif
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     const uint32_t lane = lane_id();
     const uint32_t q = blockIdx.x * 64u + lane;
@@ -1969,13 +1986,35 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     have = have && j >= im.start_seg && j < im.n_active;
     if (!lanes_where(have)) return;
     RecSource S; S.init(p, blockIdx.x, lane, have ? p.rec_gran[q] : 0u);
+#ifdef QOIMI_P3_ABL_NOLOOP
+    const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1) >> 8;
+#else
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);            // blocks of two granules = eight steps
-    u32x4 n0 = S.granule(0u), n1 = S.granule(1u);
+#endif
+    // Records are fetched kDepth blocks ahead.  A wavefront has 20 KiB of LDS, so eight of them share a CU and the record
+    // stream (4 B per chunk, 2.7 x the QOI bytes of a photograph) has to be kept in flight by the few wavefronts there are:
+    // one block ahead = 2 KiB per wavefront = 4 MiB over the chip, which at ~2 us of loaded HBM latency is 2 TB/s - the plain
+    // form (900 cycles of work per block) would wait on every block.
+#ifndef QOIMI_P3_DEPTH
+#define QOIMI_P3_DEPTH 4
+#endif
+    constexpr uint32_t kDepth = QOIMI_P3_DEPTH;
+    u32x4 ring[2u * kDepth];
+#pragma unroll
+    for (uint32_t i = 0; i < 2u * kDepth; ++i) ring[i] = S.granule(i);
     const uint32_t tc_base = lds_addr_of(&s_tabc[lane]);                 // slot k at + k*256
     const uint32_t tm_lane = lds_addr_of(&s_tabm[0]) + (lane & 31u) * 4u + (lane >> 5);
+    // PLAIN form, for as long as no lane of the wavefront has met a QOI_OP_RGBA record (opaque images: the whole segment): the
+    // alpha of every value still is its source's, so a symbolic value is "entry word s + (dr,dg,db)" or "r,g,b with the alpha
+    // of entry word s" and fits ONE dword - the code (s, or 128 + s) in the top byte, constants below.  The table is then a single LDS array, a step reads one word,
+    // writes one word and tracks neither a code nor an alpha: 14 vector instructions instead of 39.  The first such record
+    // converts table and pixel to the general form (constants + source/mask code, below) once, in place.
     // identity: slot k = entry slot k + 0, pixel = entry pixel + 0 (sym_init)
-    for (uint32_t k = 0; k < 64u; ++k) { *(lds_u32*)(tc_base + k * 256u) = 0u; *(lds_u8*)symcode_addr(tm_lane, k) = (uint8_t)k; }
-    uint32_t pc = 0u, ph = 64u;                                           // ph: code of the running pixel (entry pixel, nothing absolute)
+    bool plain = p.p3_plain != 0u;                                        // wave-uniform
+    if (plain) { for (uint32_t k = 0; k < 64u; ++k) *(lds_u32*)(tc_base + k * 256u) = k << 24; }
+    else { for (uint32_t k = 0; k < 64u; ++k) { *(lds_u32*)(tc_base + k * 256u) = 0u; *(lds_u8*)symcode_addr(tm_lane, k) = (uint8_t)k; } }
+    uint32_t ppc = 64u << 24;                                             // plain running pixel: entry pixel + 0
+    uint32_t pc = 0u, ph = 64u;                                           // general form: constants, code of the running pixel
     uint32_t slot, alpha, stash = 0u;
     if (REFINE) {
         const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
@@ -1999,64 +2038,167 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     // RUN chunks (and null records) store nothing new except as a stream's first chunk (SymState); the refinement rounds
     // skip the store by writing back the word they read (see dec_summarize)
     const bool skip_runs = REFINE && j != 0u;
-    for (uint32_t blk = 0; blk < nblk; ++blk) {
-        const u32x4 c0 = n0, c1 = n1;
-        n0 = S.granule(2u * blk + 2u); n1 = S.granule(2u * blk + 3u);
-        const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    // read-ahead state of the plain form: address and word of the next step's table read, address and word of the last table write
+    uint32_t ra_cur = and_or_b32(ring[0].x, 0x3F00u, tc_base), t_cur = 0u, wa_prev = ~0u, wv_prev = 0u;
+    if (plain) t_cur = *(const lds_u32*)ra_cur;
+#ifdef QOIMI_P3_ABL_NOLDSW
+    uint32_t abl_acc = 0u;
+#endif
+    // One loop over the blocks, unrolled kDepth times (the ring is indexed statically: registers); a block of eight steps is
+    // taken in the plain form or in the general one.  A block that holds a half of a QOI_OP_RGBA in any lane (class 3, or class 2
+    // with the stash marker: exactly the records >= 0xBF000000) ends the plain form: the table is converted in front of it.
+    // (no early exit from the unrolled blocks: the wavefront walks null records up to a multiple of kDepth blocks - with an exit
+    // in the middle the compiler rotates the ring through register copies, and every copy waits for the load just issued)
+    for (uint32_t blk0 = 0; blk0 < nblk; blk0 += kDepth) {
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; ++u) {
-            const uint32_t rec = rc[u];
-            const uint32_t idx = rec & 63u;
-            const uint32_t tm_rd = symcode_addr(tm_lane, idx);
-            const uint32_t t_c = *(const lds_u32*)(tc_base + (idx << 8));
-            const uint32_t t_m = *(const lds_u8*)tm_rd;
-            uint32_t pc_rel = pc;
-            add_byte0(pc_rel, rec); add_byte1(pc_rel, rec); add_byte2(pc_rel, rec);
-            const bool hi = (int32_t)rec < 0, lo = (int32_t)(rec << 1) < 0;
-            const uint32_t s_rel = slot + __builtin_amdgcn_udot4(rec, 0x00070503u, 0u, false);
-            // alpha an INDEX chunk leaves: the named entry's (hinted where it is still symbolic)
-            const uint32_t th = REFINE ? (uint32_t)s_hint[(t_m < kSymCodeRgb ? t_m : (t_m - kSymCodeRgb) & 0x7Fu) * 64u + lane] : alpha_in0;
-            const uint32_t ta = t_m == kSymCodeAbs ? (t_c >> 24) : th;
-            // two complete bodies: the common one knows nothing of QOI_OP_RGB / QOI_OP_RGBA (no selects on `hi`, no write-back)
-            if (__builtin_expect(lanes_where(hi) != 0, 0)) {
-                const uint32_t rgb = rec & 0x00FFFFFFu;
-                const bool is_stash = hi && !lo && ((rec >> 24) & 63u) == kRecStash;
-                const uint32_t a_new = rec & 0xFFu;
-                const uint32_t pc_rgb = (pc & 0xFF000000u) | rgb, pc_abs = stash | (rec << 24);
-                const uint32_t l_rgb = __builtin_amdgcn_udot4(rgb, 0x00070503u, 0u, false), l_st = __builtin_amdgcn_udot4(stash, 0x00070503u, 0u, false);
-                const uint32_t sb = lo ? l_st + 11u * a_new : l_rgb + 11u * alpha;
-                const uint32_t pb = lo ? pc_abs : pc_rgb;
-                const uint32_t hb = lo ? kSymCodeAbs : (ph < kSymCodeRgb ? ph + kSymCodeRgb : ph);
-                const uint32_t ab = lo ? a_new : alpha;
-                const uint32_t pa = lo ? t_c : pc_rel, ha = lo ? t_m : ph, sa = lo ? idx : s_rel, aa = lo ? ta : alpha;
-                const bool keep = is_stash || (skip_runs && (rec & 0xC0FFFFFFu) == 0u);   // the table stays as it is: the word read goes back
-                if (!is_stash) {
-                    pc = hi ? pb : pa; ph = hi ? hb : ha; slot = (hi ? sb : sa) & 63u; alpha = hi ? ab : aa;
-                } else {
-                    stash = rgb;
+      for (uint32_t d = 0; d < kDepth; ++d) {
+        const uint32_t blk = blk0 + d;
+        const u32x4 c0 = ring[2u * d], c1 = ring[2u * d + 1u];
+        const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        if (plain) {
+            const uint32_t top = max(max(max(rc[0], rc[1]), max(rc[2], rc[3])), max(max(rc[4], rc[5]), max(rc[6], rc[7])));
+            if (__builtin_expect(lanes_where(top >= 0xBF000000u) != 0, 0)) {
+                // ---- plain -> general: split every table word into constants and code, the pixel likewise ----
+                for (uint32_t k = 0; k < 64u; ++k) {
+                    const uint32_t w = *(const lds_u32*)(tc_base + k * 256u);
+                    *(lds_u32*)(tc_base + k * 256u) = w & 0x00FFFFFFu;
+                    *(lds_u8*)symcode_addr(tm_lane, k) = (uint8_t)plain_code_general(w >> 24);
                 }
-                const uint32_t wslot = keep ? idx : slot, wc = keep ? t_c : pc, wm = keep ? t_m : ph;
-                *(lds_u32*)(tc_base + (wslot << 8)) = wc;          // index update after every chunk (qoi.h:577)
-                *(lds_u8*)symcode_addr(tm_lane, wslot) = (uint8_t)wm;
-            } else {
-                pc = lo ? t_c : pc_rel; ph = lo ? t_m : ph; slot = (lo ? idx : s_rel) & 63u; alpha = lo ? ta : alpha;
-                if (REFINE) {
-                    const bool keep = skip_runs && (rec & 0xC0FFFFFFu) == 0u;
-                    const uint32_t wslot = keep ? idx : slot, wc = keep ? t_c : pc, wm = keep ? t_m : ph;
-                    *(lds_u32*)(tc_base + (wslot << 8)) = wc;
-                    *(lds_u8*)symcode_addr(tm_lane, wslot) = (uint8_t)wm;
-                } else {
-                    *(lds_u32*)(tc_base + (slot << 8)) = pc;       // index update after every chunk (qoi.h:577)
-                    *(lds_u8*)symcode_addr(tm_lane, slot) = (uint8_t)ph;
-                }
+                pc = ppc & 0x00FFFFFFu; ph = plain_code_general(ppc >> 24);
+                slot &= 63u;
+                // the alpha of the running pixel is its source's: the hinted one in a refinement round, else the entry alpha
+                alpha = REFINE ? (uint32_t)s_hint[((ppc >> 24) & 0x7Fu) * 64u + lane] : alpha_in0;
+                plain = false;
             }
         }
+        if (plain) {
+            // Two wavefronts per SIMD (the tables fill the LDS) issue one vector instruction every ~10 cycles each, whatever the
+            // instruction, as long as the next one does not depend on it (tools/ubench/valu_tput.hip: 6.9 ticks of 1.5 cycles): a
+            // step costs its VECTOR instruction count, scalar instructions ride along.  So
+            //  * there is no branch inside a block of eight steps (a branch holds a wavefront for ~40 cycles even when it is not
+            //    taken): the block is either free of QOI_OP_RGB in every lane or takes the body that handles it with selects;
+            //  * the table word an INDEX names is read ONE STEP AHEAD of its use - before the previous step's table write, which
+            //    is forwarded from registers when the addresses match - so the LDS round trip is not part of a step's chain.
+            const u32x4 nx = ring[2u * ((d + 1u) % kDepth)];                // first record of the next block (null past the end)
+            const uint32_t rx[9] = {rc[0], rc[1], rc[2], rc[3], rc[4], rc[5], rc[6], rc[7], nx.x};
+            // whether the block has a QOI_OP_RGB in some lane: the sign bit of the OR of its records
+            const uint32_t any = rc[0] | rc[1] | rc[2] | rc[3] | rc[4] | rc[5] | rc[6] | rc[7];
+            auto plain_block = [&](auto rgb_tag) {
+                constexpr bool RGB = decltype(rgb_tag)::value;
+#pragma unroll
+                for (uint32_t u = 0; u < 8u; ++u) {
+                    const uint32_t rec = rx[u];
+                    const uint32_t ra_next = and_or_b32(rx[u + 1u], 0x3F00u, tc_base);      // INDEX records carry the slot in bits 8..13 too
+#ifdef QOIMI_P3_ABL_NOLDSR
+                    const uint32_t t_next = ra_next * 0x9E3779B1u;
+#else
+                    const uint32_t t_next = *(const lds_u32*)ra_next;                  // read one step ahead, i.e. before this step's write
+#endif
+                    const uint32_t t = ra_cur == wa_prev ? wv_prev : t_cur;            // ... so the previous step's write is forwarded here
+                    const bool isabs = rec >= 0x40000000u;                            // INDEX (or RGB: the sign bit)
+                    add_byte0(ppc, rec); add_byte1(ppc, rec); add_byte2(ppc, rec);
+                    const uint32_t s_rel = __builtin_amdgcn_udot4(rec, 0x00070503u, slot, false);
+                    const uint32_t code = ppc;                                        // the code byte is not touched by the byte adds
+                    ppc = isabs ? t : ppc;
+                    slot = isabs ? rec : s_rel;                                       // modulo 64: masked where it addresses the table
+                    if (RGB) {
+                        // QOI_OP_RGB keeps the plain form: r,g,b become absolute (bit 7 of the code), the alpha stays the source's
+                        const bool hi = (int32_t)rec < 0;
+                        const uint32_t rgbc = (rec & 0x00FFFFFFu) | 0x80000000u;
+                        const uint32_t a_src = REFINE ? (uint32_t)s_hint[((code >> 24) & 0x7Fu) * 64u + lane] : alpha_in0;
+                        ppc = hi ? ((code & 0x7F000000u) | rgbc) : ppc;
+                        slot = hi ? __builtin_amdgcn_udot4(rgbc, 0x00070503u, 11u * a_src, false) : slot;
+                    }
+                    uint32_t waddr = and_or_b32(slot << 8, 0x3F00u, tc_base), wval = ppc;    // index update after every chunk (qoi.h:577)
+                    if (REFINE) {
+                        const bool keep = skip_runs && (rec & 0xC0FFFFFFu) == 0u;       // a RUN / null record read slot 0 (payload 0): it goes back
+                        waddr = keep ? tc_base : waddr; wval = keep ? t : ppc;
+                    }
+#ifdef QOIMI_P3_ABL_NOLDSW
+                    abl_acc ^= waddr + wval;
+#else
+                    *(lds_u32*)waddr = wval;
+#endif
+                    wa_prev = waddr; wv_prev = wval; ra_cur = ra_next; t_cur = t_next;
+                }
+            };
+            if (lanes_where((int32_t)any < 0) == 0) plain_block(std::false_type{}); else plain_block(std::true_type{});
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                const uint32_t rec = rc[u];
+                const uint32_t idx = rec & 63u;
+                const uint32_t tm_rd = symcode_addr(tm_lane, idx);
+                const uint32_t t_c = *(const lds_u32*)(tc_base + (idx << 8));
+                const uint32_t t_m = *(const lds_u8*)tm_rd;
+                uint32_t pc_rel = pc;
+                add_byte0(pc_rel, rec); add_byte1(pc_rel, rec); add_byte2(pc_rel, rec);
+                const bool hi = (int32_t)rec < 0, lo = (int32_t)(rec << 1) < 0;
+                const uint32_t s_rel = slot + __builtin_amdgcn_udot4(rec, 0x00070503u, 0u, false);
+                // alpha an INDEX chunk leaves: the named entry's (hinted where it is still symbolic)
+                const uint32_t th = REFINE ? (uint32_t)s_hint[(t_m < kSymCodeRgb ? t_m : (t_m - kSymCodeRgb) & 0x7Fu) * 64u + lane] : alpha_in0;
+                const uint32_t ta = t_m == kSymCodeAbs ? (t_c >> 24) : th;
+                // two complete bodies: the common one knows nothing of QOI_OP_RGB / QOI_OP_RGBA (no selects on `hi`, no write-back)
+                if (__builtin_expect(lanes_where(hi) != 0, 0)) {
+                    const uint32_t rgb = rec & 0x00FFFFFFu;
+                    const bool is_stash = hi && !lo && ((rec >> 24) & 63u) == kRecStash;
+                    const uint32_t a_new = rec & 0xFFu;
+                    const uint32_t pc_rgb = (pc & 0xFF000000u) | rgb, pc_abs = stash | (rec << 24);
+                    const uint32_t l_rgb = __builtin_amdgcn_udot4(rgb, 0x00070503u, 0u, false), l_st = __builtin_amdgcn_udot4(stash, 0x00070503u, 0u, false);
+                    const uint32_t sb = lo ? l_st + 11u * a_new : l_rgb + 11u * alpha;
+                    const uint32_t pb = lo ? pc_abs : pc_rgb;
+                    const uint32_t hb = lo ? kSymCodeAbs : (ph < kSymCodeRgb ? ph + kSymCodeRgb : ph);
+                    const uint32_t ab = lo ? a_new : alpha;
+                    const uint32_t pa = lo ? t_c : pc_rel, ha = lo ? t_m : ph, sa = lo ? idx : s_rel, aa = lo ? ta : alpha;
+                    const bool keep = is_stash || (skip_runs && (rec & 0xC0FFFFFFu) == 0u);   // the table stays as it is: the word read goes back
+                    if (!is_stash) {
+                        pc = hi ? pb : pa; ph = hi ? hb : ha; slot = (hi ? sb : sa) & 63u; alpha = hi ? ab : aa;
+                    } else {
+                        stash = rgb;
+                    }
+                    const uint32_t wslot = keep ? idx : slot, wc = keep ? t_c : pc, wm = keep ? t_m : ph;
+                    *(lds_u32*)(tc_base + (wslot << 8)) = wc;          // index update after every chunk (qoi.h:577)
+                    *(lds_u8*)symcode_addr(tm_lane, wslot) = (uint8_t)wm;
+                } else {
+                    pc = lo ? t_c : pc_rel; ph = lo ? t_m : ph; slot = (lo ? idx : s_rel) & 63u; alpha = lo ? ta : alpha;
+                    if (REFINE) {
+                        const bool keep = skip_runs && (rec & 0xC0FFFFFFu) == 0u;
+                        const uint32_t wslot = keep ? idx : slot, wc = keep ? t_c : pc, wm = keep ? t_m : ph;
+                        *(lds_u32*)(tc_base + (wslot << 8)) = wc;
+                        *(lds_u8*)symcode_addr(tm_lane, wslot) = (uint8_t)wm;
+                    } else {
+                        *(lds_u32*)(tc_base + (slot << 8)) = pc;       // index update after every chunk (qoi.h:577)
+                        *(lds_u8*)symcode_addr(tm_lane, slot) = (uint8_t)ph;
+                    }
+                }
+
+            }
+        }
+        // the ring slot is refilled when the block is through with it: the load goes straight into the registers the block
+        // after next ... reads (a refill at the top of the block lands in shadow registers and the copies wait for it)
+        ring[2u * d] = S.granule(P3ROW(2u * (blk + kDepth))); ring[2u * d + 1u] = S.granule(P3ROW(2u * (blk + kDepth) + 1u));
+      }
     }
+#ifdef QOIMI_P3_ABL_NOLDSW
+    if (abl_acc == 0x1234567u) p.summary[0] = abl_acc;
+#endif
+#ifdef QOIMI_P3_ABL_NOOUT
+    if (have && slot == 0x12345u) {
+#else
     if (have) {
+#endif
         sym_t* dst = p.summary + (size_t)q * 65u;
-        for (uint32_t k = 0; k < 64u; ++k)
-            dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)sym_code_expand(*(const lds_u8*)symcode_addr(tm_lane, k)) << 32);
-        dst[64] = (sym_t)pc | ((sym_t)sym_code_expand(ph) << 32);
+        if (plain) {                                                          // never left the plain form: code and constants share the word
+            for (uint32_t k = 0; k < 64u; ++k) {
+                const uint32_t w = *(const lds_u32*)(tc_base + k * 256u);
+                dst[k] = (sym_t)(w & 0x00FFFFFFu) | ((sym_t)sym_code_expand(plain_code_general(w >> 24)) << 32);
+            }
+            dst[64] = (sym_t)(ppc & 0x00FFFFFFu) | ((sym_t)sym_code_expand(plain_code_general(ppc >> 24)) << 32);
+        } else {
+            for (uint32_t k = 0; k < 64u; ++k)
+                dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)sym_code_expand(*(const lds_u8*)symcode_addr(tm_lane, k)) << 32);
+            dst[64] = (sym_t)pc | ((sym_t)sym_code_expand(ph) << 32);
+        }
     }
 }
 
@@ -2175,7 +2317,13 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     const uint32_t px_first = have ? p.px_off[q] : 0u;
     RecSource S; S.init(p, blockIdx.x, lane, have && px_first < limit ? p.rec_gran[q] : 0u);
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);
-    u32x4 n0 = S.granule(0u), n1 = S.granule(1u);
+#ifndef QOIMI_P4_DEPTH
+#define QOIMI_P4_DEPTH 3
+#endif
+    constexpr uint32_t kDepth = QOIMI_P4_DEPTH;                  // blocks of records in flight (see dec_summarize_rec)
+    u32x4 ring[2u * kDepth];
+#pragma unroll
+    for (uint32_t i = 0; i < 2u * kDepth; ++i) ring[i] = S.granule(i);
     Writer W;
     {   // descriptor base: the image of the wavefront's first segment (its lanes' images follow it in memory)
         const uint32_t q0 = blockIdx.x * 64u;
@@ -2202,24 +2350,28 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     const bool clip_lane = have && (j + 1u >= im.n_active || p.px_off[q + 1u] >= limit);
     auto run = [&](auto clip_tag) {
         constexpr bool CLIP = decltype(clip_tag)::value;
-        for (uint32_t blk = 0; blk < nblk; ++blk) {
-            const u32x4 c0 = n0, c1 = n1;                       // the loads issued a block (eight steps) ago
-            n0 = S.granule(2u * blk + 2u); n1 = S.granule(2u * blk + 3u);
-            W.drain_block();                                    // a static number of stores right behind the loads (BurstWriter)
+        // (no early exit from the unrolled blocks and the ring slot refilled at the END of its block: see dec_summarize_rec)
+        for (uint32_t blk0 = 0; blk0 < nblk; blk0 += kDepth) {
+#pragma unroll
+          for (uint32_t d = 0; d < kDepth; ++d) {
+            const uint32_t blk = blk0 + d;
+            const u32x4 c0 = ring[2u * d], c1 = ring[2u * d + 1u];      // the loads issued kDepth - 1 blocks (of eight steps) ago
+            W.drain_block();                                    // a static number of stores (BurstWriter)
             const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
             for (uint32_t u = 0; u < 8u; ++u) {
                 if (kDrainEvery < 8u && u == 4u) W.drain_block();
                 const uint32_t rec = rc[u];
-                const uint32_t idx8 = (rec & 63u) << 8;
-                const uint32_t t = *(const lds_u32*)(tab_base + idx8);           // slot an INDEX names
-                uint32_t rel = px;
-                add_byte0(rel, rec); add_byte1(rel, rec); add_byte2(rel, rec);
-                const bool hi = (int32_t)rec < 0, lo = (int32_t)(rec << 1) < 0;
                 uint32_t rem = (rec >> 24) & 63u;                                 // 0: null record
-                const uint32_t a = lo ? t : rel;
-                // two complete bodies: the common one knows nothing of QOI_OP_RGB / QOI_OP_RGBA
-                if (__builtin_expect(lanes_where(hi) != 0, 0)) {   // QOI_OP_RGB keeps the alpha; QOI_OP_RGBA = stash record + alpha record (qoi.h:548-557)
+                // two complete bodies (see dec_summarize_rec: a step costs its instruction count): the common one knows nothing of
+                // QOI_OP_RGB / QOI_OP_RGBA
+                if (__builtin_expect(lanes_where((int32_t)rec < 0) != 0, 0)) {   // QOI_OP_RGB keeps the alpha; QOI_OP_RGBA = stash record + alpha record (qoi.h:548-557)
+                    const uint32_t idx8 = rec & 0x3F00u;
+                    const uint32_t t = *(const lds_u32*)(tab_base + idx8);
+                    uint32_t rel = px;
+                    add_byte0(rel, rec); add_byte1(rel, rec); add_byte2(rel, rec);
+                    const bool hi = (int32_t)rec < 0, lo = (int32_t)(rec << 1) < 0;
+                    const uint32_t a = lo ? t : rel;
                     const uint32_t rgb = rec & 0x00FFFFFFu;
                     const bool is_stash = hi && !lo && rem == kRecStash;
                     const uint32_t b = lo ? (stash | (rec << 24)) : ((px & 0xFF000000u) | rgb);
@@ -2233,11 +2385,19 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                     const uint32_t waddr = is_stash ? idx8 : ((h & 63u) << 8), wval = is_stash ? t : px;
                     *(lds_u32*)(tab_base + waddr) = wval;
                 } else {
-                    uint32_t npxl = a;
-                    if (CLIP) npxl = W.ppos < limit ? npxl : px;
-                    px = npxl;
+                    const uint32_t t = *(const lds_u32*)((rec & 0x3F00u) | tab_base);   // slot an INDEX names: bits 8..13 of its record
+                    const bool lo = rec >= 0x40000000u;                      // INDEX (no lane has bit 31 here)
+                    if (CLIP) {
+                        uint32_t rel = px;
+                        add_byte0(rel, rec); add_byte1(rel, rec); add_byte2(rel, rec);
+                        const uint32_t npxl = lo ? t : rel;
+                        px = W.ppos < limit ? npxl : px;
+                    } else {
+                        add_byte0(px, rec); add_byte1(px, rec); add_byte2(px, rec);
+                        px = lo ? t : px;
+                    }
                     const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
-                    *(lds_u32*)(tab_base + ((h & 63u) << 8)) = px;       // qoi.h:577
+                    *(lds_u32*)(((h << 8) & 0x3F00u) | tab_base) = px;       // qoi.h:577
                 }
                 if (CLIP) rem = min(rem, limit - W.ppos);                 // over-long run clipped (Appendix B item 8)
                 const uint32_t n2 = min(rem, 2u);
@@ -2249,6 +2409,8 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                     if (W.ppos - W.fpos > Writer::kRing - 2u * kDrainEvery) W.drain();
                 }
             }
+            ring[2u * d] = S.granule(2u * (blk + kDepth)); ring[2u * d + 1u] = S.granule(2u * (blk + kDepth) + 1u);
+          }
         }
     };
     if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});

@@ -530,7 +530,7 @@ QOIMI_HD uint32_t decode_segment_fast(const uint8_t* in, uint32_t pos, uint32_t 
 //   bits  0..23  payload
 //   bits 24..29  pixels the record produces (0..62; 63 = stash marker, see class 2)
 //   bits 30..31  class: 0 relative   payload = byte-wise (dr,dg,db), LUMA's second byte folded in; RUN: 0 (qoi.h:561-575)
-//                       1 INDEX      payload byte 0 = slot                                           (qoi.h:558-560)
+//                       1 INDEX      payload byte 0 = slot = payload byte 1                          (qoi.h:558-560)
 //                       2 RGB        payload = r,g,b; alpha kept                                    (qoi.h:547-551)
 //                                    with pixels == 63: first half of QOI_OP_RGBA - r,g,b are stashed, NOTHING
 //                                    else happens (no pixel, the table is left exactly as it is)
@@ -553,7 +553,7 @@ QOIMI_HD uint32_t rec_template(uint32_t b) {
     const uint32_t top = b >> 6;
     if (b == 0xFEu) return rec_make(2u, 1u, 0u);
     if (b == 0xFFu) return rec_make(2u, kRecStash, 0u);
-    if (top == 0u) return rec_make(1u, 1u, b);
+    if (top == 0u) return rec_make(1u, 1u, b | (b << 8));        // the slot twice: bits 8..13 address the table as they stand
     if (top == 1u) return rec_make(0u, 1u, diff_delta(b));
     if (top == 2u) return rec_make(0u, 1u, luma_delta(b, 0u));
     return rec_make(0u, (b & 0x3Fu) + 1u, 0u);
@@ -661,6 +661,56 @@ QOIMI_HD sym_t summarize_records(const uint32_t* recs, uint32_t n_gran, uint32_t
     for (uint32_t i = 0; i < 4u * n_gran; ++i) symr_step(s, stash, recs[i], tab.get(recs[i] & 63u), tab, hint);
     return sym_pixel(s);
 }
+// P3 on records in the PLAIN form the kernel uses while no QOI_OP_RGBA has been met: a symbolic value is one dword, the code
+// (source 0..64, + 65 if r,g,b are absolute) in the top byte and the r,g,b constants below; the alpha is the source's.
+// Same function as symr_step on such records; returns false at the first record that needs the general form.
+constexpr uint32_t kPlainRgb = 65u;
+struct PlainState { uint32_t ppc, slot; };
+template <class Tab32, class Hint>
+QOIMI_HD bool symp_step(PlainState& s, uint32_t rec, uint32_t alpha_in0, bool refine, bool skip_runs, Tab32& tab, const Hint& hint) {
+    const uint32_t cls = rec_class(rec), idx = rec & 63u;
+    if (cls == 3u || (cls == 2u && rec_pixels(rec) == kRecStash)) return false;
+    const uint32_t t = tab.get(idx);
+    uint32_t npc, nslot;
+    if (cls == 0u) { npc = (s.ppc & 0xFF000000u) | (add_bytes(s.ppc, rec) & 0x00FFFFFFu); nslot = s.slot + lin_hash(rec & 0x00FFFFFFu); }
+    else if (cls == 1u) { npc = t; nslot = idx; }
+    else {
+        const uint32_t code = s.ppc >> 24, src = code < kPlainRgb ? code : code - kPlainRgb;
+        const uint32_t a_src = refine ? hint(src) : alpha_in0;
+        npc = ((src + kPlainRgb) << 24) | (rec & 0x00FFFFFFu);
+        nslot = lin_hash(rec & 0x00FFFFFFu) + 11u * a_src;
+    }
+    s.ppc = npc; s.slot = nslot & 63u;
+    const bool keep = skip_runs && (rec & 0xC0FFFFFFu) == 0u;
+    tab.set(keep ? idx : s.slot, keep ? t : s.ppc);
+    return true;
+}
+// summarize_records with the plain form for as long as it lasts (host rehearsal of dec_summarize_rec's two forms)
+template <class Tab, class Hint>
+QOIMI_HD sym_t summarize_records_plain(const uint32_t* recs, uint32_t n_gran, uint32_t slot, uint32_t alpha, Tab& tab, const Hint& hint, bool stream_start, bool refine) {
+    struct T32 { uint32_t v[64]; uint32_t get(uint32_t k) const { return v[k]; } void set(uint32_t k, uint32_t x) { v[k] = x; } } pt;
+    for (uint32_t k = 0; k < 64u; ++k) pt.v[k] = k << 24;
+    PlainState ps; ps.ppc = 64u << 24; ps.slot = slot;
+    const bool skip_runs = !stream_start;                       // as SymState::runmask: the refinement rounds of every segment but a stream's first
+    uint32_t i = 0;
+    for (; i < 4u * n_gran; ++i) if (!symp_step(ps, recs[i], alpha, refine, skip_runs, pt, hint)) break;
+    auto expand = [](uint32_t w) { const uint32_t code = w >> 24; return sym_make(w & 0x00FFFFFFu, code < kPlainRgb ? code : code - kPlainRgb, code < kPlainRgb ? 0u : 7u); };
+    if (i == 4u * n_gran) {
+        for (uint32_t k = 0; k < 64u; ++k) tab.set(k, expand(pt.v[k]));
+        return expand(ps.ppc);
+    }
+    // general form from here on
+    SymState st;
+    for (uint32_t k = 0; k < 64u; ++k) tab.set(k, expand(pt.v[k]));
+    const sym_t px = expand(ps.ppc);
+    st.pc = (uint32_t)px; st.ph = (uint32_t)(px >> 32); st.slot = ps.slot;
+    { const uint32_t code = ps.ppc >> 24, src = code < kPlainRgb ? code : code - kPlainRgb; st.alpha = refine ? hint(src) : alpha; }
+    st.runmask = stream_start ? 0u : kLutRunBit;
+    uint32_t stash = 0;
+    for (; i < 4u * n_gran; ++i) symr_step(st, stash, recs[i], tab.get(recs[i] & 63u), tab, hint);
+    return sym_pixel(st);
+}
+
 // P4 on records: same function of the chunks as pixelf_step / decode_segment_fast
 template <int OCH, class Tab32>
 QOIMI_HD uint32_t decode_records(const uint32_t* recs, uint32_t n_gran, uint32_t px, Tab32& tab, uint8_t* out, uint32_t px_pos, uint32_t px_limit) {

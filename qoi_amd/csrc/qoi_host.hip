@@ -387,6 +387,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.use_rec = c->dec_rec ? 1u : 0u;
     p.rec_rows = rec_region_dwords(B) / 4u;
     p.sync_all = 0;
+    p.p3_plain = getenv("QOIMI_P3_PLAIN") ? (uint32_t)atoi(getenv("QOIMI_P3_PLAIN")) : 1u;
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
     const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
     {   // P1/P2 on 128-byte pieces when a segment is 1, 8, 16, 32 or 64 of them

@@ -128,6 +128,7 @@ struct DecParams {
     uint32_t* first_bad;       // [n_images] min failing segment, 0xFFFFFFFF: none
     uint32_t* pending;         // [1] images that need another round
     uint32_t* redo_segs;       // [1] statistics
+    uint32_t p3_plain;         // 1: dec_summarize_rec starts in its one-dword plain form (QOIMI_P3_PLAIN=0 turns it off: diagnostics)
     uint32_t sync_all;         // 1: no look-back synchronisation - every segment takes the full parse (segment sizes the 128-byte piece parse does not cover)
     uint32_t* sync_fails;      // [1] segments whose look-back synchronisation failed in dec_transcode (they take the full parse)
     uint8_t*  sync_fail;       // [total_segs + 1] 1: the segment's entry position is not known yet (dec_transcode<0>)

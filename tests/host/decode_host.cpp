@@ -55,7 +55,7 @@ extern "C" int host_check_records(void) {
             if (k != (c.is_rgba ? 2u : 1u)) ++bad;
             if (c.is_rel && (rec_class(r[0]) != 0u || (r[0] & 0xFFFFFFu) != c.delta || rec_pixels(r[0]) != 1u)) ++bad;
             if (c.is_run && (rec_class(r[0]) != 0u || (r[0] & 0xFFFFFFu) != 0u || rec_pixels(r[0]) != chunk_run(c))) ++bad;
-            if (c.is_index && (rec_class(r[0]) != 1u || (r[0] & 0xFFFFFFu) != c.b1 || rec_pixels(r[0]) != 1u)) ++bad;
+            if (c.is_index && (rec_class(r[0]) != 1u || (r[0] & 0xFFFFFFu) != (c.b1 | (c.b1 << 8)) || rec_pixels(r[0]) != 1u)) ++bad;
             if (c.is_rgb && (rec_class(r[0]) != 2u || (r[0] & 0xFFFFFFu) != (c.rgba & 0xFFFFFFu) || rec_pixels(r[0]) != 1u)) ++bad;
             if (c.is_rgba && (rec_class(r[0]) != 2u || rec_pixels(r[0]) != kRecStash || (r[0] & 0xFFFFFFu) != (c.rgba & 0xFFFFFFu) ||
                               rec_class(r[1]) != 3u || (r[1] & 0xFFu) != (c.rgba >> 24) || rec_pixels(r[1]) != 1u)) ++bad;
@@ -174,7 +174,7 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
             const uint32_t* ent = &entry[(size_t)j * 65u];
             const uint32_t a_in = alpha_in[j];
             auto hint = [&](uint32_t src) -> uint32_t { return refine ? ent[src] >> 24 : a_in; };
-            const sym_t px = recmode ? summarize_records(&recs[(size_t)j * region], rec_gran[j], slot_in[j], alpha_in[j], t, hint, j == 0 || !refine)
+            const sym_t px = recmode ? summarize_records_plain(&recs[(size_t)j * region], rec_gran[j], slot_in[j], alpha_in[j], t, hint, j == 0 || !refine, refine)
                            : fast ? summarize_segment_fast(in, base + phase[j], end, slot_in[j], alpha_in[j], lut, t, hint, j == 0 || !refine)
                                   : summarize_segment(in, base + phase[j], end, slot_in[j], alpha_in[j], t, j == 0 || !refine);
             for (int k = 0; k < 64; ++k) summary[(size_t)j * 65u + k] = t.v[k];

@@ -11,11 +11,11 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > "$OUT/pytest.log" 2>&1; echo "rc=$?" >> "$OUT/pytest.log"; tail -4 "$OUT/pytest.log"
 echo "== bench"; timeout 900 python bench.py > "$OUT/bench.log" 2>&1; echo "rc=$?" >> "$OUT/bench.log"; tail -2 "$OUT/bench.log"
 echo "== rocprofv3 kernel trace + stats"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o trace -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu --no-others --no-single) > "$OUT/prof.log" 2>&1
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o trace -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu --no-others --no-single --no-configs) > "$OUT/prof.log" 2>&1
 echo "rc=$?" >> "$OUT/prof.log"
 echo "== PMC: HBM traffic of the bench kernels (separate passes)"
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OLDPWD/$OUT/pmc_$set" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu --no-others --no-single) > "$OUT/pmc_$set.log" 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OLDPWD/$OUT/pmc_$set" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu --no-others --no-single --no-configs) > "$OUT/pmc_$set.log" 2>&1
   echo "$set rc=$?"
 done
 python - "$OUT" <<'PY'
@@ -38,7 +38,8 @@ for k in sorted(rows):
         if v:
             e[c + '_KB'] = round(sum(v) / len(v), 1); e['launches_averaged'] = len(v)
     kern[k] = e
-doc = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu --no-others --no-single (two separate passes, tools/gpu_session.sh)",
+doc = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu --no-others --no-single --no-configs (two separate passes, tools/gpu_session.sh)",
+       "frames": 1024,
        "note": "per-launch means over the batch launches (largest grid of each kernel); KB as rocprofv3 reports them. gfx950: FETCH_SIZE tallies 128-byte read requests at 64 bytes (MI355X_MICROARCH.md HBM section); calibration: enc_slab_summary is a pure streaming read of every pixel byte of the batch, its FETCH_SIZE comes out at ~0.5 x those bytes -> read bytes = 2 x FETCH_SIZE. WRITE_SIZE is taken as reported.",
        "read_correction": 2.0, "kernels": kern}
 json.dump(doc, open(out + '/pmc_traffic.json', 'w'), indent=1)
