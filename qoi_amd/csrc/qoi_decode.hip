@@ -2318,7 +2318,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     RecSource S; S.init(p, blockIdx.x, lane, have && px_first < limit ? p.rec_gran[q] : 0u);
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);
 #ifndef QOIMI_P4_DEPTH
-#define QOIMI_P4_DEPTH 3
+#define QOIMI_P4_DEPTH 2
 #endif
     constexpr uint32_t kDepth = QOIMI_P4_DEPTH;                  // blocks of records in flight (see dec_summarize_rec)
     u32x4 ring[2u * kDepth];
@@ -2358,6 +2358,12 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
             const u32x4 c0 = ring[2u * d], c1 = ring[2u * d + 1u];      // the loads issued kDepth - 1 blocks (of eight steps) ago
             W.drain_block();                                    // a static number of stores (BurstWriter)
             const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            // Which steps of the block have a QOI_OP_RGB / QOI_OP_RGBA record, and which a run of three pixels or more, in some lane:
+            // sixteen compares up front, SCALAR tests at the steps.  (A branch on a vector compare made in the step holds the
+            // wavefront for ~40 cycles even when it is not taken, tools/ubench/valu_lat.hip - there were two per step.)
+            unsigned long long hm[8], lm[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) { hm[u] = __ballot((int32_t)rc[u] < 0); lm[u] = __ballot((rc[u] & 0x3F000000u) > 0x02000000u); }
 #pragma unroll
             for (uint32_t u = 0; u < 8u; ++u) {
                 if (kDrainEvery < 8u && u == 4u) W.drain_block();
@@ -2365,7 +2371,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                 uint32_t rem = (rec >> 24) & 63u;                                 // 0: null record
                 // two complete bodies (see dec_summarize_rec: a step costs its instruction count): the common one knows nothing of
                 // QOI_OP_RGB / QOI_OP_RGBA
-                if (__builtin_expect(lanes_where((int32_t)rec < 0) != 0, 0)) {   // QOI_OP_RGB keeps the alpha; QOI_OP_RGBA = stash record + alpha record (qoi.h:548-557)
+                if (__builtin_expect(hm[u] != 0ull, 0)) {                        // QOI_OP_RGB keeps the alpha; QOI_OP_RGBA = stash record + alpha record (qoi.h:548-557)
                     const uint32_t idx8 = rec & 0x3F00u;
                     const uint32_t t = *(const lds_u32*)(tab_base + idx8);
                     uint32_t rel = px;
@@ -2402,11 +2408,13 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                 if (CLIP) rem = min(rem, limit - W.ppos);                 // over-long run clipped (Appendix B item 8)
                 const uint32_t n2 = min(rem, 2u);
                 W.put2n(px, n2);
-                rem -= n2;
-                if (rem) {                                                 // QOI_OP_RUN of three or more (qoi.h:573-575)
-                    if (rem >= kLongRun) W.splat(px, rem);
-                    while (rem) { W.put(px); --rem; }
-                    if (W.ppos - W.fpos > Writer::kRing - 2u * kDrainEvery) W.drain();
+                if (__builtin_expect(lm[u] != 0ull, 0)) {                  // QOI_OP_RUN of three or more (qoi.h:573-575) in some lane
+                    rem -= n2;
+                    if (rem) {
+                        if (rem >= kLongRun) W.splat(px, rem);
+                        while (rem) { W.put(px); --rem; }
+                        if (W.ppos - W.fpos > Writer::kRing - 2u * kDrainEvery) W.drain();
+                    }
                 }
             }
             ring[2u * d] = S.granule(2u * (blk + kDepth)); ring[2u * d + 1u] = S.granule(2u * (blk + kDepth) + 1u);

@@ -598,6 +598,8 @@ __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, 
                 const int stop = incl ? __builtin_ctzll(incl) : 64;       // nearest inclusive record
                 const u64 need = stop >= 64 ? ~0ull : ((1ull << stop) - 1ull);
                 if (notready & need) {                                    // a record we must add is not published yet
+                    // (first pass: a predecessor that gave the image up never publishes - the image is encoded again anyway)
+                    if (ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
                     if (++spins > (1u << 22)) { if (lane == 0) atomicOr(p.err, 1u); break; }
                     __builtin_amdgcn_s_sleep(1);
                     continue;
@@ -621,17 +623,24 @@ __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, 
     const u64 pos = (u64)kHeaderBytes + excl;
     if (!(ABL & 1) && slab_bytes) {
         __builtin_amdgcn_wave_barrier();
+        // head up to the first 16-byte boundary byte by byte, aligned 16-byte stores (source re-aligned with v_alignbyte: the
+        // staged bytes sit `head` past a dword boundary), tail byte by byte - as enc_compact does from the scratch slot
         uint8_t* dst = out + pos;
-        const uint32_t mis = (uint32_t)(uintptr_t)dst & 3u;
-        const uint32_t head = min(slab_bytes, (4u - mis) & 3u);           // bytes up to the first aligned dword
+        const uint32_t mis = (uint32_t)(uintptr_t)dst & 15u;
+        const uint32_t head = min(slab_bytes, (16u - mis) & 15u);
         if (lane < head) dst[lane] = stage8[lane];
-        const uint32_t ndw = (slab_bytes - head) >> 2;
-        uint32_t* dst32 = reinterpret_cast<uint32_t*>(dst + head);
-        for (uint32_t j = lane; j < ndw; j += 64u) {                      // staged bytes sit `head` past a dword boundary
-            const uint32_t w0 = L.stage[j], w1 = L.stage[j + 1u];
-            dst32[j] = __builtin_amdgcn_alignbyte(w1, w0, head);
+        const uint32_t n16 = (slab_bytes - head) >> 4;
+        uint4* d16 = reinterpret_cast<uint4*>(dst + head);
+        const uint32_t sh = head & 3u;
+        for (uint32_t j = lane; j < n16; j += 64u) {
+            const uint32_t* q = &L.stage[(head >> 2) + 4u * j];
+            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+            uint4 v;
+            v.x = __builtin_amdgcn_alignbyte(w1, w0, sh); v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            v.z = __builtin_amdgcn_alignbyte(w3, w2, sh); v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+            d16[j] = v;
         }
-        const uint32_t done_b = head + (ndw << 2);
+        const uint32_t done_b = head + (n16 << 4);
         if (lane < slab_bytes - done_b) dst[done_b + lane] = stage8[done_b + lane];
     }
     if (LAST) {                                           // trailer (qoi.h:339,480-482) + *out_len
@@ -838,7 +847,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     const uint32_t quads_per_image = (p.spi + 3u) / 4u;
     const uint32_t wgs_per_image = (quads_per_image + p.quads_per_wg - 1u) / p.quads_per_wg;
     p.n_units = wgs_per_image * p.n_images;
-    const bool warm = p.warm && PROBE == 1 && p.scratch;
+    const bool warm = p.warm && PROBE == 1;
     uint32_t small = 2048u;                                  // grid of the passes that usually have nothing to do
     tm->mark(kT_begin, st);
     if (phases & kEncSlabs) {
@@ -857,6 +866,9 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     tm->mark(kT_enc_scan_groups, st);
     hipLaunchKernelGGL(enc_scan_images, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_images, st);
+    // look-back mode: the images the first pass gave up on are encoded again from their first slab, with look-back records and
+    // tickets of their own (those of the first pass are spent)
+    if (warm && !p.scratch) { p.status = p.status2; p.ticket = p.ticket2; }
     hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL, 0>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
     tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
     }

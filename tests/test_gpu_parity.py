@@ -248,6 +248,7 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
 @pytest.mark.parametrize("env", [
     {"QOIMI_ENC_WARM": "0"},                              # entry states from per-slab summaries + scans for every image
     {"QOIMI_ENC_LOOKBACK": "1"},                          # single-pass decoupled look-back instead of scratch + compaction
+    {"QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_WARM": "0"},   # ... with the entry states from the summary passes
     {"QOIMI_ENC_PROBE": "0"},                             # order-independent colour-table probe (ds_or masks)
     {"QOIMI_DEC_FINE": "0", "QOIMI_SEG_BYTES": "2048"},   # lane-per-segment P1/P2 instead of 128-byte pieces
     {"QOIMI_SEG_BYTES": "1024"},                          # P1/P2 on 8 pieces per segment
@@ -260,6 +261,7 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_DEC_REC": "0", "QOIMI_SEG_BYTES": "2048"},
     {"QOIMI_DEC_REC_CAP_MB": "1"},                        # record arena capped at 1 MiB: the batch is decoded in sub-batches
     {"QOIMI_SEG_BYTES": "320"},                           # a segment size without the 128-byte piece parse: full parse, transcode from S1's phases
+    {"QOIMI_P3_PLAIN": "0"},                              # P3 on records in its general form from the first chunk on
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
