@@ -179,6 +179,61 @@ def equal_batches(torch, a, b, F, stride, nbytes) -> bool:
     return True
 
 
+def dropin_path(torch, api, ctx, pixels, w, h, dev) -> dict:
+    """qoi_encode / qoi_decode of the C ABI (include/qoi_mi355x.h, = qoi.h:278/289) on malloc'ed host memory, one 4K frame."""
+    import ctypes
+    lib = api.load_library()
+    npx = w * h
+    host_px = pixels[:npx * 4].cpu().numpy().copy()                       # pageable
+    desc = api.QoiDesc(w, h, 4, api.QOI_SRGB)
+    enc, dec = lib.qoi_encode, lib.qoi_decode
+    enc.restype = ctypes.c_void_p; enc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    dec.restype = ctypes.c_void_p; dec.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    free = ctypes.CDLL(None).free; free.argtypes = [ctypes.c_void_p]; free.restype = None
+    n = ctypes.c_int(0)
+
+    def best(fn, reps=5):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return min(ts)
+    p = enc(host_px.ctypes.data, ctypes.byref(desc), ctypes.byref(n))      # warm-up (thread context, pinned staging)
+    if not p:
+        return {"error": "qoi_encode failed"}
+    stream_bytes = ctypes.string_at(p, n.value); free(p)
+    sbuf = (ctypes.c_ubyte * len(stream_bytes)).from_buffer_copy(stream_bytes)
+    outs = []
+    t_enc = best(lambda: outs.append(enc(host_px.ctypes.data, ctypes.byref(desc), ctypes.byref(n))))
+    for q in outs:
+        free(q)
+    d = api.QoiDesc()
+    q = dec(ctypes.addressof(sbuf), len(stream_bytes), ctypes.byref(d), 4)
+    ok = bool(q) and np.array_equal(np.frombuffer(ctypes.string_at(q, npx * 4), dtype=np.uint8), host_px)
+    if q:
+        free(q)
+    outs = []
+    t_dec = best(lambda: outs.append(dec(ctypes.addressof(sbuf), len(stream_bytes), ctypes.byref(d), 4)))
+    for q in outs:
+        free(q)
+    # the copies alone: pageable host <-> device, same sizes
+    dpx = torch.empty(npx * 4, dtype=torch.uint8, device=dev); dst = torch.empty(len(stream_bytes), dtype=torch.uint8, device=dev)
+    hpx = torch.from_numpy(host_px); hst = torch.frombuffer(bytearray(stream_bytes), dtype=torch.uint8)
+    hpx2 = torch.empty_like(hpx); hst2 = torch.empty_like(hst)
+
+    def sync(fn):
+        fn(); torch.cuda.synchronize()
+    sync(lambda: dpx.copy_(hpx)); sync(lambda: hst2.copy_(dst))
+    c_enc = best(lambda: sync(lambda: (dpx.copy_(hpx), hst2.copy_(dst))))
+    c_dec = best(lambda: sync(lambda: (dst.copy_(hst), hpx2.copy_(dpx))))
+    return {"workload": f"1 x {w}x{h} RGBA frame through qoi_encode / qoi_decode on host pointers (PCIe in and out inside the call)",
+            "encode_ms": round(t_enc * 1e3, 3), "decode_ms": round(t_dec * 1e3, 3),
+            "encode_mpixels_per_s": round(npx / t_enc / 1e6, 1), "decode_mpixels_per_s": round(npx / t_dec / 1e6, 1),
+            "copies_alone_ms": {"encode": round(c_enc * 1e3, 3), "decode": round(c_dec * 1e3, 3)},
+            "frac_of_copies": {"encode": round(c_enc / t_enc, 3), "decode": round(c_dec / t_dec, 3)},
+            "pcie_bytes": {"encode": npx * 4 + len(stream_bytes), "decode": npx * 4 + len(stream_bytes)},
+            "round_trip_exact": ok}
+
+
 def main() -> None:
     if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":            # one core's share of cpu_baseline_all_cores
         print(json.dumps(cpu_baseline(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))))
@@ -302,6 +357,12 @@ def main() -> None:
                                "unit": "GB/s", "frac": round(npx * 4 / dt_e / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                                "algorithmic_bytes_per_launch": npx * 4, "ms_per_launch": round(dt_e * 1e3, 4),
                                "target": "BASELINE.md: 50 % of the roofline = 8.3 us per 4K frame"}}
+
+    # The reference's own entry points (qoi.h:278/289) on HOST pointers: pixels and stream cross PCIe in both directions inside the
+    # call.  Reported beside the copies alone (the same bytes, the same pageable buffers, torch copy_), never as `value`.
+    dropin = None
+    if not args.encode_only and not args.no_single and rank == 0 and world == 1:
+        dropin = dropin_path(torch, api, ctx, pixels, w, h, dev)
 
     # next to the headline content always report `noise` (5 B/px written: most stream traffic) and
     # `constant` (longest runs) - same batch, 3 timed steps each, rank 0 of a single-GPU run only
@@ -442,6 +503,8 @@ def main() -> None:
         out["roofline_encode_total"] = roof("whole qoimi_encode_batch (all kernels)", alg_bytes, enc_tot_ms, note="SURVEY.md 8d: 4 B read per pixel")
         if single:
             out["single_frame"] = single
+        if dropin is not None:
+            out["dropin_host_pointers"] = dropin
         if cfg2:
             out["encode_1080p_batch"] = cfg2
         if cfg3:
