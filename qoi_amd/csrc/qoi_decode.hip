@@ -1984,6 +1984,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
     have = have && j >= im.start_seg && j < im.n_active;
+    if (REFINE && p.only_flat) have = have && dec_image_is_flat(im.chunks_end, im.npx);      // the first round's extra passes
     if (!lanes_where(have)) return;
     RecSource S; S.init(p, blockIdx.x, lane, have ? p.rec_gran[q] : 0u);
 #ifdef QOIMI_P3_ABL_NOLOOP
@@ -2565,11 +2566,25 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     if (!p.total_segs) return;
     const uint32_t b256 = (p.total_segs + 255u) / 256u, b64 = (p.total_segs + 63u) / 64u;
     tm->mark(kT_begin, st);
+    auto chain_state = [&]() {
+        hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
+        hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
+        hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);
+        tm->mark(kT_dec_chain_state, st);
+    };
     if (refine) {
-        if (p.use_rec) hipLaunchKernelGGL(dec_summarize_rec<true>, dim3(b64), dim3(64), 0, st, p);
-        else if (p.pair & 2u) hipLaunchKernelGGL(dec_summarize_pair<true>, dim3(b64), dim3(128), 0, st, p);
-        else hipLaunchKernelGGL(dec_summarize<true>, dim3(b64), dim3(64), 0, st, p);
-        tm->mark(kT_dec_summarize, st);
+        // A refinement round repeats "summaries from the hinted entry states, entry states from the summaries" refine_inner times
+        // before it decodes: a summary made from the hints of the previous round is stale where the new entry states differ in
+        // what the hints are read from (UI frames with several alpha levels crawled two segments per round through such
+        // stretches: 13 rounds, each with a P4 over every open segment).  P3 + S3 are a fraction of P4 on such streams.
+        const uint32_t inner = p.refine_inner ? p.refine_inner : 1u;
+        for (uint32_t it = 0; it < inner; ++it) {
+            if (p.use_rec) hipLaunchKernelGGL(dec_summarize_rec<true>, dim3(b64), dim3(64), 0, st, p);
+            else if (p.pair & 2u) hipLaunchKernelGGL(dec_summarize_pair<true>, dim3(b64), dim3(128), 0, st, p);
+            else hipLaunchKernelGGL(dec_summarize<true>, dim3(b64), dim3(64), 0, st, p);
+            tm->mark(kT_dec_summarize, st);
+            if (it + 1u < inner) chain_state();
+        }
     } else {
     if (p.use_rec) {
         hipLaunchKernelGGL(dec_transcode<1>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
@@ -2586,10 +2601,20 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     else hipLaunchKernelGGL(dec_summarize<false>, dim3(b64), dim3(64), 0, st, p);
     tm->mark(kT_dec_summarize, st);
     }
-    hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
-    hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);
-    tm->mark(kT_dec_chain_state, st);
+    chain_state();
+    if (!refine && p.use_rec && p.first_inner) {
+        // Flat images (dec_image_is_flat): their first round nearly always fails at the second or third segment - P2's guess
+        // "an INDEX chunk leaves the alpha as it is" is wrong where alpha levels go through the colour table - and a round's P4
+        // rewrites every pixel.  A few refinement passes from the speculated entry states settle most of them before it
+        // (host rehearsal, 96 UI frames: 24 verify in the first round without, 89 with two passes, 93 with four).
+        DecParams pf = p;
+        pf.only_flat = 1u;
+        for (uint32_t it = 0; it < p.first_inner; ++it) {
+            hipLaunchKernelGGL(dec_summarize_rec<true>, dim3(b64), dim3(64), 0, st, pf);
+            tm->mark(kT_dec_summarize, st);
+            chain_state();
+        }
+    }
     if (p.use_rec) {
         if (out_channels == 4) hipLaunchKernelGGL(dec_segments_rec<4>, dim3(b64), dim3(64), 0, st, p);
         else hipLaunchKernelGGL(dec_segments_rec<3>, dim3(b64), dim3(64), 0, st, p);

@@ -391,6 +391,12 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.rec_rows = rec_region_dwords(B) / 4u;
     p.sync_all = 0;
     p.p3_plain = getenv("QOIMI_P3_PLAIN") ? (uint32_t)atoi(getenv("QOIMI_P3_PLAIN")) : 1u;
+    p.refine_inner = getenv("QOIMI_DEC_INNER") ? (uint32_t)atoi(getenv("QOIMI_DEC_INNER")) : 4u;
+    {   // extra first-round passes only if the call holds a flat image at all
+        bool any_flat = false;
+        for (int i = 0; i < n_images && !any_flat; ++i) any_flat = sizes[i] > 22 && dec_image_is_flat((uint32_t)sizes[i] - 8u, descs[i].width * descs[i].height);
+        p.first_inner = any_flat ? (getenv("QOIMI_DEC_INNER1") ? (uint32_t)atoi(getenv("QOIMI_DEC_INNER1")) : 3u) : 0u;
+    }
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
     const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
     {   // P1/P2 on 128-byte pieces when a segment is 1, 8, 16, 32 or 64 of them

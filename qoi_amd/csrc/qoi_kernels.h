@@ -92,6 +92,10 @@ struct DecImage {
     uint32_t final_px;     // exit pixel of the last active segment                 (P4)
 };
 
+// "Flat" images - a stream of less than a byte per eight pixels (UI frames, constant frames): a pass over their chunks costs a
+// fraction of a pass over their pixels, so the first round spends a few refinement passes of P3 + S3 on them before its P4.
+inline __host__ __device__ bool dec_image_is_flat(uint32_t chunks_end, uint32_t npx) { return (unsigned long long)chunks_end * 8ull < (unsigned long long)npx; }
+
 struct DecParams {
     const uint8_t* streams;
     DecImage* images;      // device array [n_images]
@@ -129,6 +133,9 @@ struct DecParams {
     uint32_t* first_bad;       // [n_images] min failing segment, 0xFFFFFFFF: none
     uint32_t* pending;         // [1] images that need another round
     uint32_t* redo_segs;       // [1] statistics
+    uint32_t refine_inner;     // refinement rounds: repetitions of P3 + S3 before P4 (env QOIMI_DEC_INNER)
+    uint32_t first_inner;      // first round: refinement passes (P3 from the speculated entry states + S3) appended for flat images (env QOIMI_DEC_INNER1)
+    uint32_t only_flat;        // set by the launcher for those passes: dec_summarize_rec<true> serves flat images only
     uint32_t p3_plain;         // 1: dec_summarize_rec starts in its one-dword plain form (QOIMI_P3_PLAIN=0 turns it off: diagnostics)
     uint32_t sync_all;         // 1: no look-back synchronisation - every segment takes the full parse (segment sizes the 128-byte piece parse does not cover)
     uint32_t* sync_fails;      // [1] segments whose look-back synchronisation failed in dec_transcode (they take the full parse)

@@ -135,13 +135,6 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
         ++rounds;
         const bool refine = fast && rounds > 1;       // later rounds: entry states of the previous round serve as hints
         // P2 + S2
-        if (refine) {
-            for (uint32_t j = start; j < n_active; ++j) {
-                const uint32_t* hs = &entry[(size_t)j * 65u];      // as the kernels: entry states of the previous round
-                const uint32_t epx = hs[64];
-                slot_in[j] = (uint8_t)hash_px(epx); alpha_in[j] = (uint8_t)(epx >> 24);
-            }
-        }
         if (!refine)
         for (uint32_t j = start; j < n_active; ++j) {
             const uint32_t base = 14u + j * B, end = base + B < chunks_end ? base + B : chunks_end;
@@ -165,6 +158,22 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
                     slot_apply(srec[j], s2, a2);
                 }
                 slot_apply(gt[g], slot, alpha);
+            }
+        }
+        // P3 + S3.  Refinement rounds repeat the pair: a summary made from the hints of the previous round goes stale where the
+        // new entry states differ in what the hints are read from, and P4 over every open segment is the expensive part of a round
+        // The first round may append such repetitions to its speculative pass as well (QOIMI_DEC_INNER1).
+        const int k_inner = getenv("QOIMI_DEC_INNER") ? atoi(getenv("QOIMI_DEC_INNER")) : 4;
+        const int k_inner1 = getenv("QOIMI_DEC_INNER1") ? atoi(getenv("QOIMI_DEC_INNER1")) : (recmode && (unsigned long long)chunks_end * 8ull < npx ? 3 : 0);   // as the launcher: flat images only
+        const bool round_refine = refine;
+        const int inner = round_refine ? (k_inner < 1 ? 1 : k_inner) : 1 + (fast ? k_inner1 : 0);
+        for (int it = 0; it < inner; ++it) {
+        const bool refine = round_refine || it > 0;
+        if (refine) {
+            for (uint32_t j = start; j < n_active; ++j) {
+                const uint32_t* hs = &entry[(size_t)j * 65u];      // as the kernels: entry states of the previous pass
+                const uint32_t epx = hs[64];
+                slot_in[j] = (uint8_t)hash_px(epx); alpha_in[j] = (uint8_t)(epx >> 24);
             }
         }
         // P3
@@ -210,6 +219,7 @@ static int pipeline(const uint8_t* in, int size, uint32_t npx, int och, uint32_t
                 for (int e = 0; e < 65; ++e) { const sym_t s3 = gsum[(size_t)g * 65u + e]; nc[e] = sym_eval(s3, cur[sym_src(s3)]); }
                 memcpy(cur, nc, 260);
             }
+        }
         }
         // P4 + check
         uint32_t first_bad = 0xFFFFFFFFu;
