@@ -1865,7 +1865,13 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
 #ifdef QOIMI_TR_ABL_NOSTORE
             if (live) { if ((rr[0] ^ rr[1] ^ rr[2] ^ rr[3]) == 0x12345678u) dst[(size_t)ngran * 64u] = u32x4{rr[0], rr[1], rr[2], rr[3]}; ++ngran; }
 #else
+            // non-temporal: 13.7 GB of records per 412 frames must not sweep the stream lines out of the L2 between a lane's four
+            // 32-byte requests to one 128-byte line
+#ifdef QOIMI_TR_NT_OFF
             if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; dst[(size_t)ngran * 64u] = v; ++ngran; }
+#else
+            if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; __builtin_nontemporal_store(v, &dst[(size_t)ngran * 64u]); ++ngran; }
+#endif
 #endif
         }
     };
@@ -1896,6 +1902,13 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
 // Record source of a P3 / P4 wavefront: lane l reads the granules of segment 64 * block + l through a raw buffer descriptor
 // over the granule rows of the block (row g: 64 lanes x 16 bytes, contiguous).  A lane that is through (or has no segment) asks for an offset outside the
 // descriptor and gets zeros - the null record - so the loops never mask lanes off.
+// cache policy bits of the record loads / P4's pixel bursts (buffer instructions: 2 = nt, streaming)
+#ifndef QOIMI_REC_LOAD_AUX
+#define QOIMI_REC_LOAD_AUX 0
+#endif
+#ifndef QOIMI_P4_STORE_AUX
+#define QOIMI_P4_STORE_AUX 0
+#endif
 struct RecSource {
     __amdgpu_buffer_rsrc_t rs;
     uint32_t off;          // byte offset of the lane's column in a granule row
@@ -1906,7 +1919,11 @@ struct RecSource {
         off = lane * 16u; n_gran = grans;
     }
     __device__ __forceinline__ u32x4 granule(uint32_t g) const {
-        return __builtin_amdgcn_raw_buffer_load_b128(rs, g < n_gran ? off + 1024u * g : kNowhere, 0, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, g < n_gran ? off + 1024u * g : kNowhere, 0, QOIMI_REC_LOAD_AUX);
+    }
+    // the same as a streaming (non-temporal) load: dec_summarize_rec, -3 %; dec_segments_rec is 3 % slower with it
+    __device__ __forceinline__ u32x4 granule_nt(uint32_t g) const {
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, g < n_gran ? off + 1024u * g : kNowhere, 0, 2);
     }
 };
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -2002,7 +2019,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     constexpr uint32_t kDepth = QOIMI_P3_DEPTH;
     u32x4 ring[2u * kDepth];
 #pragma unroll
-    for (uint32_t i = 0; i < 2u * kDepth; ++i) ring[i] = S.granule(i);
+    for (uint32_t i = 0; i < 2u * kDepth; ++i) ring[i] = S.granule_nt(i);
     const uint32_t tc_base = lds_addr_of(&s_tabc[lane]);                 // slot k at + k*256
     const uint32_t tm_lane = lds_addr_of(&s_tabm[0]) + (lane & 31u) * 4u + (lane >> 5);
     // PLAIN form, for as long as no lane of the wavefront has met a QOI_OP_RGBA record (opaque images: the whole segment): the
@@ -2177,7 +2194,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
         }
         // the ring slot is refilled when the block is through with it: the load goes straight into the registers the block
         // after next ... reads (a refill at the top of the block lands in shadow registers and the copies wait for it)
-        ring[2u * d] = S.granule(P3ROW(2u * (blk + kDepth))); ring[2u * d + 1u] = S.granule(P3ROW(2u * (blk + kDepth) + 1u));
+        ring[2u * d] = S.granule_nt(P3ROW(2u * (blk + kDepth))); ring[2u * d + 1u] = S.granule_nt(P3ROW(2u * (blk + kDepth) + 1u));
       }
     }
 #ifdef QOIMI_P3_ABL_NOLDSW
@@ -2257,7 +2274,7 @@ struct BurstWriter : LaneWriter<OCH, RING_, GROUP_> {
                 const uint32_t raddr = this->row - lane * 4u + owner * 4u + ((rbo + 4u * piece) << 8);
                 u32x4 w;
                 w.x = *(const lds_u32*)(raddr); w.y = *(const lds_u32*)(raddr + 256u); w.z = *(const lds_u32*)(raddr + 512u); w.w = *(const lds_u32*)(raddr + 768u);
-                __builtin_amdgcn_raw_buffer_store_b128(w, rs, Ao + 16u * piece, 0, 0);    // kNowhere + 48 is still outside
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs, Ao + 16u * piece, 0, QOIMI_P4_STORE_AUX);    // kNowhere + 48 is still outside
             }
         } else {
             const uint32_t rbase = this->row + ((this->fpos & kG) << 8);
