@@ -630,14 +630,23 @@ extern "C" void* qoi_decode(const void* data, int size, qoi_desc* desc, int chan
     if (c->io_a.reserve((size_t)size + 16) || c->io_b.reserve(out_bytes + 16)) return NULL;
     uint8_t* pixels = (uint8_t*)malloc(out_bytes);                        // qoi.h:527-531
     if (!pixels) return NULL;
-    // The pages of the result are populated by ONE helper thread while the stream goes in and the kernels run (33 MB take it
-    // ~1.2 ms - the kernel zeroes them - which is what keeps this call at 40 % of its two copies alone; four threads contend
-    // for the address-space lock and are slower, 2.5 vs 1.95 ms per 4K frame).
-    std::thread pf;
-    if (out_bytes >= ((size_t)4 << 20)) { try { pf = std::thread(prefault_pages, (void*)pixels, out_bytes); } catch (...) {} }
+    // The pages of the result are populated by TWO helper threads while the stream goes in and the kernels run (33 MB take one
+    // thread ~1.2 ms - the kernel zeroes them).  Per 4K frame: no populate 2.6 ms, one thread 1.95, two 1.61, three 2.4, four
+    // 2.5 (they contend for the address-space lock); the two copies alone take 0.79 ms (bench.py dropin_host_pointers).
+    constexpr int kPf = 2;
+    std::thread pf[kPf];
+    if (out_bytes >= ((size_t)4 << 20)) {
+        const size_t part = ((out_bytes / kPf) + 4095u) & ~(size_t)4095u;
+        for (int i = 0; i < kPf; ++i) {
+            const size_t lo = (size_t)i * part;
+            if (lo >= out_bytes) break;
+            const size_t n = (i == kPf - 1 || lo + part > out_bytes) ? out_bytes - lo : part;
+            try { pf[i] = std::thread(prefault_pages, (void*)(pixels + lo), n); } catch (...) {}
+        }
+    }
     bool ok = hipMemcpyAsync(c->io_a.base, data, (size_t)size, hipMemcpyHostToDevice, st) == hipSuccess &&
               qoimi_decode_batch(c, c->io_a.base, (size_t)size, &size, desc, 1, channels, c->io_b.base, out_bytes, st) == QOIMI_OK;
-    if (pf.joinable()) pf.join();
+    for (auto& t : pf) if (t.joinable()) t.join();
     ok = ok && hipMemcpyAsync(pixels, c->io_b.base, out_bytes, hipMemcpyDeviceToHost, st) == hipSuccess &&
          hipStreamSynchronize(st) == hipSuccess;
     if (!ok) { free(pixels); return NULL; }
