@@ -2276,6 +2276,36 @@ struct BurstWriter : LaneWriter<OCH, RING_, GROUP_> {
                 w.x = *(const lds_u32*)(raddr); w.y = *(const lds_u32*)(raddr + 256u); w.z = *(const lds_u32*)(raddr + 512u); w.w = *(const lds_u32*)(raddr + 768u);
                 __builtin_amdgcn_raw_buffer_store_b128(w, rs, Ao + 16u * piece, 0, QOIMI_P4_STORE_AUX);    // kNowhere + 48 is still outside
             }
+        } else if (kG == 16u) {
+            // 3-byte pixels, the same way in two stages: a lane with a complete group packs its 16 pixels into 12 dwords IN PLACE
+            // (the group's ring slots are free once they are read), then three of every four adjacent lanes write one owner's 48
+            // bytes as 16-byte pieces.  (One lane per group with three stores of its own was 1.76 x the time of the 4-byte path
+            // while writing 25 % fewer bytes: 64 scattered 16-byte pieces per store instruction.)
+            const uint32_t rbase = this->row + ((this->fpos & kG) << 8);
+            if (go) {
+                uint32_t v[kG];
+#pragma unroll
+                for (uint32_t k = 0; k < kG; ++k) v[k] = *(const lds_u32*)(rbase + k * 256u);
+#pragma unroll
+                for (uint32_t k = 0; k < kG; k += 4u) {
+                    const uint32_t a = v[k] & 0xFFFFFFu, b = v[k + 1u] & 0xFFFFFFu, c = v[k + 2u] & 0xFFFFFFu, e = v[k + 3u] & 0xFFFFFFu;
+                    const uint32_t o = rbase + 3u * (k >> 2) * 256u;
+                    *(lds_u32*)(o) = a | (b << 24); *(lds_u32*)(o + 256u) = (b >> 8) | (c << 16); *(lds_u32*)(o + 512u) = (c >> 16) | (e << 8);
+                }
+            }
+            const uint32_t lane = (this->row >> 2) & 63u;
+            const uint32_t A = go ? boff + this->fpos * 3u : kNowhere;             // the group's byte offset in the descriptor
+            const uint32_t rb = this->fpos & kG;
+            const uint32_t piece = lane & 3u;                                      // piece 3 does not exist: 48 bytes per group
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t owner = lane / 4u + 16u * j;
+                const uint32_t Ao = gather_lane(A, owner), rbo = gather_lane(rb, owner);
+                const uint32_t raddr = this->row - lane * 4u + owner * 4u + ((rbo + 4u * piece) << 8);
+                u32x4 w;
+                w.x = *(const lds_u32*)(raddr); w.y = *(const lds_u32*)(raddr + 256u); w.z = *(const lds_u32*)(raddr + 512u); w.w = *(const lds_u32*)(raddr + 768u);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs, piece < 3u ? Ao + 16u * piece : kNowhere, 0, 0);
+            }
         } else {
             const uint32_t rbase = this->row + ((this->fpos & kG) << 8);
             uint32_t v[kG];
@@ -2369,10 +2399,10 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     auto run = [&](auto clip_tag) {
         constexpr bool CLIP = decltype(clip_tag)::value;
         // (no early exit from the unrolled blocks and the ring slot refilled at the END of its block: see dec_summarize_rec)
-        for (uint32_t blk0 = 0; blk0 < nblk; blk0 += kDepth) {
-#pragma unroll
-          for (uint32_t d = 0; d < kDepth; ++d) {
-            const uint32_t blk = blk0 + d;
+        // one block of eight steps on ring slot D (a compile-time index: `#pragma unroll` over the slots was refused for the
+        // 3-channel instantiation, the ring went to scratch memory and every block waited for its own loads - 1.8 x the time)
+        auto block = [&](auto dtag, const uint32_t blk) {
+            constexpr uint32_t d = decltype(dtag)::value;
             const u32x4 c0 = ring[2u * d], c1 = ring[2u * d + 1u];      // the loads issued kDepth - 1 blocks (of eight steps) ago
             W.drain_block();                                    // a static number of stores (BurstWriter)
             const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
@@ -2436,7 +2466,13 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                 }
             }
             ring[2u * d] = S.granule(2u * (blk + kDepth)); ring[2u * d + 1u] = S.granule(2u * (blk + kDepth) + 1u);
-          }
+        };
+        static_assert(kDepth >= 1u && kDepth <= 4u, "ring slots are spelled out");
+        for (uint32_t blk0 = 0; blk0 < nblk; blk0 += kDepth) {
+            block(std::integral_constant<uint32_t, 0u>{}, blk0);
+            if constexpr (kDepth > 1u) block(std::integral_constant<uint32_t, 1u>{}, blk0 + 1u);
+            if constexpr (kDepth > 2u) block(std::integral_constant<uint32_t, 2u>{}, blk0 + 2u);
+            if constexpr (kDepth > 3u) block(std::integral_constant<uint32_t, 3u>{}, blk0 + 3u);
         }
     };
     if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
