@@ -1707,6 +1707,14 @@ struct PipeReader {
         w32 = __builtin_amdgcn_alignbit(d1, d0, sh);
         b5 = (d1 >> sh) & 0xFFu;
     }
+    // the same, byte 4 left for the caller who needs it: b5 = (hi >> sh) & 0xFF (only a QOI_OP_RGBA's alpha record asks)
+    __device__ __forceinline__ void peek4(uint32_t pos, uint32_t& w32, uint32_t& hi, uint32_t& sh) const {
+        const uint32_t rp = pos - aoff;
+        const lds_u32* q = (const lds_u32*)(ring + ((rp >> 2) & (RD - 1u)) * 256u);
+        const uint32_t d0 = q[0]; hi = q[64];
+        sh = (rp & 3u) * 8u;
+        w32 = __builtin_amdgcn_alignbit(hi, d0, sh);
+    }
     // one period's memory work for register set S (compile-time 0..2): land what S holds (asked for three periods ago), ask again
     template <int S>
     __device__ __forceinline__ void turn(uint32_t pos) {
@@ -1729,7 +1737,7 @@ struct PipeReader {
 #endif
 typedef PipeReader TransReader;
 constexpr uint32_t kTrThreads = 64u * QOIMI_TR_WAVES;
-struct LdsLutT { uint32_t tpl[256], info[256]; };   // record template; chunk-table word with QOI_OP_RGBA's length set to 0 (visited twice)
+struct LdsLutT { uint32_t tpl[260], info[260]; };   // record template; chunk-table word with QOI_OP_RGBA's length set to 0 (visited twice); entry 256: the null chunk of a lane that is through (no record, no bytes, no pixels)
 
 // Parse + P2 + transcode: lane = segment.  Walks every chunk that starts in the segment, writes the chunk records of the
 // segment as 16-byte granules (row g of the wavefront's block, null-padded), counts the pixels and leaves the speculative
@@ -1759,6 +1767,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         s_lut.tpl[b] = rec_template(b);
         s_lut.info[b] = b == 0xFFu ? (i & ~7u) : i;
     }
+    if (threadIdx.x < 4u) { s_lut.tpl[256u + threadIdx.x] = 0u; s_lut.info[256u + threadIdx.x] = 0u; }
     __syncthreads();
     const uint32_t q = blockIdx.x * kTrThreads + threadIdx.x;
     bool have = q < p.total_segs;
@@ -1817,9 +1826,9 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         if (fails != 0 && lane == (uint32_t)__builtin_ctzll(fails)) atomicAdd(p.sync_fails, (uint32_t)__builtin_popcountll(fails));
     }
     bool active = have && !failed && pos < end;
-    uint32_t w32, b5; R.peek(pos, w32, b5);
-    uint32_t tpl, info;
-    {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); tpl = lq[0]; info = lq[256]; }
+    uint32_t w32, b5hi, b5sh; R.peek4(pos, w32, b5hi, b5sh);
+    uint32_t tpl, info;                        // of the chunk under the cursor; the null entry once the lane is through
+    {   const lds_u32* lq = (const lds_u32*)(lut_base + (active ? (w32 & 0xFFu) : 256u) * 4u); tpl = lq[0]; info = lq[260]; }
     uint32_t a_abs = 0u, a_last = 0u;            // a QOI_OP_RGBA occurred in the segment / the alpha of the last one (for dec_slot_tails)
     uint32_t pend = 0u;                          // 1: the stash record of the QOI_OP_RGBA chunk under the cursor is out
     bool any_pend = false;
@@ -1832,8 +1841,8 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
             uint32_t rr[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) {
-                const uint32_t c_info = active ? info : 0u;
-                uint32_t rec = active ? tpl : 0u;                        // null record once the lane is through
+                const uint32_t c_info = info;
+                uint32_t rec = tpl;                                      // null record once the lane is through (LUT entry 256)
                 uint32_t adv = lut_len(c_info);
                 // byte-wise delta of a relative chunk: table part + the second byte of a LUMA chunk (qoi.h:566-571)
                 const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)c_info, 28, 1);      // all ones for LUMA
@@ -1844,6 +1853,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                     const bool hi = lut_hi(c_info), lo = lut_lo(c_info);
                     const bool rgba = hi && lo, second = rgba && pend != 0u, first = rgba && pend == 0u;
                     const uint32_t rgb = (w32 >> 8) & 0x00FFFFFFu;
+                    const uint32_t b5 = (b5hi >> b5sh) & 0xFFu;                              // chunk byte 4: the alpha of a QOI_OP_RGBA
                     const uint32_t rec_hi = second ? rec_make(3u, 1u, b5) : (rec | rgb);      // rec still is the class-2 template here
                     rec = hi ? rec_hi : rec;
                     adv = second ? 5u : adv;
@@ -1855,12 +1865,12 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                 }
                 npix += cnt;
                 const uint32_t npos = pos + adv;
-                uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
-                const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
-                const uint32_t ntpl = lq[0], ninfo = lq[256];
+                uint32_t nw32; R.peek4(npos, nw32, b5hi, b5sh);
+                active = active && npos < end;
+                const lds_u32* lq = (const lds_u32*)(lut_base + (active ? (nw32 & 0xFFu) : 256u) * 4u);
+                const uint32_t ntpl = lq[0], ninfo = lq[260];
                 rr[u] = rec;
-                pos = npos; w32 = nw32; b5 = nb5; tpl = ntpl; info = ninfo;
-                active = active && pos < end;
+                pos = npos; w32 = nw32; tpl = ntpl; info = ninfo;
             }
 #ifdef QOIMI_TR_ABL_NOSTORE
             if (live) { if ((rr[0] ^ rr[1] ^ rr[2] ^ rr[3]) == 0x12345678u) dst[(size_t)ngran * 64u] = u32x4{rr[0], rr[1], rr[2], rr[3]}; ++ngran; }
