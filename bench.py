@@ -496,7 +496,19 @@ def main() -> None:
                              note="the kernel of the north star's 4K-encode roofline target; the kernel with the largest share of the step is in roofline_dominant"),
         }
         if not args.encode_only:
-            out["roofline_dominant"] = roof("dec_segments_rec", dec_bytes / seg_per_call, seg_ms, traffic=None, launches_per_decode_call=round(seg_per_call, 2),
+            # PMC traffic of the kernel's largest launch (a sub-batch of the decode call), scaled to the average launch by segments
+            seg_traffic = seg_src = None
+            try:
+                kdoc = json.load(open(TRAFFIC_FILE))
+                for name, k in kdoc["kernels"].items():
+                    if name.startswith("qoimi::dec_segments_rec<4>") and "FETCH_SIZE_KB" in k and "WRITE_SIZE_KB" in k and k.get("grid") and dstats.get("segments"):
+                        sc = (dstats["segments"] / seg_per_call) / float(k["grid"])
+                        seg_traffic = (k["FETCH_SIZE_KB"] * kdoc["read_correction"] + k["WRITE_SIZE_KB"]) * 1024.0 * sc
+                        seg_src = (f"profiles/{os.path.basename(TRAFFIC_FILE)}: {name}, launch of {k['grid']} segment lanes (2 x FETCH_SIZE + WRITE_SIZE), "
+                                   f"x {sc:.3f} = segments of an average launch of this run")
+            except (OSError, ValueError, KeyError):
+                pass
+            out["roofline_dominant"] = roof("dec_segments_rec", dec_bytes / seg_per_call, seg_ms, traffic=seg_traffic, traffic_source=seg_src, launches_per_decode_call=round(seg_per_call, 2),
                                             note="largest share of the step; algorithmic bytes as SURVEY.md 8d defines them for decode (stream bytes + 4 B written per pixel) - "
                                                  "the kernel itself reads one 4-byte chunk record per chunk instead of the stream (DESIGN.md section 4)")
             out["roofline_decode_total"] = roof("whole qoimi_decode_batch (all kernels)", dec_bytes, dec_tot_ms, note="SURVEY.md 8d: stream bytes read + 4 B written per pixel")
