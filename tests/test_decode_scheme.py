@@ -92,6 +92,26 @@ def test_uiflat_exact_even_if_restarts(host_lib, port):
         assert np.array_equal(got, px.reshape(-1))
 
 
+def test_refinement_passes_cut_the_rounds_of_flat_frames(host_lib, port, monkeypatch):
+    """UI frames (alpha levels through the colour table): P3 + S3 repeated inside a refinement round, and appended to the first
+    round of flat images, verify them in a few rounds; one pass per round crawls two segments per round through some stretches.
+    Same schedule as the launcher (qoi_decode.hip launch_decode_round)."""
+    w, h = 3840, 2160
+    worst = {}
+    for seed in (81, 73, 12):
+        px = synth.frame_rgba("uiflat", w, h, seed)
+        s = port.encode(px, w, h, 4)
+        for name, env in (("default", {}), ("off", {"QOIMI_DEC_INNER": "1", "QOIMI_DEC_INNER1": "0"})):
+            for k in ("QOIMI_DEC_INNER", "QOIMI_DEC_INNER1"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got, stats = run(host_lib, s, 4, 512, 64, "rec")
+            assert np.array_equal(got, px.reshape(-1)), (seed, name)
+            worst[name] = max(worst.get(name, 0), stats[0])
+    assert worst["default"] <= 5 and worst["off"] >= 2 * worst["default"], worst
+
+
 def test_record_dense_segments(host_lib, port):
     """B + 1 records from a B-byte segment (cases.dense_record_streams): the record region of a segment must hold them."""
     n = 0

@@ -409,6 +409,45 @@ def test_decode_repair_loop_is_bounded(api, oracle, rounds):
         del os.environ["QOIMI_SEG_BYTES"]
 
 
+def test_flat_ui_frames_verify_in_few_rounds(api, oracle):
+    """UI frames whose alpha levels go through the colour table: the refinement passes (P3 + S3 repeated, and appended to the
+    first round for flat images) keep them at a handful of rounds - they took 13 with one pass per round.  Checked for the
+    passes switched off as well (more rounds, the same pixels)."""
+    import torch
+    from qoi_amd import synth
+    w, h, n = 1920, 1080, 6
+    streams = [oracle.encode(synth.frame_rgba("uiflat", w, h, 80 + i), w, h, 4) for i in range(n)]
+    sstride = (max(len(s) for s in streams) + 8 + 255) // 256 * 256
+    host = np.zeros(n * sstride, dtype=np.uint8)
+    for i, s in enumerate(streams):
+        host[i * sstride:i * sstride + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    want = [oracle.decode(s, 4)[0] for s in streams]
+    rounds = {}
+    for env in ({}, {"QOIMI_DEC_INNER": "1", "QOIMI_DEC_INNER1": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        os.environ["QOIMI_SEG_BYTES"] = "512"
+        try:
+            c = api.Context(0)
+            buf = torch.from_numpy(host).cuda()
+            pstride = (w * h * 4 + 255) // 256 * 256
+            out = torch.full((n * pstride,), 0xCD, dtype=torch.uint8, device="cuda")
+            c.decode_batch(buf.data_ptr(), sstride, [len(s) for s in streams], [api.QoiDesc(w, h, 4, 0)] * n, 4, out.data_ptr(), pstride)
+            rounds[len(env)] = c.decode_stats()["rounds"]
+            got = out.cpu().numpy()
+            for i in range(n):
+                assert np.array_equal(got[i * pstride:i * pstride + want[i].size], want[i]), (env, i)
+            c.close()
+        finally:
+            del os.environ["QOIMI_SEG_BYTES"]
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    assert rounds[0] <= 6 and rounds[0] <= rounds[2], rounds
+
+
 def test_hostile_stream_finishes_in_bounded_rounds(api, ctx, oracle):
     """The same hostile stream with the default limits: the number of rounds stays below the limit of the library however
     many segments mis-speculate (round 1 would have taken one round per segment: thousands)."""
