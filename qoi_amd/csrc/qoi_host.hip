@@ -633,6 +633,8 @@ extern "C" void* qoi_decode(const void* data, int size, qoi_desc* desc, int chan
     // The pages of the result are populated by TWO helper threads while the stream goes in and the kernels run (33 MB take one
     // thread ~1.2 ms - the kernel zeroes them).  Per 4K frame: no populate 2.6 ms, one thread 1.95, two 1.61, three 2.4, four
     // 2.5 (they contend for the address-space lock); the two copies alone take 0.79 ms (bench.py dropin_host_pointers).
+    // (Copying back in 4 MiB parts behind the populating threads instead of after them: 4.2 ms - every pageable copy pins its
+    // pages under the same lock the populating threads hold.)
     constexpr int kPf = 2;
     std::thread pf[kPf];
     if (out_bytes >= ((size_t)4 << 20)) {
