@@ -255,9 +255,6 @@ struct LaneWriter {
     // write out every complete aligned group of kGroup pixels; a leading partial group (segment head) pixel by pixel
     static constexpr uint32_t kGroup = GROUP_;
     __device__ __forceinline__ void store4(uint32_t i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
-#ifdef QOIMI_ABL_NOSTORE
-        if (v0 == 0x12345678u && v1 == v2 + v3)
-#endif
         if (OCH == 4) {
             *reinterpret_cast<uint4*>(out + (size_t)i * 4u) = make_uint4(v0, v1, v2, v3);
         } else {                                                      // 4 pixels -> 3 dwords of packed r,g,b
@@ -1720,11 +1717,7 @@ struct PipeReader {
     __device__ __forceinline__ void turn(uint32_t pos) {
         if (valid[S]) { put4(wr, set[S][0]); put4(wr + 4u, set[S][1]); wr += 8u; }
         const uint32_t space = RD - (req - ((pos - aoff) >> 2));      // dwords neither unread nor on their way
-#ifdef QOIMI_TR_ABL_NOLOAD
-        const bool go = space >= 8u && pos == 0xFFFFFFFFu;            // ablation: never a real request
-#else
         const bool go = space >= 8u;
-#endif
         set[S][0] = load16(abase + (size_t)req * 4u, go);
         set[S][1] = load16(abase + (size_t)req * 4u + 16u, go);
         valid[S] = go;
@@ -1872,17 +1865,9 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                 rr[u] = rec;
                 pos = npos; w32 = nw32; tpl = ntpl; info = ninfo;
             }
-#ifdef QOIMI_TR_ABL_NOSTORE
-            if (live) { if ((rr[0] ^ rr[1] ^ rr[2] ^ rr[3]) == 0x12345678u) dst[(size_t)ngran * 64u] = u32x4{rr[0], rr[1], rr[2], rr[3]}; ++ngran; }
-#else
             // non-temporal: 13.7 GB of records per 412 frames must not sweep the stream lines out of the L2 between a lane's four
-            // 32-byte requests to one 128-byte line
-#ifdef QOIMI_TR_NT_OFF
-            if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; dst[(size_t)ngran * 64u] = v; ++ngran; }
-#else
+            // 32-byte requests to one 128-byte line (with plain stores FETCH_SIZE was 3.8 x the stream bytes, now 2.5 x)
             if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; __builtin_nontemporal_store(v, &dst[(size_t)ngran * 64u]); ++ngran; }
-#endif
-#endif
         }
     };
     while (lanes_where(active)) {                                 // a period = one granule of four steps; three periods per turn of the register sets
@@ -1981,11 +1966,6 @@ __device__ __forceinline__ uint32_t symcode_addr(uint32_t lane_base, uint32_t ro
 
 // P3 on records.  One wavefront per 64 segments; 20 KiB of LDS (24 in the refinement rounds): eight per CU.
 // Same step as dec_summarize / symr_step (qoi_decode_core.h).
-#ifdef QOIMI_P3_ABL_HOT
-#define P3ROW(g) ((g) & 3u)      // timing experiment: every fetch hits the same four rows (results are wrong)
-#else
-#define P3ROW(g) (g)
-#endif
 // (a & m) | b as ONE instruction whatever else the compiler could share the parts with
 __device__ __forceinline__ uint32_t and_or_b32(uint32_t a, uint32_t m, uint32_t b) {
     uint32_t r;
@@ -1999,10 +1979,6 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     __shared__ __attribute__((aligned(16384))) uint32_t s_tabc[64 * 64];
     __shared__ __attribute__((aligned(4096))) uint8_t s_tabm[64 * 64];
     __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 4];
-#ifdef QOIMI_P3_PAD_KB
-    __shared__ uint32_t s_pad[QOIMI_P3_PAD_KB * 256];      // occupancy experiment
-    if (p.total_segs == 0xFFFFFFFFu) s_pad[threadIdx.x] = 0u;
-#endif
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     const uint32_t lane = lane_id();
     const uint32_t q = blockIdx.x * 64u + lane;
@@ -2014,11 +1990,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     if (REFINE && p.only_flat) have = have && dec_image_is_flat(im.chunks_end, im.npx);      // the first round's extra passes
     if (!lanes_where(have)) return;
     RecSource S; S.init(p, blockIdx.x, lane, have ? p.rec_gran[q] : 0u);
-#ifdef QOIMI_P3_ABL_NOLOOP
-    const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1) >> 8;
-#else
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);            // blocks of two granules = eight steps
-#endif
     // Records are fetched kDepth blocks ahead.  A wavefront has 20 KiB of LDS, so eight of them share a CU and the record
     // stream (4 B per chunk, 2.7 x the QOI bytes of a photograph) has to be kept in flight by the few wavefronts there are:
     // one block ahead = 2 KiB per wavefront = 4 MiB over the chip, which at ~2 us of loaded HBM latency is 2 TB/s - the plain
@@ -2069,9 +2041,6 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     // read-ahead state of the plain form: address and word of the next step's table read, address and word of the last table write
     uint32_t ra_cur = and_or_b32(ring[0].x, 0x3F00u, tc_base), t_cur = 0u, wa_prev = ~0u, wv_prev = 0u;
     if (plain) t_cur = *(const lds_u32*)ra_cur;
-#ifdef QOIMI_P3_ABL_NOLDSW
-    uint32_t abl_acc = 0u;
-#endif
     // One loop over the blocks, unrolled kDepth times (the ring is indexed statically: registers); a block of eight steps is
     // taken in the plain form or in the general one.  A block that holds a half of a QOI_OP_RGBA in any lane (class 3, or class 2
     // with the stash marker: exactly the records >= 0xBF000000) ends the plain form: the table is converted in front of it.
@@ -2117,11 +2086,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
                 for (uint32_t u = 0; u < 8u; ++u) {
                     const uint32_t rec = rx[u];
                     const uint32_t ra_next = and_or_b32(rx[u + 1u], 0x3F00u, tc_base);      // INDEX records carry the slot in bits 8..13 too
-#ifdef QOIMI_P3_ABL_NOLDSR
-                    const uint32_t t_next = ra_next * 0x9E3779B1u;
-#else
                     const uint32_t t_next = *(const lds_u32*)ra_next;                  // read one step ahead, i.e. before this step's write
-#endif
                     const uint32_t t = ra_cur == wa_prev ? wv_prev : t_cur;            // ... so the previous step's write is forwarded here
                     const bool isabs = rec >= 0x40000000u;                            // INDEX (or RGB: the sign bit)
                     add_byte0(ppc, rec); add_byte1(ppc, rec); add_byte2(ppc, rec);
@@ -2142,11 +2107,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
                         const bool keep = skip_runs && (rec & 0xC0FFFFFFu) == 0u;       // a RUN / null record read slot 0 (payload 0): it goes back
                         waddr = keep ? tc_base : waddr; wval = keep ? t : ppc;
                     }
-#ifdef QOIMI_P3_ABL_NOLDSW
-                    abl_acc ^= waddr + wval;
-#else
                     *(lds_u32*)waddr = wval;
-#endif
                     wa_prev = waddr; wv_prev = wval; ra_cur = ra_next; t_cur = t_next;
                 }
             };
@@ -2204,17 +2165,10 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
         }
         // the ring slot is refilled when the block is through with it: the load goes straight into the registers the block
         // after next ... reads (a refill at the top of the block lands in shadow registers and the copies wait for it)
-        ring[2u * d] = S.granule_nt(P3ROW(2u * (blk + kDepth))); ring[2u * d + 1u] = S.granule_nt(P3ROW(2u * (blk + kDepth) + 1u));
+        ring[2u * d] = S.granule_nt(2u * (blk + kDepth)); ring[2u * d + 1u] = S.granule_nt(2u * (blk + kDepth) + 1u);
       }
     }
-#ifdef QOIMI_P3_ABL_NOLDSW
-    if (abl_acc == 0x1234567u) p.summary[0] = abl_acc;
-#endif
-#ifdef QOIMI_P3_ABL_NOOUT
-    if (have && slot == 0x12345u) {
-#else
     if (have) {
-#endif
         sym_t* dst = p.summary + (size_t)q * 65u;
         if (plain) {                                                          // never left the plain form: code and constants share the word
             for (uint32_t k = 0; k < 64u; ++k) {
