@@ -230,7 +230,9 @@ __device__ __forceinline__ uint32_t prev_pixels(uint32_t v, uint32_t before) {
 // so the later (compiler-visible) reads of the staging buffer see these stores.
 // a lane mask the compiler may have lost track of as wave-uniform -> SGPR pair (free when it already is one)
 __device__ __forceinline__ u64 uniform64(u64 m) {
-    return (u64)__builtin_amdgcn_readfirstlane((uint32_t)m) | ((u64)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32);
+    // (the builtin returns int: without the casts to uint32_t a low half with bit 31 set sign-extends over the high half - the
+    // generic path then took 32 slots of the image-level table for group-local ones whenever slot 31 had been written in the group)
+    return (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m) | ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32);
 }
 __device__ __forceinline__ void stage_short(uint32_t addr, uint32_t w, u64 any, u64 second) {
     uint32_t hi;

@@ -95,7 +95,10 @@ struct qoimi_ctx {
     long long enc_calls = 0;            // encode calls so far: the self-test is repeated every 256 of them
     bool recheck_pending = false;       // a repeated self-test is in flight on own_stream, result in host_word[8]
     int enc_ablate = 0, enc_ticket = 1, enc_quads = 0, enc_warm = 1;   // tuning / profiling knobs (env QOIMI_ENC_*)
-    int enc_lookback = 0;               // 1: single-pass decoupled look-back instead of scratch + compaction
+    int enc_lookback = -1;              // 1: single-pass decoupled look-back instead of scratch + compaction; 0: never; -1: by the last call's output (below)
+    // placement mode by content: the first stream's length of the previous qoimi_encode_batch is read back through host_word[10]
+    // (copy on the caller's stream behind the kernels, looked at when the next call finds it done)
+    hipEvent_t enc_len_ev = nullptr; bool enc_len_pending = false; uint32_t enc_len_npx = 0; bool enc_dense = false;
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
     int dec_pair = 3;                   // bit 0: P4, bit 1: P3 run as reader / worker wavefront pairs; 0: one wavefront per 64 segments
@@ -164,6 +167,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
 extern "C" void qoimi_ctx_destroy(qoimi_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
+    if (c->enc_len_ev) { if (c->enc_len_pending) (void)hipEventSynchronize(c->enc_len_ev); (void)hipEventDestroy(c->enc_len_ev); }   // the read-back lands in host_word
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     c->enc_ws.release(); c->dec_ws.release(); c->io_a.release(); c->io_b.release(); c->io_c.release();
     if (c->host_word) (void)hipHostFree(c->host_word);
@@ -262,6 +266,14 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         launch_lds_order_selftest(d_flag, c->own_stream);
         if (hipMemcpyAsync(&c->host_word[8], d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->own_stream) == hipSuccess) c->recheck_pending = true;
     }
+    // Streams of several bytes per pixel (noise, RGBA-dense frames): parking the slabs and moving them again is a second trip of
+    // ~5 B/px through HBM, the look-back placement writes them once (256 4K noise frames 9.4 -> 6.2 ms; photographs at 1.2 B/px
+    // are a draw, flat UI frames lose - DESIGN.md section 3).  Both give the same bytes.
+    if (c->enc_len_pending && hipEventQuery(c->enc_len_ev) == hipSuccess) {
+        c->enc_len_pending = false;
+        c->enc_dense = c->enc_len_npx && (unsigned long long)c->host_word[10] > 3ull * c->enc_len_npx;
+    }
+    const bool lookback = c->enc_lookback < 0 ? c->enc_dense : c->enc_lookback != 0;
     p.probe_xchg = c->xchg_ordered ? 1 : 0;
     p.use_ticket = c->enc_ticket ? 1 : 0;
     p.ablate = (uint8_t)c->enc_ablate;
@@ -280,13 +292,13 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         Carver w(pass ? c->enc_ws.base : nullptr);
         p.status = w.take<u64>(T); p.ticket = w.take<uint32_t>((size_t)n_images); p.err = w.take<uint32_t>(1);
         p.need_generic = w.take<uint32_t>((size_t)n_images); p.any_generic = w.take<uint32_t>(1);
-        if (c->enc_lookback) { p.status2 = w.take<u64>(T); p.ticket2 = w.take<uint32_t>((size_t)n_images); }
+        if (lookback) { p.status2 = w.take<u64>(T); p.ticket2 = w.take<uint32_t>((size_t)n_images); }
         const size_t zero_bytes = w.off;
         p.sum_tab = w.take<uint32_t>(T * 64); p.sum_valid = w.take<u64>(T); p.sum_le = w.take<int>(T);
         p.ent_tab = w.take<uint32_t>(T * 64); p.ent_valid = w.take<u64>(T); p.ent_le = w.take<int>(T);
         p.grp_tab = w.take<uint32_t>(G * 64); p.grp_valid = w.take<u64>(G); p.grp_le = w.take<int>(G);
         p.gent_tab = w.take<uint32_t>(G * 64); p.gent_le = w.take<int>(G);
-        if (!c->enc_lookback) {
+        if (!lookback) {
             p.slab_size = w.take<uint32_t>(T); p.slab_off = w.take<uint32_t>(T);
             p.scratch = w.take<uint8_t>(T * kEncScratchStride);
         }
@@ -301,6 +313,22 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     c->timer.mark(kT_begin, st);
     launch_encode(p, st, &c->timer);
     c->timer.mark(kT_enc_total, st);
+    if (const char* dump = getenv("QOIMI_ENC_DEBUG_DUMP")) {          // diagnostics: the entry-state arrays of this call, raw
+        (void)hipStreamSynchronize(st);
+        if (FILE* fo = fopen(dump, "wb")) {
+            auto put = [&](const void* d, size_t bytes) { std::vector<uint8_t> h(bytes); (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost); fwrite(h.data(), 1, bytes, fo); };
+            const uint64_t hdr[4] = {T, G, (uint64_t)p.spi, (uint64_t)p.gpi};
+            fwrite(hdr, 8, 4, fo);
+            put(p.sum_tab, T * 256); put(p.sum_valid, T * 8); put(p.ent_tab, T * 256); put(p.ent_valid, T * 8);
+            put(p.grp_tab, G * 256); put(p.grp_valid, G * 8); put(p.gent_tab, G * 256);
+            fclose(fo);
+        }
+    }
+    if (c->enc_lookback < 0 && !c->enc_len_pending && n_images > 0) {
+        if (!c->enc_len_ev && hipEventCreateWithFlags(&c->enc_len_ev, hipEventDisableTiming) != hipSuccess) c->enc_len_ev = nullptr;
+        if (c->enc_len_ev && hipMemcpyAsync(&c->host_word[10], d_stream_len, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipEventRecord(c->enc_len_ev, st) == hipSuccess) { c->enc_len_pending = true; c->enc_len_npx = (uint32_t)npx; }
+    }
     HIP_TRY(hipGetLastError());
     return QOIMI_OK;
 }

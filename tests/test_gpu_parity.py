@@ -247,6 +247,7 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
 
 @pytest.mark.parametrize("env", [
     {"QOIMI_ENC_WARM": "0"},                              # entry states from per-slab summaries + scans for every image
+    {"QOIMI_ENC_LOOKBACK": "0"},                          # scratch slots + compaction whatever the content (default: by the last call's bytes per pixel)
     {"QOIMI_ENC_LOOKBACK": "1"},                          # single-pass decoupled look-back instead of scratch + compaction
     {"QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_WARM": "0"},   # ... with the entry states from the summary passes
     {"QOIMI_ENC_PROBE": "0"},                             # order-independent colour-table probe (ds_or masks)
@@ -407,6 +408,62 @@ def test_decode_repair_loop_is_bounded(api, oracle, rounds):
     finally:
         del os.environ["QOIMI_DEC_MAX_ROUNDS"]
         del os.environ["QOIMI_SEG_BYTES"]
+
+
+@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_WARM": "0"}, {"QOIMI_ENC_LOOKBACK": "1"}])
+def test_flat_frames_byte_identical(api, oracle, env):
+    """Flat UI frames go through the generic entry-state path (per-slab summaries + scans).  Frame 60 of this sweep was
+    encoded three bytes too long by every path until round 2: a 64-bit lane mask lost its upper half (sign extension of
+    readfirstlane) whenever hash slot 31 had been written in a slab's group, and 32 slots of the entry table came out as zero -
+    decodable, round-trip exact, but not the reference's bytes.  The sweep keeps that class of error visible."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = api.Context(0)
+        w, h, n = 1024, 600, 8
+        b = DeviceBatch(c, w, h, 4, n)
+        for base in (40, 56, 72):
+            frames = [synth.frame_rgba("uiflat", w, h, base + i) for i in range(n)]
+            for i in range(n):
+                b.upload(i, frames[i])
+            lens = b.encode()
+            torch.cuda.synchronize()
+            for i in range(n):
+                want = oracle.encode(frames[i], w, h, 4)
+                assert b.stream_bytes(i, lens[i]) == want, (env, base + i, int(lens[i]), len(want))
+        c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_placement_mode_follows_content(api, oracle):
+    """qoimi_encode_batch picks its placement (parked slabs + compaction, or look-back) from the bytes per pixel of the previous
+    call on the context: a context that sees noise, noise, photo, photo, noise goes through both switches; every stream stays
+    byte-identical to the reference's."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    c = api.Context(0)
+    w, h, n = 1024, 600, 3
+    b = DeviceBatch(c, w, h, 4, n)
+    for step, kind in enumerate(("noise", "noise", "noise", "photo", "photo", "noise", "uiflat")):
+        frames = [synth.frame_rgba(kind, w, h, 40 + step * 3 + i) for i in range(n)]
+        for i in range(n):
+            b.upload(i, frames[i])
+        lens = b.encode()
+        torch.cuda.synchronize()
+        for i in range(n):
+            want = oracle.encode(frames[i], w, h, 4)
+            got = b.stream_bytes(i, lens[i])
+            assert got == want, (step, kind, i, len(got), len(want))
+    c.close()
 
 
 def test_flat_ui_frames_verify_in_few_rounds(api, oracle):
