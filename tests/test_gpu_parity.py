@@ -443,6 +443,41 @@ def test_flat_frames_byte_identical(api, oracle, env):
                 os.environ[k] = v
 
 
+def test_random_sweep_of_contents_and_shapes(api, oracle):
+    """A seeded sweep over every synthetic content kind at shapes from a few pixels to several 64-slab groups, 3 and 4 channels:
+    encode byte-identical to the reference, decode of that stream bit-identical to the pixels.  (The fixed shapes of the other
+    tests never put hash slot 31 into the entry path that lost its upper mask half; a sweep would have.)"""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    rng = np.random.default_rng(20260923)
+    shapes = [(1, 1), (3, 2), (64, 16), (65, 17), (1023, 1), (1, 1025), (257, 255), (640, 360), (1024, 600), (1400, 900), (2048, 130)]
+    c = api.Context(0)
+    checked = 0
+    for (w, h) in shapes:
+        for ch in (4, 3):
+            n = 5
+            kinds = [synth.KINDS[int(k)] for k in rng.integers(0, len(synth.KINDS), n)]
+            seeds = [int(x) for x in rng.integers(0, 1 << 20, n)]
+            frames = [np.ascontiguousarray(synth.frame_rgba(kinds[i], w, h, seeds[i])[:, :, :ch]) for i in range(n)]
+            b = DeviceBatch(c, w, h, ch, n)
+            for i in range(n):
+                b.upload(i, frames[i])
+            lens = b.encode()
+            torch.cuda.synchronize()
+            for i in range(n):
+                want = oracle.encode(frames[i], w, h, ch)
+                assert b.stream_bytes(i, lens[i]) == want, ("encode", w, h, ch, kinds[i], seeds[i], int(lens[i]), len(want))
+            out = torch.full((n * b.pixel_stride,), 0xCD, dtype=torch.uint8, device="cuda")
+            stride = b.decode_into(out, lens, ch)
+            got = out.cpu().numpy()
+            for i in range(n):
+                assert np.array_equal(got[i * stride:i * stride + w * h * ch], frames[i].reshape(-1)), ("decode", w, h, ch, kinds[i], seeds[i])
+                checked += 1
+    c.close()
+    assert checked == len(shapes) * 2 * 5
+
+
 def test_placement_mode_follows_content(api, oracle):
     """qoimi_encode_batch picks its placement (parked slabs + compaction, or look-back) from the bytes per pixel of the previous
     call on the context: a context that sees noise, noise, photo, photo, noise goes through both switches; every stream stays
