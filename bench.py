@@ -21,7 +21,7 @@ configs[4] in total, 8192/N per GPU, processed as passes over at most F resident
 `--gpus N` without a torch.distributed.run environment starts the N ranks itself.
 
 Extra objects on the JSON line (rank 0, N = 1 unless noted):
-  roofline             enc_slabs, the kernel the north star's 50 % target is stated on: algorithmic bytes
+  roofline             enc_sets, the kernel the north star's 50 % target is stated on: algorithmic bytes
                        (4 B read per pixel) / its mean launch duration measured with HIP
                        events on the launch stream during the timed steps, against the 8 TB/s HBM peak
   roofline_dominant    the same for the kernel that takes the largest share of the step (dec_segments_rec)
@@ -383,9 +383,13 @@ def main() -> None:
                 ctx.decode_batch(streams.data_ptr(), sstride, ksizes, descs, 4, decoded.data_ptr(), pstride, stream)
             dt = timed(both, 3)
             kok = equal_batches(torch, decoded, pixels, F, pstride, npx * 4)
+            # two frames of every content class against the REFERENCE codec as well (a valid, round-tripping but longer stream -
+            # round 1's uiflat error - is only visible in a byte comparison)
+            kchk = check_against_reference(torch, pixels, pstride, streams, sstride, ksizes, w, h, sorted({0, F - 1})) if rank == 0 else None
+            kok = kok and (kchk is None or (kchk["streams_byte_identical"] and kchk["reference_decoder_round_trips"]))
             other[kind] = {"mpixels_per_s": round(F * npx / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                            "stream_bytes_per_px": round(sum(ksizes) / (F * npx), 4), "decode_rounds": ctx.decode_stats()["rounds"],
-                           "verified_bit_exact": kok}
+                           "verified_bit_exact": kok, "reference_check": kchk}
 
     # BASELINE configs[2]: 1024 x 1920x1080 RGBA, encode only (the HBM-bound roofline run) and configs[3]: one 16384 x 16384
     # image, encode + decode - in the buffers of the main batch where they fit
@@ -411,7 +415,7 @@ def main() -> None:
             cfg2 = {"workload": f"BASELINE configs[2]: {F2} x {w2}x{h2} RGBA frames (photo), encode only, HBM-resident ({F2 * n2 * 4 / 1e9:.2f} GB of pixels per launch)",
                     "ms_per_step": round(dt * 1e3, 4), "mpixels_per_s": round(F2 * n2 / dt / 1e6, 1),
                     "stream_bytes_per_px": round(sum(s2) / (F2 * n2), 4), "reference_check": chk,
-                    "roofline": {"bound": "hbm", "kernel": "enc_slabs (+ entry-state passes)", "achieved": round(F2 * n2 * 4 / (slabs_ms * 1e-3) / 1e9, 1),
+                    "roofline": {"bound": "hbm", "kernel": "enc_sets (+ entry-state passes)", "achieved": round(F2 * n2 * 4 / (slabs_ms * 1e-3) / 1e9, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(F2 * n2 * 4 / (slabs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "traffic": None, "algorithmic_bytes_per_launch": F2 * n2 * 4, "ms_per_launch": round(slabs_ms, 4)},
                     "roofline_encode_total": {"bound": "hbm", "kernel": "whole qoimi_encode_batch (all kernels)", "achieved": round(F2 * n2 * 4 / (tot_ms * 1e-3) / 1e9, 1),
@@ -448,7 +452,7 @@ def main() -> None:
         # whole calls on the launch stream
         enc_ms = prof["encode_total"][0] if prof.get("encode_total", (0, 0))[1] else sum(prof[k][0] for k in prof if k.startswith("enc_"))
         dec_ms = prof["decode_total"][0] if prof.get("decode_total", (0, 0))[1] else sum(prof[k][0] for k in prof if k.startswith("dec_"))
-        # The encode kernel of the roofline: enc_slabs plus the entry-state passes that run before its second launch
+        # The encode kernel of the roofline: enc_sets (timer tag "enc_slabs") plus the entry-state passes that run before its second launch
         # for images the first launch could not finish on its own (flat content) - every kernel that reads pixels.
         slabs_calls = prof["enc_slabs"][1]
         slabs_ms = sum(prof[k][0] for k in ("enc_slabs", "enc_slabs_generic", "enc_slab_summary", "enc_scan_groups", "enc_scan_images") if k in prof)
@@ -465,14 +469,14 @@ def main() -> None:
         dec_bytes = alg_bytes + stream_bytes               # stream read + 4 B written per pixel (whole decode)
         enc_tot_ms, dec_tot_ms = enc_ms / max(1, launches), dec_ms / max(1, launches)
 
-        slabs = (npx + 1023) // 1024
-        grid = ((slabs + 3) // 4) * F * 256
-        traffic, traffic_src = measured_traffic("qoimi::enc_slabs<4, 16, 1, 0, 1>", grid)
-        if traffic is None and args.kind == "photo" and (w, h) == (3840, 2160):        # PMC passes of a smaller batch of the same frames: per-frame traffic scales
-            for f_prof in (256, 64):
-                traffic, traffic_src = measured_traffic("qoimi::enc_slabs<4, 16, 1, 0, 1>", ((slabs + 3) // 4) * f_prof * 256, F / f_prof)
-                if traffic is not None:
-                    break
+        # PMC traffic of enc_sets from the committed passes of this command (same frames; per-frame traffic scales with the batch)
+        traffic = traffic_src = None
+        if args.kind == "photo" and (w, h) == (3840, 2160):
+            try:
+                f_prof = float(json.load(open(TRAFFIC_FILE)).get("frames", F))
+            except (OSError, ValueError):
+                f_prof = float(F)
+            traffic, traffic_src = measured_traffic("qoimi::enc_sets<4, 1, 1>", -1, F / f_prof)
         roof = lambda kernel, nbytes, ms, **kw: dict({"bound": "hbm", "kernel": kernel, "achieved": round(gbs(nbytes, ms), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                       "frac": round(gbs(nbytes, ms) / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 4)}, **kw)
         out = {
@@ -492,7 +496,7 @@ def main() -> None:
             "decode_mpps_kernels": round(F * npx * launches / (dec_ms * 1e3), 1) if dec_ms else None,
             "decode_rounds": dstats["rounds"], "decode_redo_segments": dstats["redo_segments"], "decode_sync_fallback_segments": dstats.get("sync_fallback_segments"),
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
-            "roofline": roof("enc_slabs (+ entry-state passes)", alg_bytes, per_launch_ms, traffic=traffic, traffic_source=traffic_src,
+            "roofline": roof("enc_sets (+ entry-state passes)", alg_bytes, per_launch_ms, traffic=traffic, traffic_source=traffic_src,
                              note="the kernel of the north star's 4K-encode roofline target; the kernel with the largest share of the step is in roofline_dominant"),
         }
         if not args.encode_only:
@@ -513,6 +517,11 @@ def main() -> None:
                                                  "the kernel itself reads one 4-byte chunk record per chunk instead of the stream (DESIGN.md section 4)")
             out["roofline_decode_total"] = roof("whole qoimi_decode_batch (all kernels)", dec_bytes, dec_tot_ms, note="SURVEY.md 8d: stream bytes read + 4 B written per pixel")
         out["roofline_encode_total"] = roof("whole qoimi_encode_batch (all kernels)", alg_bytes, enc_tot_ms, note="SURVEY.md 8d: 4 B read per pixel")
+        if not args.encode_only:
+            # the whole step against SURVEY.md 8d's bytes for encode + decode (pixels read, stream written and read back, pixels written)
+            out["roofline_step"] = roof("whole step: qoimi_encode_batch + qoimi_decode_batch (wall clock)", 2 * alg_bytes + 2 * stream_bytes, ms_step / max(1, passes),
+                                        note="SURVEY.md 8d: 4 B read per pixel + stream bytes written (encode), stream bytes read + 4 B written per pixel (decode)")
+        out["scaling_note"] = ("single GPU" if world == 1 else f"{world} ranks") + "; no multi-GPU scaling curve has been measured for this repository (gpurun exposes one GPU) - the driver computes efficiency from its own per-N runs"
         if single:
             out["single_frame"] = single
         if dropin is not None:

@@ -2,22 +2,23 @@
 //
 // Replaces the sequential loop of the reference encoder (qoi.h:356-486) with a
 // slab-parallel evaluation of the SAME function of the input pixels; the emitted
-// stream is byte-identical to the reference's (tests/test_gpu_encode.py).
+// stream is byte-identical to the reference's (tests/test_gpu_parity.py).
 //
 // Every output byte is a pure function of the input:
 //   * prev pixel           = the neighbouring input pixel (qoi.h:477)
 //   * "edge" pixel         = px[i] != px[i-1] (qoi.h:415)
 //   * run bytes            = function of the distance to the last edge (qoi.h:416-428)
 //   * colour-table content = last edge pixel per hash slot (qoi.h:430-436)
-// so an image is cut into slabs of 64*K pixels (one wavefront each) and only three
-// small quantities are carried between slabs:
-//   (1) the 64-entry colour table       -> passes E1 (slab summary) + E2 (scan)
-//   (2) the position of the last edge   -> same passes
+// so an image is cut into SETS of R slabs of 1024 pixels (one wavefront per set) and only
+// three small quantities are carried between sets:
+//   (1) the 64-entry colour table       -> replay of the 512 pixels before the set (hot path),
+//                                          passes E1 (slab summary) + E2 (scan) for flat content
+//   (2) the position of the last edge   -> same
 //   (3) the output byte offset          -> decoupled look-back inside pass E3
 //
-// Pass E3 is the hot kernel: one coalesced dword load per pixel, an LDS-resident
-// colour table per wavefront, 64-bit ballots / mbcnt for run lengths and byte
-// offsets.  Byte/integer work only - no MFMA.
+// Pass E3 (enc_sets) is the hot kernel: two coalesced dword loads per pixel (the pixel and the
+// one before it), an LDS-resident colour table per wavefront, 64-bit ballots / mbcnt for run
+// lengths and byte offsets.  Byte/integer work only - no MFMA.
 #include "qoi_dev.h"
 #include "qoi_kernels.h"
 
@@ -33,6 +34,17 @@ __device__ __forceinline__ uint32_t load_px(const uint8_t* __restrict__ img, uin
         return reinterpret_cast<const uint32_t*>(img)[i];
     } else {
         const uint8_t* p = img + (size_t)i * 3u;
+        return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
+    }
+}
+
+// the same relative to a per-lane pointer: pixel `k` (a compile-time constant, may be negative) after the one q points to
+template <int CH>
+__device__ __forceinline__ uint32_t load_px_at(const uint8_t* __restrict__ q, int k) {
+    if constexpr (CH == 4) {
+        return reinterpret_cast<const uint32_t*>(q)[k];
+    } else {
+        const uint8_t* p = q + k * 3;
         return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
     }
 }
@@ -150,60 +162,53 @@ __global__ __launch_bounds__(64) void enc_scan_images(EncParams p) {
 }
 
 // ---------------------------------------------------------------------------------
-// E3: classify + size + look-back + emit, one wavefront per slab.
-// ---------------------------------------------------------------------------------
-
-// Literal (non-run, non-index) chunk for px after prev: RGBA / DIFF / LUMA / RGB
-// (qoi.h:438-474).  Returns the chunk bytes little-endian in `bytes`, length in `len`.
-__device__ __forceinline__ void literal_chunk(uint32_t px, uint32_t prev, u64& bytes, uint32_t& len) {
-    const int dr = (int)(int8_t)((px & 0xFF) - (prev & 0xFF));
-    const int dg = (int)(int8_t)(((px >> 8) & 0xFF) - ((prev >> 8) & 0xFF));
-    const int db = (int)(int8_t)(((px >> 16) & 0xFF) - ((prev >> 16) & 0xFF));
-    const int drg = (int)(int8_t)(dr - dg);
-    const int dbg = (int)(int8_t)(db - dg);
-    const bool alpha_same = ((px ^ prev) >> 24) == 0;
-    const bool is_diff = (unsigned)(dr + 2) < 4u && (unsigned)(dg + 2) < 4u && (unsigned)(db + 2) < 4u;
-    const bool is_luma = (unsigned)(dg + 32) < 64u && (unsigned)(drg + 8) < 16u && (unsigned)(dbg + 8) < 16u;
-    const uint32_t diff_b = kTagDiff | ((dr + 2) << 4) | ((dg + 2) << 2) | (db + 2);
-    const uint32_t luma_b = (kTagLuma | (dg + 32)) | ((((drg + 8) << 4) | (dbg + 8)) << 8);
-    const u64 rgb_b = (u64)kTagRgb | ((u64)(px & 0x00FFFFFFu) << 8);
-    const u64 rgba_b = (u64)kTagRgba | ((u64)px << 8);
-    if (!alpha_same) { bytes = rgba_b; len = 5; }
-    else if (is_diff) { bytes = diff_b; len = 1; }
-    else if (is_luma) { bytes = luma_b; len = 2; }
-    else { bytes = rgb_b; len = 4; }
-}
-
+// E3: the hot kernel.  One wavefront encodes a SET of R consecutive slabs of one image
+// (R = p.set_slabs, 1..8): the colour table, the distance to the last edge and the staged
+// bytes carry over from slab to slab, so the entry state (below) is paid once per set and
+// the set's bytes leave the LDS in ONE piece.
+//
 // PROBE selects how the colour table is probed/updated for the 64 pixels of a step:
 //   0  ds_or_b64 lane masks + ds_bpermute (order-independent, always valid)
-//   1  one ds_wrxchg_rtn_b32 per edge lane: relies on the LDS serving the lanes of one
+//   1  one ds_wrxchg_rtn_b32 per step: relies on the LDS serving the lanes of one
 //      instruction that hit the same address in ascending lane order - MEASURED at context
 //      creation by lds_order_selftest; the host only picks 1 when that test passes.
-// LAST: the slab holds the image's last pixel (and possibly lanes beyond it).
-// ABL:  ablation bits for profiling only (1: no emission, 2: no look-back, 4: no probe).
+// GEN: the general form of a step - lanes beyond the image's last pixel are masked, the last
+//      pixel closes its run, the probe is restricted to the edge lanes.  Used for the image's
+//      FIRST set and for the group of steps that holds the image's last pixel; every other
+//      step runs the plain form (all 64 lanes valid, see probe_swap_all).
 //
-// Instruction budget (profiles/r01_s3_issue_rates.txt): a wave64 VALU op costs ~1.25 ns of a SIMD,
-// an SALU op ~1.8 ns (one scalar unit per CU) and overlaps with VALU only up to about half the
-// VALU count, a DS op 4 LDS cycles of the CU whatever its width.  So the step below is written
+// Instruction budget (profiles/r01_s3_issue_rates.txt): a wave64 VALU op costs ~1.25-1.75 ns of a
+// SIMD, an SALU op ~1.8 ns (one scalar unit per CU) and overlaps with VALU only up to about half
+// the VALU count, a DS op 4 LDS cycles of the CU whatever its width.  So the step below is written
 // for few instructions of every kind:
 //   * every pixel emits at most ONE chunk: a repeat pixel carries the run byte of the run it
 //     closes (qoi.h:417-421,425-428 put that byte in front of the next edge's chunk, which is
 //     the same stream position), so chunk length is in {0,1,2,4,5} per lane;
+//   * the previous pixel of every lane is LOADED (a second, 4-byte-shifted request to the lines the
+//     pixels themselves come from, served by the L1) instead of moved across lanes;
 //   * per-lane predicates live as 64-bit lane masks in SGPRs (ballot results); the few mask
 //     combinations are explicit scalar ops and come back as exec / v_cndmask masks through
 //     inverse_ballot;
-//   * work that a step does not need is skipped by wave-uniform branches (no repeats: no run
-//     arithmetic; no edges: no hash/probe/deltas; no literal: no deltas; no 4/5-byte chunk: no
-//     third offset count).
-// Chunk bytes go to a per-wave LDS staging buffer at slab-local offsets; once the slab's byte
-// offset is known the staged bytes are copied out with aligned dword stores.
-template <int K>
+//   * chunk words keep byte 0 in bits 0..7 and byte 1 in bits 16..23 (ds_write_b8 /
+//     ds_write_b8_d16_hi take them from there), the length class in bits 25..26;
+//   * work that a step does not need is skipped by wave-uniform branches (no edges: no
+//     hash/probe/deltas; no 4/5-byte chunk: no third offset count).
+// Chunk bytes go to a per-wave LDS staging buffer; when the set is done its byte offset in the
+// stream is found by decoupled look-back over the earlier sets of the image and the staged bytes
+// are copied out with aligned 16-byte stores.  A set whose bytes do not fit the staging buffer
+// (more than ~1.4 bytes per pixel) spills whole 16-byte pieces to its scratch slot as it goes and
+// moves them to their place itself after the look-back.
+constexpr int kGroupSteps = 8;                          // steps whose pixels are loaded together (one register group)
+constexpr uint32_t kGroupPx = 64u * kGroupSteps;
+constexpr uint32_t kStageBytes = 7424u;                 // staging buffer of a wavefront
+constexpr uint32_t kStageSpill = kStageBytes - kGroupSteps * 320u - 16u;   // more staged bytes than this before a group: spill first
+
+template <int PROBE>
 struct EncLds {
-    static constexpr uint32_t kStageBytes = 64u * K * 5u + 8u;     // <= 5 B/px, + slack
-    static constexpr uint32_t kStageDwords = ((kStageBytes + 15u) / 16u) * 4u;
+    static constexpr uint32_t kStageDwords = kStageBytes / 4u + 8u;
     alignas(256) uint32_t table[64];   // 256-byte aligned: slot address = base | (4*slot)
-    u64 mask[64];                      // PROBE 0 only
     alignas(16) uint32_t stage[kStageDwords];
+    u64 mask[PROBE == 0 ? 64 : 1];     // PROBE 0 only
 };
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -218,31 +223,54 @@ __device__ __forceinline__ uint32_t ffbh(uint32_t v) {
     return r;
 }
 // lane l: v of lane l-1; lane 0: `before` of lane 63 (the previous 64 pixels).  Two DPP moves,
-// no trip through an SGPR.
+// no trip through an SGPR.  (Entry-state replay only; the steps load their previous pixels.)
 __device__ __forceinline__ uint32_t prev_pixels(uint32_t v, uint32_t before) {
     const int first = __builtin_amdgcn_mov_dpp((int)before, 0x13C, 0xf, 0xf, false);              // wave_ror:1 (every lane has a source)
     return (uint32_t)__builtin_amdgcn_update_dpp(first, (int)v, 0x138, 0xf, 0xf, false);          // wave_shr:1, lane 0 keeps `first`
 }
 
-// Byte 0 of every chunk and byte 1 of the 2+-byte chunks of one step into the LDS staging buffer.
-// Runs with all 64 lanes enabled (the slab loop is wave-uniform), so exec is switched with plain
-// moves: 3 scalar + 1 vector op around the two stores.  LDS ops of a wave complete in issue order,
-// so the later (compiler-visible) reads of the staging buffer see these stores.
 // a lane mask the compiler may have lost track of as wave-uniform -> SGPR pair (free when it already is one)
 __device__ __forceinline__ u64 uniform64(u64 m) {
     // (the builtin returns int: without the casts to uint32_t a low half with bit 31 set sign-extends over the high half - the
     // generic path then took 32 slots of the image-level table for group-local ones whenever slot 31 had been written in the group)
     return (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m) | ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32);
 }
+// 64 + number of leading zeros of a non-zero lane mask, on the scalar unit (the result stays in an SGPR)
+__device__ __forceinline__ uint32_t clz64_plus64(u64 m) {
+    uint32_t r;
+    asm("s_flbit_i32_b64 %0, %1\n\ts_or_b32 %0, %0, 64" : "=s"(r) : "s"(m) : "scc");
+    return r;
+}
+// v + 64 on the scalar unit (v is wave-uniform; the readfirstlane is free when the compiler already holds it in an SGPR)
+__device__ __forceinline__ uint32_t scalar_add64(uint32_t v) {
+    uint32_t r;
+    asm("s_add_u32 %0, %1, 64" : "=s"(r) : "s"(__builtin_amdgcn_readfirstlane((int)v)) : "scc");
+    return r;
+}
+// Byte 0 (bits 0..7 of w) of every chunk and byte 1 (bits 16..23) of the 2-byte chunks of one step into the LDS
+// staging buffer.  Runs with all 64 lanes enabled (the step loop is wave-uniform), so exec is switched with plain
+// moves.  LDS ops of a wave complete in issue order, so the later (compiler-visible) reads of the staging buffer
+// see these stores.
 __device__ __forceinline__ void stage_short(uint32_t addr, uint32_t w, u64 any, u64 second) {
-    uint32_t hi;
-    asm volatile("s_mov_b64 exec, %3\n\t"
-                 "ds_write_b8 %1, %2\n\t"
-                 "v_lshrrev_b32 %0, 8, %2\n\t"
-                 "s_mov_b64 exec, %4\n\t"
-                 "ds_write_b8 %1, %0 offset:1\n\t"
+    asm volatile("s_mov_b64 exec, %2\n\t"
+                 "ds_write_b8 %0, %1\n\t"
+                 "s_mov_b64 exec, %3\n\t"
+                 "ds_write_b8_d16_hi %0, %1 offset:1\n\t"
                  "s_mov_b64 exec, -1"
-                 : "=&v"(hi) : "v"(addr), "v"(w), "s"(any), "s"(second) : "memory");
+                 : : "v"(addr), "v"(w), "s"(any), "s"(second) : "memory");
+}
+// bytes 2, 3 (g, b) of the 4/5-byte chunks and byte 4 (a) of the 5-byte chunks (exec switching instead of divergent
+// branches: a divergent branch anywhere in the step makes the compiler restructure its wave-uniform branches as well)
+__device__ __forceinline__ void stage_long_rest(uint32_t addr, uint32_t px, u64 lng, u64 five) {
+    uint32_t t;
+    asm volatile("s_mov_b64 exec, %3\n\t"
+                 "v_lshrrev_b32 %0, 8, %2\n\t"
+                 "ds_write_b8 %1, %0 offset:2\n\t"
+                 "ds_write_b8_d16_hi %1, %2 offset:3\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "ds_write_b8_d16_hi %1, %0 offset:4\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "=&v"(t) : "v"(addr), "v"(px), "s"(lng), "s"(five) : "memory");
 }
 // Colour-table probe of one step (PROBE 1): the edge lanes swap their pixel into their slot and get
 // what the slot held.  Lanes of one instruction that hit the same slot are served in ascending lane
@@ -256,8 +284,37 @@ __device__ __forceinline__ uint32_t probe_swap(uint32_t addr, uint32_t px, u64 e
                  : "=&v"(seen) : "v"(addr), "v"(px), "s"(edges) : "memory");
     return seen;
 }
+// The same with ALL 64 lanes: a repeat pixel (px == prev) swaps the value in that the pixel before it - an
+// edge pixel, or a repeat pixel for which the same holds - has left in that very slot, so its swap changes
+// nothing (no pixel lies between the two) and what it gets back is not looked at.  Two scalar instructions
+// less per step.  Not valid where lanes hold no pixel (beyond the image's end) nor before the image's first
+// edge (repeats of the start value {0,0,0,255} of qoi.h:396-399, which was never written to the table): the
+// GEN form of the step uses probe_swap().
+__device__ __forceinline__ uint32_t probe_swap_all(uint32_t addr, uint32_t px) {
+    uint32_t seen;
+    asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2" : "=&v"(seen) : "v"(addr), "v"(px) : "memory");
+    return seen;
+}
 __device__ __forceinline__ void probe_wait(uint32_t& seen) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(seen) : : "memory"); }
 
+// lanes where byte 3 (alpha) of a and b differ: one compare on the two bytes (SDWA)
+__device__ __forceinline__ u64 alpha_differs(uint32_t a, uint32_t b) {
+    u64 m;
+    asm("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+// w = (seen == px ? idx : we) in the lanes of `edges`, unchanged elsewhere.  Waits for the probe's LDS result first.
+// (The scalar instructions between the compare and the select are also the two wait states gfx950 wants between a VALU
+// write of vcc and a VALU read of it.)
+__device__ __forceinline__ void select_edge_word(uint32_t& w, uint32_t we, uint32_t idx, uint32_t seen, uint32_t px, u64 edges) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "v_cmp_eq_u32 vcc, %3, %4\n\t"
+                 "s_mov_b64 exec, %5\n\t"
+                 "s_nop 0\n\t"
+                 "v_cndmask_b32 %0, %1, %2, vcc\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(w) : "v"(we), "v"(idx), "v"(seen), "v"(px), "s"(edges) : "vcc", "memory");
+}
 // byte k of a minus byte k of b in the low byte of the result (upper bits: don't care)
 __device__ __forceinline__ uint32_t sub_byte1(uint32_t a, uint32_t b) {
     uint32_t r;
@@ -270,88 +327,195 @@ __device__ __forceinline__ uint32_t sub_byte2(uint32_t a, uint32_t b) {
     return r;
 }
 
-// a != b on the scalar unit (hipcc turns a uniform bool -> int into v_cndmask and the masks built from it into VGPRs)
-__device__ __forceinline__ uint32_t scalar_ne(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("s_cmp_lg_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc");
-    return r;
-}
+// chunk word tags (bits 25..26, above the bytes a short chunk stores): length class of the lane
+constexpr uint32_t kLenOne = 0u, kLenTwo = 1u << 25, kLenLong = 1u << 26;   // 1-byte chunks need no tag: nothing tests for them
 
-// chunk word tags (bits 16..18, above the two bytes a short chunk stores): length class of the lane
-constexpr uint32_t kLenOne = 0u, kLenTwo = 1u << 17, kLenLong = 1u << 18;   // 1-byte chunks need no tag: nothing tests for them
-
-// Everything a slab reads from global memory before its first step; fetched one slab ahead so
-// that every wavefront always has a slab's worth of loads in flight (without it the kernel is
-// bound by HBM latency: ~3 TB/s whatever the content).
-template <int K>
-struct SlabIn {
-    uint32_t warm[8];            // ENTRY 1: the 512 pixels before the slab (step k: pixels lo-64(k+1) .. +63), and the one before them
-    uint32_t warm_carry;
-    uint32_t px[K];              // pixel t*64 + lane of the slab
-    uint32_t carry0;             // pixel before the slab (qoi.h:396-399 start value for slab 0)
-    uint32_t next_first;         // first pixel of the next slab
-    uint32_t tab_loc, tab_far;   // entry colour table: group-local part / image-level part (lane = slot)
-    u64 tab_valid;
-    int le_loc, le_far;          // last edge before the slab: group-local / image-level
+// per-lane constants of the step
+struct LaneConst {
+    uint32_t below_lo, below_hi;   // masks of the lanes below this one
+    uint32_t lane_run;             // lane + 128: + clz(edges below) = 0xBF + run length
+    uint32_t tbase;                // LDS address of the colour table (256-byte aligned), kept in a VGPR: slot address = one v_and_or
 };
 
-template <int CH, int K, int ENTRY>
-__device__ __forceinline__ void load_slab(const EncParams& p, uint32_t g, uint32_t lane, SlabIn<K>& in) {
-    const uint32_t img = g / p.spi, s = g - img * p.spi;
-    const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
-    const uint32_t n = p.npx, lo = s * (64u * K);
-    if (ENTRY == 1) {                                        // issued first: they are needed first
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = (int)lo - 64 * (k + 1) + (int)lane;
-            in.warm[k] = i >= 0 ? load_px<CH>(pix, (uint32_t)i) : kInitPx;
+// ---- one step: the chunks of 64 pixels -----------------------------------------------------------
+// px / prev: this lane's pixel and the one before it.  Ec: edge lanes (px != prev) of this step.  nb63: bit 63 set if the
+// pixel after lane 63 is an edge.  GEN only: V valid lanes, lastbit the lane of the image's last pixel.
+// ccp (scalar) = 63 + (first pixel of the step - last edge before the step): stands in for clz(edges below the lane).
+// vbase (same value in every lane): LDS address of the next staged byte.
+template <int PROBE, bool GEN>
+__device__ __forceinline__ void encode_step(EncLds<PROBE>& L, const LaneConst& C, uint32_t lane, uint32_t px, uint32_t prev,
+                                            u64 Ec, u64 nb63, u64 V, u64 lastbit, uint32_t& ccp, uint32_t& vbase) {
+    const u64 En = (Ec >> 1) | nb63 | lastbit;             // lanes whose successor is an edge (or that end the image)
+    const u64 NE = GEN ? (~Ec & V) : ~Ec;                  // repeat pixels
+    u64 RB = NE & En;                                      // repeat pixels that close a run: they carry its run byte
+
+    // ---- repeats: run byte 0xC0|(run-1) on the pixel that closes a run (qoi.h:416-421,425-428) ----
+    // clz of the edges below the lane; ccp stands in when the run began before this step
+    uint32_t w;
+    {
+        const uint32_t fhi = ffbh((uint32_t)(Ec >> 32) & C.below_hi);
+        const uint32_t flo = ffbh((uint32_t)Ec & C.below_lo) | 32u;
+        const uint32_t m = min(min(fhi, flo), ccp);
+        w = m + C.lane_run;                                // 0xBF + count, count = repeats since the last edge
+        if (__ballot(w > 0xFCu) & NE) {                    // some run reaches 62: wave-uniform slow path (flat content)
+            const uint32_t cnt = w - 0xBFu;
+            const uint32_t xm = cnt % 62u;
+            w = xm ? 0xBFu + xm : 0xFDu;                   // a repeat landing on a multiple of 62 closes a full run
+            RB |= NE & __ballot(xm == 0u);
         }
-        const int ci = (int)lo - 64 * 8 - 1;
-        in.warm_carry = ci >= 0 ? load_px<CH>(pix, (uint32_t)ci) : kInitPx;
     }
-    if (lo + 64u * K < n) {                                  // interior slab: no bounds checks
-#pragma unroll
-        for (int t = 0; t < K; ++t) in.px[t] = load_px<CH>(pix, lo + t * 64u + lane);
-        in.next_first = load_px<CH>(pix, lo + 64u * K);
-    } else {
-#pragma unroll
-        for (int t = 0; t < K; ++t) { const uint32_t i = lo + t * 64u + lane; in.px[t] = i < n ? load_px<CH>(pix, i) : 0u; }
-        in.next_first = 0;
+    // (Control flow of the step: plain `if` blocks only, no `else`.  The compiler restructures every if / else into two
+    // consecutive ifs on a flag even where the condition is wave-uniform - five scalar instructions per step.)
+    u64 any = Ec | RB;                                     // lanes that emit a chunk
+    ccp = scalar_add64(ccp);                               // no edge in this step: the last edge is 64 pixels further away
+    if (Ec) {
+        ccp = clz64_plus64(Ec);
+        // ---- colour-table probe/update (qoi.h:430-436) for edge pixels ---------------------
+        const uint32_t hsh = __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);   // 4 * QOI_COLOR_HASH (qoi.h:322)
+        uint32_t seen = ~px;
+        if (PROBE == 1) {
+            seen = GEN ? probe_swap((hsh & 0xFCu) | C.tbase, px, Ec) : probe_swap_all((hsh & 0xFCu) | C.tbase, px);
+        } else {
+            const uint32_t so = hsh & 0xFCu;
+            const bool edge = in_mask(Ec);
+            const u64 lane_bit = 1ull << lane;
+            if (edge) __hip_atomic_fetch_or(&L.mask[so >> 2], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_wave_barrier();
+            const u64 same = edge ? L.mask[so >> 2] : 0ull;    // edge lanes of this step sharing the slot
+            const uint32_t tval = L.table[so >> 2];
+            __builtin_amdgcn_wave_barrier();
+            if (edge) L.mask[so >> 2] = 0;
+            const u64 pred = same & (lane_bit - 1ull);
+            const uint32_t pv = gather_lane(px, pred ? (uint32_t)msb64(pred) : lane);
+            seen = pred ? pv : tval;                           // nearest earlier same-slot edge, else carried table
+            if (edge && ((same >> lane) >> 1) == 0) L.table[so >> 2] = px;   // last lane per slot updates the table
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- chunk of an edge pixel (qoi.h:432-474): INDEX, else RGBA if alpha moved, else DIFF, LUMA, RGB ----
+        // wrapped byte deltas live in the low byte of d*; consumers sign-extend that byte (SDWA)
+        const uint32_t d_r = px - prev, d_g = sub_byte1(px, prev), d_b = sub_byte2(px, prev);
+        const uint32_t tr = (int)(int8_t)d_r + 2, tg = (int)(int8_t)d_g + 2, tb = (int)(int8_t)d_b + 2;
+        const uint32_t tg8 = (int)(int8_t)d_g - 6, ug = (int)(int8_t)d_g + 32;
+        const uint32_t ur = tr - tg8, ub = tb - tg8;       // dr-dg+8, db-dg+8
+        const bool is_diff = (tr | tg | tb) < 4u;
+        const bool is_luma = ((ug >> 2) | ur | ub) < 16u;
+        const u64 m_ad = alpha_differs(px, prev);          // lanes whose alpha differs from the previous pixel's
+        const bool is_ad = in_mask(m_ad);
+        const uint32_t w_diff = (kTagDiff | kLenOne) | (tr << 4) | (tg << 2) | tb;
+        const uint32_t w_luma = (kTagLuma | kLenTwo | ug) | (ur << 20) | (ub << 16);
+        uint32_t we = is_luma ? w_luma : kLenLong;
+        we = is_diff ? w_diff : we;
+        we = is_ad ? kLenLong : we;
+        asm volatile("" : "+v"(we));                       // keep the literal classes branch-free (no sinking under !hit)
+        // QOI_OP_INDEX (qoi.h:432-434) where the slot held the pixel; the edge lanes take their chunk word, the others keep
+        // their run byte (one v_cndmask under exec = edges instead of two)
+        select_edge_word(w, we, (hsh >> 2) & 63u, seen, px, Ec);
+        const u64 lng = __ballot(w >= kLenLong);
+        if (__builtin_expect(lng != 0ull, 0)) {
+            // rare in natural images: some lane carries QOI_OP_RGB / QOI_OP_RGBA (qoi.h:461-474): tag r g b (a)
+            const u64 five = lng & m_ad;
+            const u64 two = __ballot(w >= kLenTwo) & ~lng;
+            const u64 b0 = (any & ~(two | lng)) | five;            // odd lengths: 1-byte chunks and RGBA
+            const uint32_t off = vbase + count_below(b0) + 2u * count_below(two) + 4u * count_below(lng);
+            const bool is_long = in_mask(lng);
+            const uint32_t w0 = is_long ? (in_mask(five) ? kTagRgba : kTagRgb) | (px << 16) : w;   // byte 0: tag, bits 16..23: r
+            stage_short(off, w0, any, two | lng);
+            stage_long_rest(off, px, lng, five);
+            vbase += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(two) + 4u * (uint32_t)__builtin_popcountll(lng);
+            any = 0ull;                                            // nothing left for the tail below
+        }
     }
-    in.carry0 = (lo > 0) ? load_px<CH>(pix, lo - 1) : kInitPx;
-    if (ENTRY == 0) {
-        const uint32_t G = img * p.gpi + (s >> 6);
-        in.tab_loc = p.ent_tab[(size_t)g * 64u + lane];
-        in.tab_far = p.gent_tab[(size_t)G * 64u + lane];
-        in.tab_valid = p.ent_valid[g];
-        in.le_loc = p.ent_le[g];
-        in.le_far = p.gent_le[G];
+    // ---- common case: chunk lengths 1 and 2 only.  offset = #chunks below + #LUMA chunks below ----
+    {
+        const u64 two = __ballot(w >= kLenTwo) & any;
+        const uint32_t off = count_below_from(two, count_below_from(any, vbase));
+        stage_short(off, w, any, two);
+        vbase += (uint32_t)__builtin_popcountll(any) + (uint32_t)__builtin_popcountll(two);
     }
 }
 
-// ENTRY 1: a slab finds its entry state itself.  The colour table before pixel `lo` is "the last edge pixel
-// per hash slot" (qoi.h:430-436), so the wavefront walks BACKWARDS over the pixels before its slab, 64 at a
+// lanes 0..r-1 (r <= 0: none, r >= 64: all)
+__device__ __forceinline__ u64 lanes_upto(int r) { return r >= 64 ? ~0ull : (r <= 0 ? 0ull : (1ull << r) - 1ull); }
+
+// ---- a group of kGroupSteps steps whose pixels (px) and previous pixels (pv) sit in registers ----------
+// E: edges of the group's first step on entry, of the first step AFTER the group on exit (from nx_px / nx_pv: the first
+// step of the next group, or the two pixels around the end of the set).  GEN: rem = pixels of the image left at the
+// group's first pixel.
+template <int PROBE, bool GEN>
+__device__ __forceinline__ void process_group(EncLds<PROBE>& L, const LaneConst& C, uint32_t lane,
+                                              const uint32_t (&px)[kGroupSteps], const uint32_t (&pv)[kGroupSteps],
+                                              uint32_t nx_px, uint32_t nx_pv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase) {
+    if (GEN) E &= lanes_upto(rem);                         // (the group before this one does not know where the image ends)
+#pragma unroll
+    for (int t = 0; t < kGroupSteps; ++t) {
+        const u64 Ec = E;
+        u64 V = ~0ull, lastbit = 0ull;
+        if (GEN) {
+            const int r = rem - t * 64;                    // pixels of the image left at this step
+            V = lanes_upto(r);
+            lastbit = (r >= 1 && r <= 64) ? 1ull << (r - 1) : 0ull;
+        }
+        // edges of the next step (its lane 0 tells lane 63 whether its run ends here)
+        if (t + 1 < kGroupSteps) E = __ballot(px[t + 1] != pv[t + 1]);
+        else E = __ballot(nx_px != nx_pv);
+        if (GEN) E &= lanes_upto(rem - (t + 1) * 64);
+        const u64 nb63 = E << 63;
+        if (GEN && V == 0ull) continue;
+        encode_step<PROBE, GEN>(L, C, lane, px[t], pv[t], Ec, nb63, V, lastbit, ccp, vbase);
+    }
+}
+
+// pixels base + 64 t + lane and the pixels before them, t = 0..kGroupSteps-1, of a group that lies inside the image and
+// does not hold its first pixel: no bounds checks, one 64-bit address, the 16 loads differ in their immediate offsets only
+template <int CH>
+__device__ __forceinline__ void load_group(const uint8_t* __restrict__ pix, uint32_t base, uint32_t lane,
+                                           uint32_t (&px)[kGroupSteps], uint32_t (&pv)[kGroupSteps]) {
+    const uint8_t* __restrict__ q = pix + (size_t)(base + lane) * (size_t)CH;
+#pragma unroll
+    for (int t = 0; t < kGroupSteps; ++t) {
+        px[t] = load_px_at<CH>(q, t * 64);
+        pv[t] = load_px_at<CH>(q, t * 64 - 1);
+    }
+}
+// pixel i and the one before it, any i: lanes beyond the image's last pixel get 0, the pixel before the image's first one is
+// the start value of qoi.h:396-399
+template <int CH>
+__device__ __forceinline__ void load_pair_guarded(const uint8_t* __restrict__ pix, uint32_t i, uint32_t n, uint32_t& px, uint32_t& pv) {
+    px = i < n ? load_px<CH>(pix, i) : 0u;
+    pv = (i < n && i > 0u) ? load_px<CH>(pix, i - 1u) : kInitPx;
+}
+
+// Everything a set reads from global memory before its first step besides its first group of pixels.
+struct SetIn {
+    uint32_t warm[8];            // ENTRY 1: the 512 pixels before the set (step k: pixels lo-64(k+1) .. +63), and the one before them
+    uint32_t warm_carry;
+    uint32_t tab_loc, tab_far;   // ENTRY 0: entry colour table: group-local part / image-level part (lane = slot)
+    u64 tab_valid;
+    int le_loc, le_far;          // ENTRY 0: last edge before the set: group-local / image-level
+};
+
+// ENTRY 1: a set finds its entry state itself.  The colour table before pixel `lo` is "the last edge pixel
+// per hash slot" (qoi.h:430-436), so the wavefront walks BACKWARDS over the pixels before its set, 64 at a
 // time, and fills every slot that is still empty with the latest edge pixel that hashes there, until all 64
 // slots are known or the image start is reached (untouched slots are then the zeroes of qoi.h:393).  Natural
 // images and noise need 5-8 steps (SURVEY: all 64 slots are rewritten within ~700 pixels); flat content does
-// not finish within the window - the slab then flags its image and the generic passes (per-slab summaries +
+// not finish within the window - the set then flags its image and the generic passes (per-slab summaries +
 // scans, ENTRY 0) redo that image.  Unfilled slots hold slot+1, a value that cannot hash to its own slot
 // (3(s+1) != s mod 64).  Returns false if the window did not suffice.
 constexpr int kWarmSteps = 128;      // look-back window: 8192 pixels (natural content is done after 5-11 steps)
 constexpr int kWarmBatch = 8;        // 64-pixel steps loaded together
 constexpr int kWarmMinFilled = 48;   // slots that must be known after the first batch (512 pixels), else the content is flat: give up
 
-template <int CH, int K>
-__device__ __forceinline__ bool warm_entry_state(const EncParams& p, uint32_t img, uint32_t lo, uint32_t lane,
-                                                 EncLds<K>& L, uint32_t tbase, const SlabIn<K>& in, int& last_edge) {
+template <int CH, int PROBE>
+__device__ __forceinline__ bool warm_entry_state(const uint8_t* __restrict__ pix, uint32_t lo, uint32_t lane,
+                                                 EncLds<PROBE>& L, uint32_t tbase, const SetIn& in, int& last_edge) {
     last_edge = -1;
     if (lo == 0u) { L.table[lane] = 0u; return true; }       // qoi.h:393: zeroed table, no edge yet
-    const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
     const uint32_t sent = lane + 1u;
     L.table[lane] = sent;
     __builtin_amdgcn_wave_barrier();
-    // ---- the 512 pixels right before the slab, oldest first: later edge pixels simply overwrite earlier ones
-    //      (these loads were issued ahead of the slab's own pixels) ------------------------------------------
+    // ---- the 512 pixels right before the set, oldest first: later edge pixels simply overwrite earlier ones
+    //      (these loads were issued ahead of the set's own pixels) ------------------------------------------
     {
         const uint32_t carry = __builtin_amdgcn_readfirstlane(in.warm_carry);
 #pragma unroll
@@ -408,22 +572,113 @@ __device__ __forceinline__ bool warm_entry_state(const EncParams& p, uint32_t im
     return full && (last_edge >= 0 || at_start);
 }
 
-template <int CH, int K, int PROBE, bool LAST, int ABL, int ENTRY>
-__device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, uint32_t lane, EncLds<K>& L, const SlabIn<K>& in) {
-    const uint32_t img = g / p.spi, s = g - img * p.spi;
-    const uint32_t n = p.npx, lo = s * (64u * K);
-    uint8_t* stage8 = reinterpret_cast<uint8_t*>(L.stage);
-    const uint32_t* cur = in.px;
-    // same value in every lane, but loaded into VGPRs: make them provably wave-uniform
-    const uint32_t carry0 = __builtin_amdgcn_readfirstlane(in.carry0);
-    const uint32_t next_first = __builtin_amdgcn_readfirstlane(in.next_first);
+// n bytes from a 16-byte aligned source in global memory to dst (any alignment): head up to the first 16-byte boundary byte by
+// byte, aligned 16-byte stores (source re-aligned with v_alignbyte), tail byte by byte.  One wavefront.
+__device__ __forceinline__ void copy_global_out(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t n, uint32_t lane) {
+    const uint32_t mis = (uint32_t)(uintptr_t)dst & 15u;
+    const uint32_t head = min(n, (16u - mis) & 15u);                 // bytes before dst becomes 16-byte aligned
+    if (lane < head) dst[lane] = src[lane];
+    const uint32_t n16 = (n - head) >> 4;
+    uint4* __restrict__ d16 = reinterpret_cast<uint4*>(dst + head);
+    const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(src) + (head >> 2);
+    const uint32_t sh = head & 3u;
+    for (uint32_t j = lane; j < n16; j += 64u) {
+        const uint32_t* q = s32 + 4u * j;
+        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+        uint4 v;
+        v.x = __builtin_amdgcn_alignbyte(w1, w0, sh); v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        v.z = __builtin_amdgcn_alignbyte(w3, w2, sh); v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+        d16[j] = v;
+    }
+    const uint32_t done = head + (n16 << 4);
+    if (lane < n - done) dst[done + lane] = src[done + lane];
+}
+// the same from the wavefront's LDS staging buffer (n <= kStageBytes)
+__device__ __forceinline__ void copy_stage_out(const uint32_t* stage, uint8_t* __restrict__ dst, uint32_t n, uint32_t lane) {
+    const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
+    const uint32_t mis = (uint32_t)(uintptr_t)dst & 15u;
+    const uint32_t head = min(n, (16u - mis) & 15u);
+    if (lane < head) dst[lane] = stage8[lane];
+    const uint32_t n16 = (n - head) >> 4;
+    uint4* d16 = reinterpret_cast<uint4*>(dst + head);
+    const uint32_t sh = head & 3u;
+    for (uint32_t j = lane; j < n16; j += 64u) {
+        const uint32_t* q = &stage[(head >> 2) + 4u * j];
+        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+        uint4 v;
+        v.x = __builtin_amdgcn_alignbyte(w1, w0, sh); v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        v.z = __builtin_amdgcn_alignbyte(w3, w2, sh); v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+        d16[j] = v;
+    }
+    const uint32_t done_b = head + (n16 << 4);
+    if (lane < n - done_b) dst[done_b + lane] = stage8[done_b + lane];
+}
+
+// Moves the staged bytes [0, spos) to the set's scratch slot behind the `spilled` bytes already there (a multiple of 16).
+// all = false: whole 16-byte pieces only, the remainder moves to the front of the staging buffer.  Returns the bytes left staged.
+template <int PROBE>
+__device__ __forceinline__ uint32_t spill_stage(EncLds<PROBE>& L, uint8_t* __restrict__ slot, uint32_t& spilled, uint32_t spos, bool all, uint32_t lane) {
+    const uint32_t n16 = all ? (spos + 15u) >> 4 : spos >> 4;
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(slot + spilled);
+    const uint4* src = reinterpret_cast<const uint4*>(L.stage);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < n16; j += 64u) dst[j] = src[j];
+    spilled += n16 << 4;
+    if (all) return 0u;
+    const uint32_t keep = lane < 4u ? L.stage[(n16 << 2) + lane] : 0u;     // the incomplete piece (LDS ops of a wavefront run in order)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 4u) L.stage[lane] = keep;
+    __builtin_amdgcn_wave_barrier();
+    return spos & 15u;
+}
+
+template <int CH, int PROBE, int ENTRY>
+__device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, EncLds<PROBE>& L) {
+    const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
+    const uint32_t n = p.npx;
+    const uint32_t lo = set * p.set_px;                        // first pixel of the set (a slab boundary)
+    const uint32_t hi = min(n, lo + p.set_px);                 // one past its last pixel
+    const bool last_set = hi == n;
+    const uint32_t ngroups = (hi - lo + kGroupPx - 1u) / kGroupPx;
+    const size_t sg = (size_t)img * p.sets_per_image + set;    // global index of the set
+
+    // ---- loads: what the entry state needs first, then the first group of pixels ------------------------------
+    SetIn in;
+    if (ENTRY == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = (int)lo - 64 * (k + 1) + (int)lane;
+            in.warm[k] = i >= 0 ? load_px<CH>(pix, (uint32_t)i) : kInitPx;
+        }
+        const int ci = (int)lo - 64 * 8 - 1;
+        in.warm_carry = ci >= 0 ? load_px<CH>(pix, (uint32_t)ci) : kInitPx;
+    } else {
+        const uint32_t s = set * p.set_slabs;                  // first slab of the set: its entry state is the set's
+        const size_t g = (size_t)img * p.spi + s;
+        const size_t G = (size_t)img * p.gpi + (s >> 6);
+        in.tab_loc = p.ent_tab[g * 64u + lane];
+        in.tab_far = p.gent_tab[G * 64u + lane];
+        in.tab_valid = p.ent_valid[g];
+        in.le_loc = p.ent_le[g];
+        in.le_far = p.gent_le[G];
+    }
+    // The pipelined loop below handles the groups that lie inside the image (all 64 lanes of every step valid, the probe may
+    // run with all lanes); the image's first set and the group that holds the image's last pixel take the general form after it.
+    const bool gen_set = lo == 0u;
+    const uint32_t nint = gen_set ? 0u : (last_set ? ngroups - 1u : ngroups);
+    uint32_t ax[kGroupSteps], av[kGroupSteps], bx[kGroupSteps], bv[kGroupSteps];
+    if (nint) load_group<CH>(pix, lo, lane, ax, av);
 
     // ---- entry state: colour table + distance to the last edge ---------------------------
+    LaneConst C;
+    C.below_lo = lane < 32u ? (1u << lane) - 1u : 0xFFFFFFFFu;
+    C.below_hi = lane < 32u ? 0u : (1u << (lane - 32u)) - 1u;
+    C.lane_run = lane + 128u;
+    C.tbase = lds_addr(L.table);                               // 256-byte aligned
+    asm volatile("" : "+v"(C.tbase));                          // keep in a VGPR
     int last_edge;
     if (ENTRY == 1) {
-        uint32_t tb = lds_addr(L.table);
-        asm volatile("" : "+v"(tb));
-        if (!warm_entry_state<CH, K>(p, img, lo, lane, L, tb, in, last_edge)) {
+        if (!warm_entry_state<CH, PROBE>(pix, lo, lane, L, C.tbase, in, last_edge)) {
             if (lane == 0) { atomicOr(&p.need_generic[img], 1u); atomicOr(p.any_generic, 1u); }
             return;
         }
@@ -433,168 +688,82 @@ __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, 
         last_edge = max(__builtin_amdgcn_readfirstlane(in.le_loc), __builtin_amdgcn_readfirstlane(in.le_far));   // max edge position < lo, or -1
     }
     if (PROBE == 0) L.mask[lane] = 0;
-    // ccp = 63 + (first pixel of the step - last edge before the step): stands in for clz(edges below the lane)
-    uint32_t ccp = 63u + (uint32_t)((int)lo - last_edge);
+    uint32_t ccp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(63u + (uint32_t)((int)lo - last_edge)));
     __builtin_amdgcn_wave_barrier();
 
-    // lane constants
-    const uint32_t below_lo = lane < 32u ? (1u << lane) - 1u : 0xFFFFFFFFu;
-    const uint32_t below_hi = lane < 32u ? 0u : (1u << (lane - 32u)) - 1u;
-    const uint32_t lane_run = lane + 128u + kLenOne;       // + clz(edges below) = 0xBF + run length, tagged 1-byte
-    uint32_t tbase = lds_addr(L.table);                    // 256-byte aligned
-    asm volatile("" : "+v"(tbase));                        // keep in a VGPR: slot address = one v_and_or
     const uint32_t sbase = lds_addr(L.stage);
+    uint32_t vbase = sbase;                                    // LDS address of the next staged byte (same in every lane)
+    uint32_t spilled = 0;                                      // bytes of the set already moved to its scratch slot
+    uint8_t* __restrict__ slot = p.scratch + sg * p.set_stride;
 
-    uint32_t spos = 0;                                     // bytes staged so far (wave-uniform)
-    // edges of step 0
-    uint32_t prev_n = from_lane_below(cur[0], carry0);
-    u64 E = __ballot(cur[0] != prev_n);
-    if (LAST) { const uint32_t r = n - lo; if (r < 64u) E &= (1ull << r) - 1ull; }
-#pragma unroll
-    for (int t = 0; t < K; ++t) {
-        const uint32_t px = cur[t];
-        const uint32_t prev = prev_n;
-        const u64 Ec = E;
-        // ---- lane masks of this step -------------------------------------------------------
-        u64 V = ~0ull, lastbit = 0ull;                     // LAST: valid lanes, lane of the image's last pixel
-        if (LAST) {
-            const int r = (int)(n - lo) - t * 64;         // pixels of the image left at this step
-            V = r >= 64 ? ~0ull : (r <= 0 ? 0ull : (1ull << r) - 1ull);
-            lastbit = (r >= 1 && r <= 64) ? 1ull << (r - 1) : 0ull;
-        }
-        // edges of the next step (its lane 0 tells lane 63 whether its run ends here)
-        u64 nb;
-        if (t + 1 < K) {
-            prev_n = prev_pixels(cur[t + 1], px);
-            E = __ballot(cur[t + 1] != prev_n);
-            if (LAST) { const int r = (int)(n - lo) - (t + 1) * 64; E &= r >= 64 ? ~0ull : (r <= 0 ? 0ull : (1ull << r) - 1ull); }
-            nb = E & 1ull;
-        } else {
-            nb = LAST ? 0ull : (u64)scalar_ne(next_first, read_lane(px, 63));    // 1: the next slab starts with an edge
-        }
-        if (LAST && V == 0ull) continue;
-        const u64 En = (Ec >> 1) | (nb << 63) | lastbit;  // lanes whose successor is an edge (or that end the image)
-        const u64 NE = ~Ec & V;                            // repeat pixels
-        u64 RB = NE & En;                                  // repeat pixels that close a run: they carry its run byte
-
-        // ---- repeats: run byte 0xC0|(run-1) on the pixel that closes a run (qoi.h:416-421,425-428) ----
-        // clz of the edges below the lane; ccp stands in when the run began before this step
-        uint32_t w;
-        {
-            const uint32_t fhi = ffbh((uint32_t)(Ec >> 32) & below_hi);
-            const uint32_t flo = ffbh((uint32_t)Ec & below_lo) | 32u;
-            const uint32_t m = min(min(fhi, flo), ccp);
-            w = m + lane_run;                              // 0xBF + count (tagged), count = repeats since the last edge
-            if (__ballot(w > (0xFCu | kLenOne)) & NE) {    // some run reaches 62: wave-uniform slow path (flat content)
-                const uint32_t cnt = w - (0xBFu | kLenOne);
-                const uint32_t xm = cnt % 62u;
-                w = (xm ? 0xBFu + xm : 0xFDu) | kLenOne;   // a repeat landing on a multiple of 62 closes a full run
-                RB |= NE & __ballot(xm == 0u);
+    uint32_t g = 0;
+    if (nint) {
+        u64 E = __ballot(ax[0] != av[0]);
+        // ---- two groups per turn: while one is encoded the loads of the next are in flight ----------------------------
+        // (the pair loaded when no group follows inside the loop: the two pixels around the end of the set, or around the
+        // start of the image's last group - every lane reads the same two, only "is the next pixel an edge" is taken from them)
+#pragma unroll 1
+        for (;;) {
+            {   // group g sits in a*; fetch g+1 into b*
+                const uint32_t base = lo + g * kGroupPx;
+                const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
+                if (spos > kStageSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+                if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, bx, bv);
+                else { bx[0] = load_px<CH>(pix, base + kGroupPx); bv[0] = load_px<CH>(pix, base + kGroupPx - 1u); }
+                process_group<PROBE, false>(L, C, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
+                if (++g >= nint) break;
+            }
+            {   // group g sits in b*; fetch g+1 into a*
+                const uint32_t base = lo + g * kGroupPx;
+                const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
+                if (spos > kStageSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+                if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, ax, av);
+                else { ax[0] = load_px<CH>(pix, base + kGroupPx); av[0] = load_px<CH>(pix, base + kGroupPx - 1u); }
+                process_group<PROBE, false>(L, C, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
+                if (++g >= nint) break;
             }
         }
-        const u64 any = Ec | RB;                           // lanes that emit a chunk
-        if (Ec) {
-            ccp = (uint32_t)__builtin_clzll(Ec) + 64u;
-            // ---- colour-table probe/update (qoi.h:430-436) for edge pixels ---------------------
-            const uint32_t hsh = __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);   // 4 * QOI_COLOR_HASH (qoi.h:322)
-            uint32_t seen = ~px;
-            if (!(ABL & 4)) {
-                if (PROBE == 1) {
-                    seen = probe_swap((hsh & 0xFCu) | tbase, px, Ec);
-                } else {
-                    const uint32_t so = hsh & 0xFCu;
-                    const bool edge = in_mask(Ec);
-                    const u64 lane_bit = 1ull << lane;
-                    if (edge) __hip_atomic_fetch_or(&L.mask[so >> 2], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __builtin_amdgcn_wave_barrier();
-                    const u64 same = edge ? L.mask[so >> 2] : 0ull;    // edge lanes of this step sharing the slot
-                    const uint32_t tval = L.table[so >> 2];
-                    __builtin_amdgcn_wave_barrier();
-                    if (edge) L.mask[so >> 2] = 0;
-                    const u64 pred = same & (lane_bit - 1ull);
-                    const uint32_t pv = gather_lane(px, pred ? (uint32_t)msb64(pred) : lane);
-                    seen = pred ? pv : tval;                           // nearest earlier same-slot edge, else carried table
-                    if (edge && ((same >> lane) >> 1) == 0) L.table[so >> 2] = px;   // last lane per slot updates the table
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            // ---- chunk of an edge pixel (qoi.h:432-474): INDEX, else RGBA if alpha moved, else DIFF, LUMA, RGB ----
-            // wrapped byte deltas live in the low byte of d*; consumers sign-extend that byte (SDWA)
-            const uint32_t d_r = px - prev, d_g = sub_byte1(px, prev), d_b = sub_byte2(px, prev);
-            const uint32_t tr = (int)(int8_t)d_r + 2, tg = (int)(int8_t)d_g + 2, tb = (int)(int8_t)d_b + 2;
-            const uint32_t tg8 = (int)(int8_t)d_g - 6, ug = (int)(int8_t)d_g + 32;
-            const uint32_t ur = tr - tg8, ub = tb - tg8;   // dr-dg+8, db-dg+8
-            const bool is_diff = (tr | tg | tb) < 4u;
-            const bool is_luma = ((ug >> 2) | ur | ub) < 16u;
-            const bool is_ad = (px ^ prev) > 0x00FFFFFFu;  // alpha differs
-            const uint32_t w_diff = (kTagDiff | kLenOne) | (tr << 4) | (tg << 2) | tb;
-            const uint32_t w_luma = (kTagLuma | kLenTwo | ug) | (ur << 12) | (ub << 8);
-            uint32_t we = is_luma ? w_luma : kLenLong;
-            we = is_diff ? w_diff : we;
-            we = is_ad ? kLenLong : we;
-            asm volatile("" : "+v"(we));                   // keep the literal classes branch-free (no sinking under !hit)
-            if (PROBE == 1 && !(ABL & 4)) probe_wait(seen);
-            const bool is_hit = seen == px;
-            we = is_hit ? (((hsh >> 2) & 63u) | kLenOne) : we;         // QOI_OP_INDEX (qoi.h:432-434)
-            w = in_mask(Ec) ? we : w;
-            const u64 lng = __ballot(w >= kLenLong);
-            if (__builtin_expect(lng != 0ull, 0)) {
-                // rare in natural images: some lane carries QOI_OP_RGB / QOI_OP_RGBA (qoi.h:461-474)
-                const u64 five = lng & __ballot(is_ad);
-                const u64 two = __ballot(w >= kLenTwo) & ~lng;
-                const u64 b0 = (any & ~(two | lng)) | five;            // odd lengths: 1-byte chunks and RGBA
-                const uint32_t w_long = (px << 8) | (in_mask(five) ? kTagRgba : kTagRgb);   // tag r g b (a follows for RGBA)
-                w = in_mask(lng) ? w_long : w;
-                const uint32_t off = sbase + spos + count_below(b0) + 2u * count_below(two) + 4u * count_below(lng);
-                spos += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(two) + 4u * (uint32_t)__builtin_popcountll(lng);
-                if (!(ABL & 1)) {
-                    stage_short(off, w, any, two | lng);
-                    lds_u8* dst = (lds_u8*)off;
-                    if (in_mask(lng)) { dst[2] = (uint8_t)(w >> 16); dst[3] = (uint8_t)(w >> 24); }
-                    if (in_mask(five)) dst[4] = (uint8_t)(px >> 24);
-                }
-                continue;
-            }
-        } else {
-            ccp += 64u;
-        }
-        // ---- common case: chunk lengths 1 and 2 only.  offset = #chunks below + #LUMA chunks below ----
-        const u64 two = __ballot(w >= kLenTwo) & any;
-        const uint32_t off = count_below_from(two, count_below_from(any, sbase + spos));
-        spos += (uint32_t)__builtin_popcountll(any) + (uint32_t)__builtin_popcountll(two);
-        if (!(ABL & 1)) stage_short(off, w, any, two);
     }
-    const uint32_t slab_pos = spos;
+    // ---- general form, group by group (no loads in flight across groups: one set per image, and one group more) -----------
+#pragma unroll 1
+    for (; g < ngroups; ++g) {
+        const uint32_t base = lo + g * kGroupPx;
+        const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
+        if (spos > kStageSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+        uint32_t nxp, nxv;
+#pragma unroll
+        for (int t = 0; t < kGroupSteps; ++t) load_pair_guarded<CH>(pix, base + t * 64u + lane, n, ax[t], av[t]);
+        load_pair_guarded<CH>(pix, base + kGroupPx + lane, n, nxp, nxv);
+        u64 E = __ballot(ax[0] != av[0]);
+        process_group<PROBE, true>(L, C, lane, ax, av, nxp, nxv, (int)(n - base), E, ccp, vbase);
+    }
+    uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
+    const uint32_t set_bytes = spilled + spos;
 
-    const uint32_t slab_bytes = slab_pos;
-    if (p.scratch) {
-        // ---- order-free mode: park the slab's bytes in its scratch slot, E4 compacts ------------
-        if (lane == 0) p.slab_size[g] = slab_bytes;
-        __builtin_amdgcn_wave_barrier();
-        uint4* dst = reinterpret_cast<uint4*>(p.scratch + (size_t)g * kEncScratchStride);
-        const uint4* src = reinterpret_cast<const uint4*>(L.stage);
-        const uint32_t n16 = (slab_bytes + 15u) >> 4;
-        for (uint32_t j = lane; j < n16; j += 64u) dst[j] = src[j];
+    if (!p.lookback) {
+        // ---- order-free mode: park the set's bytes in its scratch slot, E4 (enc_offsets + enc_compact) places them ----
+        (void)spill_stage<PROBE>(L, slot, spilled, spos, true, lane);
+        if (lane == 0) p.set_size[sg] = set_bytes;
         return;
     }
 
-    // ---- slab byte count -> offset: decoupled look-back over earlier slabs -----------------
+    // ---- set byte count -> offset: decoupled look-back over the earlier sets of the image -----------------
     u64 excl = 0;
-    if (!(ABL & 2)) {
+    {
         constexpr u64 kAgg = 1ull << 62, kIncl = 2ull << 62, kVal = (1ull << 62) - 1ull;
         u64* st = p.status;
-        if (s == 0) {
-            if (lane == 0) granule_store(&st[g], kIncl | slab_bytes);
+        if (set == 0) {
+            if (lane == 0) granule_store(&st[sg], kIncl | set_bytes);
         } else {
-            if (lane == 0) granule_store(&st[g], kAgg | slab_bytes);
-            const uint32_t first = g - s;                 // global id of this image's slab 0
-            int64_t look = (int64_t)g - 1;                // newest slab of the current window
+            if (lane == 0) granule_store(&st[sg], kAgg | set_bytes);
+            const int64_t first = (int64_t)(sg - set);        // global id of this image's set 0
+            int64_t look = (int64_t)sg - 1;                   // newest set of the current window
             uint32_t spins = 0;
             bool done = false;
             while (!done) {
                 const int64_t mine = look - (int64_t)lane;
-                const bool inwin = mine >= (int64_t)first;
-                u64 v = inwin ? granule_load(&st[mine]) : kIncl;   // before slab 0: inclusive prefix 0
+                const bool inwin = mine >= first;
+                u64 v = inwin ? granule_load(&st[mine]) : kIncl;   // before set 0: inclusive prefix 0
                 const u64 notready = __ballot((v >> 62) == 0);
                 const u64 incl = __ballot((v >> 62) == 2);
                 const int stop = incl ? __builtin_ctzll(incl) : 64;       // nearest inclusive record
@@ -603,118 +772,99 @@ __device__ __forceinline__ void encode_one_slab(const EncParams& p, uint32_t g, 
                     // (first pass: a predecessor that gave the image up never publishes - the image is encoded again anyway)
                     if (ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
                     if (++spins > (1u << 22)) { if (lane == 0) atomicOr(p.err, 1u); break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(2);
                     continue;
                 }
                 const u64 part = wave_sum64_upto(v & kVal, lane, stop);
                 excl += part;
                 if (incl) done = true; else look -= 64;
             }
-            if (lane == 0) granule_store(&st[g], kIncl | (excl + slab_bytes));
+            if (lane == 0) granule_store(&st[sg], kIncl | (excl + set_bytes));
         }
     }
 
-    // ---- copy the staged bytes out ---------------------------------------------------------
+    // ---- copy the set's bytes out ----------------------------------------------------------
     uint8_t* __restrict__ out = p.out + (size_t)img * p.out_stride;
-    if (s == 0 && lane < (uint32_t)kHeaderBytes) {        // 14-byte header (qoi.h:384-388)
+    if (set == 0 && lane < (uint32_t)kHeaderBytes) {        // 14-byte header (qoi.h:384-388)
         const uint32_t w = p.width, h = p.height;
         const u64 hdr_lo = 0x66696F71ull | ((u64)__builtin_bswap32(w) << 32);             // "qoif", width BE
         const u64 hdr_hi = (u64)__builtin_bswap32(h) | ((u64)p.channels << 32) | ((u64)p.colorspace << 40);
         out[lane] = (uint8_t)((lane < 8u ? hdr_lo : hdr_hi) >> (8u * (lane & 7u)));
     }
     const u64 pos = (u64)kHeaderBytes + excl;
-    if (!(ABL & 1) && slab_bytes) {
-        __builtin_amdgcn_wave_barrier();
-        // head up to the first 16-byte boundary byte by byte, aligned 16-byte stores (source re-aligned with v_alignbyte: the
-        // staged bytes sit `head` past a dword boundary), tail byte by byte - as enc_compact does from the scratch slot
-        uint8_t* dst = out + pos;
-        const uint32_t mis = (uint32_t)(uintptr_t)dst & 15u;
-        const uint32_t head = min(slab_bytes, (16u - mis) & 15u);
-        if (lane < head) dst[lane] = stage8[lane];
-        const uint32_t n16 = (slab_bytes - head) >> 4;
-        uint4* d16 = reinterpret_cast<uint4*>(dst + head);
-        const uint32_t sh = head & 3u;
-        for (uint32_t j = lane; j < n16; j += 64u) {
-            const uint32_t* q = &L.stage[(head >> 2) + 4u * j];
-            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
-            uint4 v;
-            v.x = __builtin_amdgcn_alignbyte(w1, w0, sh); v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            v.z = __builtin_amdgcn_alignbyte(w3, w2, sh); v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
-            d16[j] = v;
-        }
-        const uint32_t done_b = head + (n16 << 4);
-        if (lane < slab_bytes - done_b) dst[done_b + lane] = stage8[done_b + lane];
+    if (spilled) {                                          // the part that went through the scratch slot: by this wavefront, from this CU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        copy_global_out(slot, out + pos, spilled, lane);
     }
-    if (LAST) {                                           // trailer (qoi.h:339,480-482) + *out_len
-        const u64 end = pos + slab_bytes;
+    if (spos) {
+        __builtin_amdgcn_wave_barrier();
+        copy_stage_out(L.stage, out + pos + spilled, spos, lane);
+    }
+    if (last_set) {                                         // trailer (qoi.h:339,480-482) + *out_len
+        const u64 end = pos + set_bytes;
         if (lane < (uint32_t)kTrailerBytes) out[end + lane] = (lane == 7u) ? 1 : 0;
         if (lane == 0) p.out_len[img] = (int)(end + kTrailerBytes);
     }
 }
 
-// ENTRY 0: entry state from the per-slab summaries + scans (E1/E2).  ENTRY 1: each slab finds it itself
-// (warm_entry_state); slabs whose look-back window does not suffice flag their image, and the launcher runs
+// ENTRY 0: entry state from the per-slab summaries + scans (E1/E2).  ENTRY 1: each set finds it itself
+// (warm_entry_state); sets whose look-back window does not suffice flag their image, and the launcher runs
 // the ENTRY 0 passes with only_flagged set: small grid-stride grids that return at once when nothing was
-// flagged.  A workgroup serves unit u = (image u % n_images, group u / n_images) so that the slabs in flight
-// spread over all images.
-template <int CH, int K, int PROBE, int ABL, int ENTRY>
-__global__ __launch_bounds__(256, 6) void enc_slabs(EncParams p) {
-    __shared__ EncLds<K> s_lds[4];
-    __shared__ uint32_t s_ticket;
+// flagged.  A workgroup serves unit u = (image u % n_images, four consecutive sets u / n_images) so that the
+// sets in flight spread over all images.
+template <int CH, int PROBE, int ENTRY>
+__global__ __launch_bounds__(256, 5) void enc_sets(EncParams p) {
+    __shared__ EncLds<PROBE> s_lds[4];
+    __shared__ uint32_t s_ticket[2];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
+    uint32_t turn = 0;
 #pragma unroll 1
-    for (uint32_t unit = blockIdx.x; unit < p.n_units; unit += gridDim.x) {
+    for (uint32_t unit = blockIdx.x; unit < p.n_units; unit += gridDim.x, turn ^= 1u) {
         const uint32_t img = unit % p.n_images;
-        uint32_t quad = unit / p.n_images;                 // order-free (scratch) mode: any order will do
+        uint32_t quad = unit / p.n_images;                 // order-free mode: any order will do
         if (p.only_flagged && p.need_generic[img] == 0u) continue;
-        if (p.use_ticket && !p.scratch) {
-            // look-back mode (one unit per workgroup): groups are handed out by the image's ticket counter, i.e. in
+        if (p.use_ticket && p.lookback) {
+            // look-back mode: the four-set units of an image are handed out by the image's ticket counter, i.e. in
             // START order, hence every predecessor a look-back can wait on is already running or finished (no
             // reliance on dispatch order; guide G16).  One counter per image keeps the atomics off a single hot word.
-            if (threadIdx.x == 0) s_ticket = atomicAdd(&p.ticket[img], 1u);
+            // (s_ticket alternates between two words: a wavefront may still read the one of the previous turn.)
+            if (threadIdx.x == 0) s_ticket[turn] = atomicAdd(&p.ticket[img], 1u);
             __syncthreads();
-            quad = __builtin_amdgcn_readfirstlane(s_ticket);
+            quad = __builtin_amdgcn_readfirstlane(s_ticket[turn]);
         }
-        uint32_t s_pos = quad * p.quads_per_wg * 4u + wave;
-#pragma unroll 1
-        for (uint32_t r = 0; r < p.quads_per_wg && s_pos < p.spi; ++r, s_pos += 4u) {
-            const uint32_t g = img * p.spi + s_pos;
-            if (ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // image already sent to the generic path
-            SlabIn<K> in;
-            load_slab<CH, K, ENTRY>(p, g, lane, in);
-            if (s_pos == p.spi - 1u) encode_one_slab<CH, K, PROBE, true, ABL, ENTRY>(p, g, lane, s_lds[wave], in);
-            else encode_one_slab<CH, K, PROBE, false, ABL, ENTRY>(p, g, lane, s_lds[wave], in);
-            __builtin_amdgcn_wave_barrier();
-        }
+        const uint32_t set = quad * 4u + wave;
+        if (set < p.sets_per_image &&
+            !(ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))   // image already sent to the generic path
+            encode_set<CH, PROBE, ENTRY>(p, img, set, lane, s_lds[wave]);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 // ---------------------------------------------------------------------------------
-// E4a: exclusive scan of the slab byte counts of one image (one workgroup per image);
+// E4a (order-free mode): exclusive scan of the set byte counts of one image (one workgroup per image);
 // also writes the 14-byte header (qoi.h:384-388), the 8-byte end marker (qoi.h:339,480-482)
 // and *out_len (qoi.h:484).
 // ---------------------------------------------------------------------------------
-// The scan walks the image in tiles of 16384 slabs, 1024 per wavefront: counts are loaded coalesced (next tile's
+// The scan walks the image in tiles of 16384 sets, 1024 per wavefront: counts are loaded coalesced (next tile's
 // while this one is scanned), turned through a wavefront-private LDS stripe so that a lane holds 16 consecutive
 // counts, scanned (lane-serial, then six rounds over the wavefront, then over the 16 wavefronts) and written back
-// the same way.  A 4K frame is one tile, a 16384 x 16384 image 16 - the first version gave every thread a
-// contiguous 1/256 of the image to add up serially and took 0.4 ms on that image.
+// the same way.
 __global__ __launch_bounds__(1024) void enc_offsets(EncParams p) {
     constexpr uint32_t kPer = 16, kStripe = 64u * kPer, kTile = 16u * kStripe;
     __shared__ uint32_t s_turn[16][kStripe + 64u];             // element e of a stripe at e + e/16 (bank spread)
     __shared__ uint32_t s_wave[16];
     const uint32_t img = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t* __restrict__ sz = p.slab_size + (size_t)img * p.spi;
-    uint32_t* __restrict__ off = p.slab_off + (size_t)img * p.spi;
-    const uint32_t n = p.spi;
+    const uint32_t* __restrict__ sz = p.set_size + (size_t)img * p.sets_per_image;
+    uint32_t* __restrict__ off = p.set_off + (size_t)img * p.sets_per_image;
+    const uint32_t n = p.sets_per_image;
     uint32_t* turn = s_turn[wave];
     uint32_t carry = 0;
     uint32_t nv[kPer];
 #pragma unroll
     for (uint32_t j = 0; j < kPer; ++j) { const uint32_t e = wave * kStripe + j * 64u + lane; nv[j] = e < n ? sz[e] : 0u; }
     for (uint32_t base = 0; base < n; base += kTile) {
-        const uint32_t sbase = base + wave * kStripe;          // first slab of this wavefront's stripe
+        const uint32_t sbase = base + wave * kStripe;          // first set of this wavefront's stripe
 #pragma unroll
         for (uint32_t j = 0; j < kPer; ++j) { const uint32_t e = j * 64u + lane; turn[e + (e >> 4)] = nv[j]; }
 #pragma unroll
@@ -757,34 +907,16 @@ __global__ __launch_bounds__(1024) void enc_offsets(EncParams p) {
     if (tid == 0) p.out_len[img] = (int)(kHeaderBytes + total + kTrailerBytes);
 }
 
-// E4b: move every slab's bytes from its scratch slot to its place in the stream
-// (one wavefront per slab; aligned 16-byte stores, source re-aligned with v_alignbyte).
+// E4b (order-free mode): move every set's bytes from its scratch slot to its place in the stream
+// (one wavefront per set; aligned 16-byte stores, source re-aligned with v_alignbyte).
 __global__ __launch_bounds__(256) void enc_compact(EncParams p) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t g = blockIdx.x * 4u + wave;
-    if (g >= p.n_images * p.spi) return;
-    const uint32_t img = g / p.spi;
-    const uint32_t n = p.slab_size[g];
+    const size_t sg = (size_t)blockIdx.x * 4u + wave;
+    if (sg >= (size_t)p.n_images * p.sets_per_image) return;
+    const uint32_t img = (uint32_t)(sg / p.sets_per_image);
+    const uint32_t n = p.set_size[sg];
     if (n == 0) return;
-    const uint8_t* __restrict__ src = p.scratch + (size_t)g * kEncScratchStride;      // 16-byte aligned
-    uint8_t* __restrict__ dst = p.out + (size_t)img * p.out_stride + kHeaderBytes + p.slab_off[g];
-    const uint32_t mis = (uint32_t)(uintptr_t)dst & 15u;
-    const uint32_t head = min(n, (16u - mis) & 15u);                 // bytes before dst becomes 16-byte aligned
-    if (lane < head) dst[lane] = src[lane];
-    const uint32_t n16 = (n - head) >> 4;
-    uint4* __restrict__ d16 = reinterpret_cast<uint4*>(dst + head);
-    const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(src) + (head >> 2);
-    const uint32_t sh = head & 3u;
-    for (uint32_t j = lane; j < n16; j += 64u) {
-        const uint32_t* q = s32 + 4u * j;
-        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
-        uint4 v;
-        v.x = __builtin_amdgcn_alignbyte(w1, w0, sh); v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
-        v.z = __builtin_amdgcn_alignbyte(w3, w2, sh); v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
-        d16[j] = v;
-    }
-    const uint32_t done = head + (n16 << 4);
-    if (lane < n - done) dst[done + lane] = src[done + lane];
+    copy_global_out(p.scratch + sg * p.set_stride, p.out + (size_t)img * p.out_stride + kHeaderBytes + p.set_off[sg], n, lane);
 }
 
 // Measures whether one ds_wrxchg_rtn_b32 serves same-address lanes in ascending lane order
@@ -842,53 +974,53 @@ __global__ __launch_bounds__(64 * WAVES) void lds_order_selftest(uint32_t* out) 
 // ---------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------
-template <int CH, int K, int PROBE, int ABL>
+template <int CH, int PROBE>
 static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int phases) {
-    const uint32_t total = p.n_images * p.spi;
-    const uint32_t blocks = (total + 3u) / 4u;
-    const uint32_t quads_per_image = (p.spi + 3u) / 4u;
-    const uint32_t wgs_per_image = (quads_per_image + p.quads_per_wg - 1u) / p.quads_per_wg;
-    p.n_units = wgs_per_image * p.n_images;
+    const uint32_t total_slabs = p.n_images * p.spi;
+    const uint32_t slab_blocks = (total_slabs + 3u) / 4u;
+    const uint32_t quads_per_image = (p.sets_per_image + 3u) / 4u;
+    p.n_units = quads_per_image * p.n_images;
     const bool warm = p.warm && PROBE == 1;
     uint32_t small = 2048u;                                  // grid of the passes that usually have nothing to do
     tm->mark(kT_begin, st);
     if (phases & kEncSlabs) {
     if (warm) {
         p.only_flagged = 0;
-        hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL, 1>), dim3(p.n_units), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1>), dim3(p.n_units), dim3(256), 0, st, p);
         tm->mark(kT_enc_slabs, st);
         p.only_flagged = 1;
     } else {
         p.only_flagged = 0;
         small = 0xFFFFFFFFu;
     }
-    hipLaunchKernelGGL((enc_slab_summary<CH, K>), dim3(blocks < small ? blocks : small), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((enc_slab_summary<CH, kEncSteps>), dim3(slab_blocks < small ? slab_blocks : small), dim3(256), 0, st, p);
     tm->mark(kT_enc_summary, st);
     hipLaunchKernelGGL(enc_scan_groups, dim3(p.n_images * p.gpi), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_groups, st);
     hipLaunchKernelGGL(enc_scan_images, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_images, st);
-    // look-back mode: the images the first pass gave up on are encoded again from their first slab, with look-back records and
+    // look-back mode: the images the first pass gave up on are encoded again from their first set, with look-back records and
     // tickets of their own (those of the first pass are spent)
-    if (warm && !p.scratch) { p.status = p.status2; p.ticket = p.ticket2; }
-    hipLaunchKernelGGL((enc_slabs<CH, K, PROBE, ABL, 0>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
+    if (warm && p.lookback) { p.status = p.status2; p.ticket = p.ticket2; }
+    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
     tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
     }
-    if (p.scratch && (phases & kEncPlace)) {
+    if (!p.lookback && (phases & kEncPlace)) {
+        const uint32_t set_blocks = (p.n_images * p.sets_per_image + 3u) / 4u;
         hipLaunchKernelGGL(enc_offsets, dim3(p.n_images), dim3(1024), 0, st, p);
         tm->mark(kT_enc_offsets, st);
-        hipLaunchKernelGGL(enc_compact, dim3(blocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(enc_compact, dim3(set_blocks), dim3(256), 0, st, p);
         tm->mark(kT_enc_compact, st);
     }
 }
 
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phases) {
     if (p.channels == 3) {
-        if (p.probe_xchg) launch_encode_t<3, kEncSteps, 1, 0>(p, st, tm, phases); else launch_encode_t<3, kEncSteps, 0, 0>(p, st, tm, phases);
+        if (p.probe_xchg) launch_encode_t<3, 1>(p, st, tm, phases); else launch_encode_t<3, 0>(p, st, tm, phases);
         return;
     }
-    if (!p.probe_xchg) { launch_encode_t<4, kEncSteps, 0, 0>(p, st, tm, phases); return; }
-    launch_encode_t<4, kEncSteps, 1, 0>(p, st, tm, phases);
+    if (!p.probe_xchg) { launch_encode_t<4, 0>(p, st, tm, phases); return; }
+    launch_encode_t<4, 1>(p, st, tm, phases);
 }
 
 // returns the number of mismatching patterns of the LDS exchange-order self-test (0 = ordered)

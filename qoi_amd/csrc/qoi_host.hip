@@ -94,11 +94,9 @@ struct qoimi_ctx {
     bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
     long long enc_calls = 0;            // encode calls so far: the self-test is repeated every 256 of them
     bool recheck_pending = false;       // a repeated self-test is in flight on own_stream, result in host_word[8]
-    int enc_ablate = 0, enc_ticket = 1, enc_quads = 0, enc_warm = 1;   // tuning / profiling knobs (env QOIMI_ENC_*)
-    int enc_lookback = -1;              // 1: single-pass decoupled look-back instead of scratch + compaction; 0: never; -1: by the last call's output (below)
-    // placement mode by content: the first stream's length of the previous qoimi_encode_batch is read back through host_word[10]
-    // (copy on the caller's stream behind the kernels, looked at when the next call finds it done)
-    hipEvent_t enc_len_ev = nullptr; bool enc_len_pending = false; uint32_t enc_len_npx = 0; bool enc_dense = false;
+    int enc_ticket = 1, enc_set_slabs = 0, enc_warm = 1;   // tuning / test knobs (env QOIMI_ENC_*)
+    int enc_lookback = 1;               // 1: sets place their bytes themselves (decoupled look-back); 0: order-free (scratch slots + enc_offsets + enc_compact)
+    std::string enc_debug_dump;         // env QOIMI_ENC_DEBUG_DUMP: file that receives the entry-state arrays of every encode call
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
     int dec_pair = 3;                   // bit 0: P4, bit 1: P3 run as reader / worker wavefront pairs; 0: one wavefront per 64 segments
@@ -145,9 +143,9 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         c->xchg_ordered = run_lds_order_selftest(pst) == 0;
     }
     if (const char* e = getenv("QOIMI_ENC_PROBE")) { if (atoi(e) == 0) c->xchg_ordered = false; }
-    if (const char* e = getenv("QOIMI_ENC_ABLATE")) c->enc_ablate = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_TICKET")) c->enc_ticket = atoi(e);
-    if (const char* e = getenv("QOIMI_ENC_QUADS")) c->enc_quads = atoi(e);
+    if (const char* e = getenv("QOIMI_ENC_SET_SLABS")) c->enc_set_slabs = atoi(e);
+    if (const char* e = getenv("QOIMI_ENC_DEBUG_DUMP")) c->enc_debug_dump = e;
     if (const char* e = getenv("QOIMI_ENC_WARM")) c->enc_warm = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
@@ -167,7 +165,6 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
 extern "C" void qoimi_ctx_destroy(qoimi_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
-    if (c->enc_len_ev) { if (c->enc_len_pending) (void)hipEventSynchronize(c->enc_len_ev); (void)hipEventDestroy(c->enc_len_ev); }   // the read-back lands in host_word
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     c->enc_ws.release(); c->dec_ws.release(); c->io_a.release(); c->io_b.release(); c->io_c.release();
     if (c->host_word) (void)hipHostFree(c->host_word);
@@ -266,42 +263,41 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         launch_lds_order_selftest(d_flag, c->own_stream);
         if (hipMemcpyAsync(&c->host_word[8], d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->own_stream) == hipSuccess) c->recheck_pending = true;
     }
-    // Streams of several bytes per pixel (noise, RGBA-dense frames): parking the slabs and moving them again is a second trip of
-    // ~5 B/px through HBM, the look-back placement writes them once (256 4K noise frames 9.4 -> 6.2 ms; photographs at 1.2 B/px
-    // are a draw, flat UI frames lose - DESIGN.md section 3).  Both give the same bytes.
-    if (c->enc_len_pending && hipEventQuery(c->enc_len_ev) == hipSuccess) {
-        c->enc_len_pending = false;
-        c->enc_dense = c->enc_len_npx && (unsigned long long)c->host_word[10] > 3ull * c->enc_len_npx;
-    }
-    const bool lookback = c->enc_lookback < 0 ? c->enc_dense : c->enc_lookback != 0;
+    // Placement: by default a set finds its place in the stream by decoupled look-back and writes its bytes once, straight from
+    // the LDS (sets of more than ~1.4 bytes per pixel spill to their scratch slot and move that part themselves);
+    // QOIMI_ENC_LOOKBACK=0 selects the order-free form (every set parks its bytes, enc_offsets + enc_compact place them).
+    // Both give the same bytes.
+    const bool lookback = c->enc_lookback != 0;
     p.probe_xchg = c->xchg_ordered ? 1 : 0;
     p.use_ticket = c->enc_ticket ? 1 : 0;
-    p.ablate = (uint8_t)c->enc_ablate;
-    const size_t T = (size_t)p.n_images * p.spi, G = (size_t)p.n_images * p.gpi;
-    {   // slabs one wavefront walks through (it prefetches the next while it encodes one): enough of them that
-        // the load latency is hidden, few enough that the grid still fills 256 CUs x 6 workgroups several times
-        const size_t total_quads = (size_t)n_images * ((p.spi + 3u) / 4u);
-        size_t r = 1u;
-        (void)total_quads;
-        p.warm = c->enc_warm ? 1 : 0;
-        p.quads_per_wg = c->enc_quads > 0 ? (uint32_t)c->enc_quads : (uint32_t)(r < 1 ? 1 : (r > 16 ? 16 : r));
+    p.lookback = lookback ? 1 : 0;
+    p.warm = c->enc_warm ? 1 : 0;
+    {   // slabs per set: a wavefront carries the colour table and its staged bytes from slab to slab, so the entry-state replay
+        // and the look-back are paid once per set - as long as the sets still fill the 256 CUs x 20 wavefronts several times
+        const size_t total_slabs = (size_t)n_images * p.spi;
+        uint32_t r = total_slabs >= 4u * 65536u ? 4u : (total_slabs >= 2u * 65536u ? 2u : 1u);
+        if (c->enc_set_slabs > 0) r = (uint32_t)c->enc_set_slabs;
+        if (r > kEncMaxSetSlabs) r = kEncMaxSetSlabs;
+        p.set_slabs = r;
+        p.set_px = r * kEncSlabPx;
+        p.sets_per_image = (p.spi + r - 1u) / r;
+        p.set_stride = r * kEncSlabWorst + 16u;
     }
+    const size_t T = (size_t)p.n_images * p.spi, G = (size_t)p.n_images * p.gpi, S = (size_t)p.n_images * p.sets_per_image;
     if (T > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (slab index overflows 32 bits)");
 
     for (int pass = 0; pass < 2; ++pass) {      // pass 0 measures, pass 1 carves
         Carver w(pass ? c->enc_ws.base : nullptr);
-        p.status = w.take<u64>(T); p.ticket = w.take<uint32_t>((size_t)n_images); p.err = w.take<uint32_t>(1);
+        p.status = w.take<u64>(S); p.ticket = w.take<uint32_t>((size_t)n_images); p.err = w.take<uint32_t>(1);
         p.need_generic = w.take<uint32_t>((size_t)n_images); p.any_generic = w.take<uint32_t>(1);
-        if (lookback) { p.status2 = w.take<u64>(T); p.ticket2 = w.take<uint32_t>((size_t)n_images); }
+        p.status2 = w.take<u64>(S); p.ticket2 = w.take<uint32_t>((size_t)n_images);
         const size_t zero_bytes = w.off;
         p.sum_tab = w.take<uint32_t>(T * 64); p.sum_valid = w.take<u64>(T); p.sum_le = w.take<int>(T);
         p.ent_tab = w.take<uint32_t>(T * 64); p.ent_valid = w.take<u64>(T); p.ent_le = w.take<int>(T);
         p.grp_tab = w.take<uint32_t>(G * 64); p.grp_valid = w.take<u64>(G); p.grp_le = w.take<int>(G);
         p.gent_tab = w.take<uint32_t>(G * 64); p.gent_le = w.take<int>(G);
-        if (!lookback) {
-            p.slab_size = w.take<uint32_t>(T); p.slab_off = w.take<uint32_t>(T);
-            p.scratch = w.take<uint8_t>(T * kEncScratchStride);
-        }
+        p.set_size = w.take<uint32_t>(S); p.set_off = w.take<uint32_t>(S);
+        p.scratch = w.take<uint8_t>(S * p.set_stride);
         if (!pass) { int rc = c->enc_ws.reserve(w.off + 256); if (rc) return rc; }
         else HIP_TRY(hipMemsetAsync(c->enc_ws.base, 0, zero_bytes, st));   // look-back records, ticket, err
     }
@@ -313,7 +309,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     c->timer.mark(kT_begin, st);
     launch_encode(p, st, &c->timer);
     c->timer.mark(kT_enc_total, st);
-    if (const char* dump = getenv("QOIMI_ENC_DEBUG_DUMP")) {          // diagnostics: the entry-state arrays of this call, raw
+    if (const char* dump = c->enc_debug_dump.empty() ? nullptr : c->enc_debug_dump.c_str()) {          // diagnostics: the entry-state arrays of this call, raw
         (void)hipStreamSynchronize(st);
         if (FILE* fo = fopen(dump, "wb")) {
             auto put = [&](const void* d, size_t bytes) { std::vector<uint8_t> h(bytes); (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost); fwrite(h.data(), 1, bytes, fo); };
@@ -323,11 +319,6 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
             put(p.grp_tab, G * 256); put(p.grp_valid, G * 8); put(p.gent_tab, G * 256);
             fclose(fo);
         }
-    }
-    if (c->enc_lookback < 0 && !c->enc_len_pending && n_images > 0) {
-        if (!c->enc_len_ev && hipEventCreateWithFlags(&c->enc_len_ev, hipEventDisableTiming) != hipSuccess) c->enc_len_ev = nullptr;
-        if (c->enc_len_ev && hipMemcpyAsync(&c->host_word[10], d_stream_len, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
-            hipEventRecord(c->enc_len_ev, st) == hipSuccess) { c->enc_len_pending = true; c->enc_len_npx = (uint32_t)npx; }
     }
     HIP_TRY(hipGetLastError());
     return QOIMI_OK;

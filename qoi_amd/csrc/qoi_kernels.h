@@ -29,8 +29,9 @@ struct KernelTimer {
 
 // ---- encode ------------------------------------------------------------------------
 constexpr int kEncSteps = 16;                         // 64-pixel steps per slab
-constexpr uint32_t kEncSlabPx = 64u * kEncSteps;      // pixels per slab (one wavefront)
-constexpr uint32_t kEncScratchStride = ((kEncSlabPx * 5u + 8u + 15u) / 16u) * 16u;   // scratch slot of one slab
+constexpr uint32_t kEncSlabPx = 64u * kEncSteps;      // pixels per slab: the unit of the generic entry-state passes
+constexpr uint32_t kEncMaxSetSlabs = 8;               // a wavefront encodes a SET of 1..8 consecutive slabs
+constexpr uint32_t kEncSlabWorst = kEncSlabPx * 5u;   // most bytes a slab can produce (QOI_OP_RGBA everywhere)
 
 struct EncParams {
     const uint8_t* pixels;   // image i at pixels + i*pixel_stride
@@ -39,30 +40,33 @@ struct EncParams {
     uint32_t n_images;
     uint32_t spi;            // slabs per image
     uint32_t gpi;            // 64-slab groups per image
+    uint32_t set_slabs;      // slabs per set (R)
+    uint32_t set_px;         // pixels per set = R * kEncSlabPx
+    uint32_t sets_per_image; // ceil(spi / R)
+    uint32_t set_stride;     // bytes of a set's scratch slot (R * kEncSlabWorst + 16)
     uint32_t width, height;
     uint8_t channels, colorspace;
     uint8_t probe_xchg;      // 1: ds_wrxchg colour-table probe (needs the LDS order self-test to have passed)
-    uint8_t use_ticket;      // 1: slab ids by atomic ticket (start order); 0: by blockIdx
-    uint8_t ablate;          // profiling only
-    uint8_t warm;            // 1: slabs find their entry state themselves (look-back window), E1/E2 only for flagged images
+    uint8_t use_ticket;      // 1: set ids by atomic ticket (start order); 0: by blockIdx
+    uint8_t lookback;        // 1: a set finds its place in the stream by decoupled look-back and writes its bytes itself;
+                             // 0: order-free - sets park their bytes in scratch slots, enc_offsets + enc_compact place them
+    uint8_t warm;            // 1: sets find their entry state themselves (look-back window), E1/E2 only for flagged images
     uint8_t only_flagged;    // set by the launcher: this pass handles images with need_generic[img] != 0 only
-    uint32_t n_units;        // set by the launcher: (image, group of quads_per_wg x 4 slabs) work units
-    uint32_t quads_per_wg;   // consecutive 4-slab groups one workgroup walks through
+    uint32_t n_units;        // set by the launcher: (image, four consecutive sets) work units
     // workspace
     uint32_t* sum_tab;   u64* sum_valid;  int* sum_le;     // E1 out        [n_images*spi]
     uint32_t* ent_tab;   u64* ent_valid;  int* ent_le;     // E2a out       [n_images*spi]
     uint32_t* grp_tab;   u64* grp_valid;  int* grp_le;     // E2a aggregate [n_images*gpi]
     uint32_t* gent_tab;  int* gent_le;                     // E2b out       [n_images*gpi]
-    u64* status;         // look-back records [n_images*spi]   -- zeroed before every launch
-    uint32_t* ticket;    // per-image slab ticket counters [n_images] -- zeroed before every launch
+    u64* status;         // look-back records [n_images*sets_per_image]   -- zeroed before every launch
+    uint32_t* ticket;    // per-image ticket counters [n_images]          -- zeroed before every launch
     u64* status2; uint32_t* ticket2;   // look-back mode: the same two for the second (generic) pass over flagged images
     uint32_t* err;       // liveness-bound flag               -- zeroed before every launch
     uint32_t* need_generic;  // [n_images] image needs the E1/E2 path  -- zeroed before every launch
     uint32_t* any_generic;   // [1]                                    -- zeroed before every launch
-    // order-free mode (scratch != nullptr): slabs park their bytes in scratch slots, E4 compacts
-    uint8_t* scratch;    // [n_images*spi][kEncScratchStride]
-    uint32_t* slab_size; // [n_images*spi]
-    uint32_t* slab_off;  // [n_images*spi]
+    uint8_t* scratch;    // [n_images*sets_per_image][set_stride]: parked sets (order-free mode) / spilled pieces (look-back mode)
+    uint32_t* set_size;  // [n_images*sets_per_image]  order-free mode
+    uint32_t* set_off;   // [n_images*sets_per_image]  order-free mode
     // output
     uint8_t* out; size_t out_stride; int* out_len;
 };

@@ -247,9 +247,13 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
 
 @pytest.mark.parametrize("env", [
     {"QOIMI_ENC_WARM": "0"},                              # entry states from per-slab summaries + scans for every image
-    {"QOIMI_ENC_LOOKBACK": "0"},                          # scratch slots + compaction whatever the content (default: by the last call's bytes per pixel)
-    {"QOIMI_ENC_LOOKBACK": "1"},                          # single-pass decoupled look-back instead of scratch + compaction
-    {"QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_WARM": "0"},   # ... with the entry states from the summary passes
+    {"QOIMI_ENC_LOOKBACK": "0"},                          # order-free placement: sets park their bytes, enc_offsets + enc_compact place them
+    {"QOIMI_ENC_LOOKBACK": "0", "QOIMI_ENC_WARM": "0"},   # ... with the entry states from the summary passes
+    {"QOIMI_ENC_SET_SLABS": "4"},                         # four slabs per wavefront (what large batches use), look-back placement
+    {"QOIMI_ENC_SET_SLABS": "8", "QOIMI_ENC_WARM": "0"},
+    {"QOIMI_ENC_SET_SLABS": "3", "QOIMI_ENC_LOOKBACK": "0"},
+    {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_PROBE": "0"},
+    {"QOIMI_ENC_TICKET": "0"},                            # sets by workgroup index instead of by ticket
     {"QOIMI_ENC_PROBE": "0"},                             # order-independent colour-table probe (ds_or masks)
     {"QOIMI_DEC_FINE": "0", "QOIMI_SEG_BYTES": "2048"},   # lane-per-segment P1/P2 instead of 128-byte pieces
     {"QOIMI_SEG_BYTES": "1024"},                          # P1/P2 on 8 pieces per segment
@@ -410,7 +414,8 @@ def test_decode_repair_loop_is_bounded(api, oracle, rounds):
         del os.environ["QOIMI_SEG_BYTES"]
 
 
-@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_WARM": "0"}, {"QOIMI_ENC_LOOKBACK": "1"}])
+@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_WARM": "0"}, {"QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_SET_SLABS": "4"},
+                                 {"QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "0"}])
 def test_flat_frames_byte_identical(api, oracle, env):
     """Flat UI frames go through the generic entry-state path (per-slab summaries + scans).  Frame 60 of this sweep was
     encoded three bytes too long by every path until round 2: a 64-bit lane mask lost its upper half (sign extension of
@@ -478,10 +483,47 @@ def test_random_sweep_of_contents_and_shapes(api, oracle):
     assert checked == len(shapes) * 2 * 5
 
 
-def test_placement_mode_follows_content(api, oracle):
-    """qoimi_encode_batch picks its placement (parked slabs + compaction, or look-back) from the bytes per pixel of the previous
-    call on the context: a context that sees noise, noise, photo, photo, noise goes through both switches; every stream stays
-    byte-identical to the reference's."""
+@pytest.mark.parametrize("slabs", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("lookback", ["1", "0"])
+def test_set_sizes_and_placements(api, oracle, slabs, lookback):
+    """A wavefront encodes a SET of R consecutive slabs (R = 1..8; the library picks it from the batch size, here it is forced) and
+    places its bytes by look-back (bytes beyond the staging buffer spill through the set's scratch slot) or order-free.  Shapes
+    with a partial last set / last group / last step, every content class in 3 and 4 channels: byte-identical to the reference."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    old = {k: os.environ.get(k) for k in ("QOIMI_ENC_SET_SLABS", "QOIMI_ENC_LOOKBACK")}
+    os.environ["QOIMI_ENC_SET_SLABS"] = str(slabs)
+    os.environ["QOIMI_ENC_LOOKBACK"] = lookback
+    try:
+        c = api.Context(0)
+        for (w, h) in ((1400, 900), (517, 313), (64, 9), (1024, 16)):
+            for ch in (4, 3):
+                kinds = ["photo", "noise", "uiflat", "constant", "photo", "noise"]
+                n = len(kinds)
+                frames = [np.ascontiguousarray(synth.frame_rgba(kinds[i], w, h, 300 + 7 * i + slabs)[:, :, :ch]) for i in range(n)]
+                if ch == 4:
+                    frames[4] = frames[4].copy(); frames[4][::3, ::5, 3] = 128          # alpha changes: QOI_OP_RGBA among short chunks
+                b = DeviceBatch(c, w, h, ch, n)
+                for i in range(n):
+                    b.upload(i, frames[i])
+                lens = b.encode()
+                torch.cuda.synchronize()
+                for i in range(n):
+                    want = oracle.encode(frames[i], w, h, ch)
+                    assert b.stream_bytes(i, lens[i]) == want, (slabs, lookback, w, h, ch, kinds[i], int(lens[i]), len(want))
+        c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_one_context_through_changing_content(api, oracle):
+    """One context encodes noise, noise, photo, photo, noise, flat frames in turn (workspace layout and placement stay the
+    same from call to call); every stream stays byte-identical to the reference's."""
     import torch
     from gpu_util import DeviceBatch
     from qoi_amd import synth
