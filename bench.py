@@ -254,6 +254,10 @@ def main() -> None:
     ap.add_argument("--no-others", action="store_true", help="skip the noise / constant / uiflat side figures")
     ap.add_argument("--no-single", action="store_true", help="skip the single-frame figure (profiling runs: keeps every launch batch-sized)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2] / configs[3] side figures")
+    ap.add_argument("--counter-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend that gathers the counters (nothing else crosses ranks).  nccl = RCCL, one GPU per rank; "
+                         "gloo: counters as CPU tensors, ranks may share a GPU (rank r uses device r mod device count) - how the "
+                         "multi-rank path is exercised on a one-GPU box (tests/test_bench_ranks.py)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -266,9 +270,17 @@ def main() -> None:
     rank, world, local = qdist.env_world()
     if world != args.gpus:
         sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        sys.exit("bench.py: no GPU visible (there is no CPU codec in this library)")
+    if args.counter_backend == "nccl" and world > n_dev:
+        sys.exit(f"bench.py: --gpus {world} but only {n_dev} GPU(s) visible; RCCL needs one GPU per rank "
+                 f"(--counter-backend gloo lets ranks share a GPU, for testing the multi-rank path only)")
+    local = local % n_dev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    qdist.init("nccl", dev)          # RCCL; only counters ever cross GPUs
+    cdev = dev if args.counter_backend == "nccl" else "cpu"     # where the counter tensors live
+    qdist.init(args.counter_backend, dev)          # RCCL (or gloo); only counters ever cross ranks
     ctx = api.Context(local)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -443,8 +455,9 @@ def main() -> None:
                                               "unit": "GB/s", "frac": round(n3 * 4 / dte / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": n3 * 4, "ms_per_launch": round(dte * 1e3, 3)}}
 
     # RCCL: counters only (max elapsed; summed pixels / stream bytes / verified ranks)
-    elapsed, (total_px, total_stream_bytes, n_ok) = qdist.reduce_counters(
-        elapsed, [float(F * npx * launches), float(sum(sizes)) * launches, float(ok)], dev)
+    my_frames = range(first_frame, first_frame + (len(mine) if strong else F))       # synthetic frame ids this rank coded
+    elapsed, (total_px, total_stream_bytes, n_ok, frames_coded, frame_id_sum) = qdist.reduce_counters(
+        elapsed, [float(F * npx * launches), float(sum(sizes)) * launches, float(ok), float(len(my_frames)), float(sum(my_frames))], cdev)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -492,6 +505,7 @@ def main() -> None:
                        "frames_per_gpu": F * passes, "frames_resident": F, "width": w, "height": h, "content": args.kind,
                        "stream_bytes_per_px": round(total_stream_bytes / total_px, 4), "parallelism": f"frames sharded x{world}"},
             "verified_bit_exact": n_ok == world, "reference_check": refcheck,
+            "counter_backend": args.counter_backend, "frames_coded_all_ranks": int(frames_coded), "frame_id_sum_all_ranks": int(frame_id_sum),
             "encode_mpps_kernels": round(F * npx * launches / (enc_ms * 1e3), 1) if enc_ms else None,
             "decode_mpps_kernels": round(F * npx * launches / (dec_ms * 1e3), 1) if dec_ms else None,
             "decode_rounds": dstats["rounds"], "decode_redo_segments": dstats["redo_segments"], "decode_sync_fallback_segments": dstats.get("sync_fallback_segments"),

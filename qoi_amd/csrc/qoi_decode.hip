@@ -234,7 +234,7 @@ __device__ __forceinline__ uint32_t apply_relative(uint32_t px, uint32_t w32, ui
 // how close in time the pieces of a cache line arrive (tools/ubench/store_patterns.hip, MI355X, 9 GB in 64-lane wavefronts
 // with 6.9 KB between the lanes' streams): 16 bytes per drain, the pieces of a line several hundred cycles apart - 1.0-1.4
 // TB/s (the L2 no longer merges them); 64 bytes per lane in one burst - 3.6 TB/s; 4 lanes x 16 bytes to one line - the same.
-// dec_segments_rec therefore drains groups of 16 pixels from a ring of 32 (dec_segments / dec_segments_pair: 4 from 16).
+// dec_segments_rec therefore drains groups of 16 pixels from a ring of 32.
 template <int OCH, uint32_t RING_ = 16, uint32_t GROUP_ = QOIMI_DRAIN_GROUP>
 struct LaneWriter {
     static constexpr uint32_t kRing = RING_;
@@ -436,26 +436,22 @@ struct FineBuf {
     }
 };
 
-// TAIL: the walk behind the chains' meeting point also accumulates the speculative slot transfer (P2) of that tail for
-// dec_slot_heads_fine.  With chunk records (DecParams::use_rec) the transcoder walks every chunk from its true entry
-// position anyway and leaves the whole transfer: the parse then carries chunk lengths and pixel counts only.
-template <bool TAIL>
+// The five-phase parse of the segments dec_transcode<0> could not synchronise (it flags them in sync_fail): chunk lengths
+// and pixel counts for every possible entry phase; the transcoder (MODE 1) then walks them from the phase S1 finds.
 __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     __shared__ uint32_t s_buf[4][kFineDwords * 64];
     __shared__ uint32_t s_rec[4][64][6];          // per lane: exit map, pixels[5]
     __shared__ uint32_t s_res[4][64][2];          // per (group, entry phase): exit phase, pixels
     __shared__ LdsLut s_lut;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    if (!TAIL && *p.sync_fails == 0u) return;              // record pipeline: nothing to parse (dec_transcode synchronised every segment)
+    if (*p.sync_fails == 0u) return;                       // nothing to parse (dec_transcode synchronised every segment)
     build_lut(s_lut, threadIdx.x, 256u);
     const uint32_t G = p.fine_per_seg, gs = p.fine_shift;
     const uint32_t F = blockIdx.x * 256u + threadIdx.x;
     const uint32_t q = F >> gs, sub = F & (G - 1u);
     bool have = q < p.total_segs;
-    if (!TAIL) {                                          // only the segments dec_transcode could not synchronise
-        have = have && p.sync_fail[have ? q : 0u] != 0u;
-        if (!lanes_where(have)) return;
-    }
+    have = have && p.sync_fail[have ? q : 0u] != 0u;      // only the segments dec_transcode could not synchronise
+    if (!lanes_where(have)) return;
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
@@ -478,12 +474,8 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
             active = m < end;
         }
     }
-    // From the byte where the chains met, the chunk sequence no longer depends on the entry phase: the same
-    // walk also yields the speculative slot/alpha transfer (P2) of this tail; dec_slot_heads_fine later adds the
-    // few chunks between the piece's actual entry position and the meeting point.
-    const uint32_t moff = merged ? m - base : 255u;       // chains met at base + moff (<= 132)
+    // From the byte where the chains met, the chunk sequence no longer depends on the entry phase.
     uint32_t add = 0;
-    SlotFast st; slotf_init(st);
     // one chunk per step; the next chunk's bytes and its table word are asked for before this chunk's arithmetic
     // No lane is masked off inside the loop: a lane that is through with its piece runs a null chunk (length 0, no
     // pixels, slot shift 0) - with the exec mask untouched the loop has no merge copies; two steps per iteration with
@@ -499,11 +491,7 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
         R.peek_raw(m, nw32, nhi, nsh);                                     // stays inside the buffer: m <= end + 4
         ninfo = s_lut.info[nw32 & 0xFFu];
         add += lut_pixels(c_info);
-        if (TAIL) {
-            const bool any_hi = lanes_where(lut_hi(c_info)) != 0;
-            const uint32_t b5 = any_hi ? (hiw >> (sh8 & 24u)) & 0xFFu : 0u;   // byte 4 of the chunk: QOI_OP_RGBA's alpha only
-            slotf_step_split(st, w32, b5, c_info, any_hi);
-        }
+        (void)w32; (void)hiw; (void)sh8;
     };
     while (lanes_where(m < end_b)) {
         uint32_t wb, hb, sb, ib;
@@ -515,14 +503,6 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
         s.c0 += add; s.c1 += add; s.c2 += add; s.c3 += add; s.c4 += add;
     }
     ParseRec r; parse_finish(s, base, kFineBytes, r);
-    if (have) {
-        p.fine_exit[F] = (uint16_t)r.exit_phase;
-        if (TAIL) {
-            SlotRec tr; slotf_finish(st, tr);
-            p.fine_tail[F] = slot_pack(tr);
-            p.fine_moff[F] = (uint8_t)moff;
-        }
-    }
     if (G == 1u) { if (have) p.parse[q] = r; return; }     // 128-byte segments: the piece is the segment
     // compose the G (8..64) pieces of every segment: lane `sub` = e < 5 walks the pieces for entry phase e
     s_rec[wave][lane][0] = r.exit_phase;
@@ -547,85 +527,6 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
             o.pixels[e] = s_res[wave][lane + e][1];
         }
         p.parse[q] = o;
-    }
-}
-
-// P2 on 128-byte pieces.  dec_parse_fine already walked every piece from the byte where its five phase chains
-// met and left the slot transfer of that tail; what is missing is the head: the few chunks from the piece's
-// actual entry position (segment entry phase pushed through the exit maps of the pieces before it) to the
-// meeting point.  Head and tail compose to the piece's transfer, the pieces' transfers to the segment's.
-__global__ __launch_bounds__(256) void dec_slot_heads_fine(DecParams p) {
-    __shared__ uint32_t s_buf[4][kFineDwords * 64];
-    __shared__ uint32_t s_x[4][64];
-    __shared__ LdsLut s_lut;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    build_lut(s_lut, threadIdx.x, 256u);
-    const uint32_t G = p.fine_per_seg, gs = p.fine_shift;
-    const uint32_t F = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t q = F >> gs, sub = F & (G - 1u);
-    bool have = q < p.total_segs;
-    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
-    const DecImage im = p.images[img];
-    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
-    have = have && j >= im.start_seg && j < im.n_active;
-    if (!lanes_where(have)) return;
-    const uint32_t cbase = (uint32_t)kHeaderBytes + j * p.seg_bytes;
-    const uint32_t cend = min(cbase + p.seg_bytes, im.chunks_end);
-    const uint32_t base = cbase + sub * kFineBytes;
-    const uint32_t end = min(base + kFineBytes, cend);
-    // entry phase of this piece
-    s_x[wave][lane] = have ? p.fine_exit[F] : 0u;
-    const uint32_t moff = have ? p.fine_moff[F] : 255u;
-    const uint32_t tail = have ? p.fine_tail[F] : slot_pack(SlotRec{0, 1, 0, 0, 0});
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t g0 = lane - sub;
-    uint32_t ph = have ? p.entry_phase[q] : 0u;
-    for (uint32_t k = 0; k + 1u < G; ++k) {
-        const uint32_t mp = s_x[wave][g0 + k];
-        if (k < sub) ph = (mp >> (3u * ph)) & 7u;
-    }
-    uint32_t pos = base + ph;
-    const uint32_t stop = moff == 255u ? end : min(base + moff, end);     // never met: the head is the whole piece
-    bool active = have && pos < stop;
-    // bytes [pos, stop + 8) of the lanes that have a head at all; usually one or two 16-byte pieces
-    const uint32_t lo16 = min(base, im.chunks_end);
-    FineBuf R;
-    {
-        const uint8_t* stream = p.streams + im.stream_off;
-        const uint8_t* pp = stream + lo16;
-        const uint8_t* abase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(pp) & ~(uintptr_t)15);
-        const uint8_t* aend = stream + im.chunks_end + kTrailerBytes;
-        R.buf = lds_addr_of(&s_buf[wave][lane]);
-        R.aoff = lo16 - (uint32_t)(pp - abase);
-        const uint32_t need = active ? (stop - R.aoff + 8u + 15u) >> 4 : 0u;      // 16-byte pieces this lane needs
-        for (uint32_t r = 0; r < kFinePieces; ++r) {
-            if (!lanes_where(r < need)) break;
-            if (r < need) {
-                const uint4 v = abase + 16u * r < aend ? load_global16(abase + 16u * r) : make_uint4(0u, 0u, 0u, 0u);
-                lds_u32* qd = (lds_u32*)(R.buf + r * 1024u);
-                qd[0] = v.x; qd[64] = v.y; qd[128] = v.z; qd[192] = v.w;
-            }
-        }
-    }
-    SlotFast s; slotf_init(s);
-    while (lanes_where(active)) {
-        if (active) {
-            uint32_t w32, b5; R.peek(pos, w32, b5);
-            const uint32_t b1 = w32 & 0xFFu;
-            slotf_step(s, w32, b5, s_lut.info[b1]);
-            pos += len_of(b1);
-            active = pos < stop;
-        }
-    }
-    SlotRec r; slotf_finish(s, r);
-    if (moff != 255u) r = slot_compose(r, slot_unpack(tail));
-    __builtin_amdgcn_wave_barrier();
-    s_x[wave][lane] = slot_pack(r);
-    __builtin_amdgcn_wave_barrier();
-    if (have && sub == 0u) {
-        SlotRec acc = {0, 1, 0, 0, 0};
-        for (uint32_t k = 0; k < G; ++k) acc = slot_compose(acc, slot_unpack(s_x[wave][lane + k]));
-        p.slot_rec[q] = acc;
     }
 }
 
@@ -790,41 +691,6 @@ __global__ __launch_bounds__(64) void dec_chain_parse_l3(DecParams p) {
     if (lane == 0 && act && boundary) atomicMax(&p.images[img].n_active, j0 + 64u - (uint32_t)__builtin_clzll(act));
 }
 
-// ---------------------------------------------------------------------------------
-// P2: speculative slot/alpha transfer (lane = segment)
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_slot_walk(DecParams p) {
-    __shared__ uint32_t s_ring[4][LaneReader::kSlots * 64];
-    __shared__ LdsLut s_lut;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    build_lut(s_lut, threadIdx.x, 256u);
-    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
-    bool have = q < p.total_segs;
-    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
-    const DecImage im = p.images[img];
-    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
-    have = have && j >= im.start_seg && j < im.n_active;
-    if (!lanes_where(have)) return;
-    const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
-    const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
-    uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
-    LaneReader R;
-    R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
-    SlotFast s; slotf_init(s);
-    bool active = have && pos < end;
-    for (uint32_t it = 0; lanes_where(active); ++it) {
-        if (R.due(it)) R.refill(pos);
-        if (active) {
-            uint32_t w32, b5; R.peek(pos, w32, b5);
-            const uint32_t b1 = w32 & 0xFFu;
-            slotf_step(s, w32, b5, s_lut.info[b1]);
-            pos += len_of(b1);
-            active = pos < end;
-        }
-    }
-    if (have) { SlotRec r; slotf_finish(s, r); p.slot_rec[q] = r; }
-}
-
 // S2 with the same log-step scans.  Lane l holds the packed transfer of record l (identity outside the range).
 constexpr uint32_t kSlotIdentity = 1u << 8;                    // slot_pack({0, 1, 0, 0, 0})
 __device__ __forceinline__ uint32_t wave_scan_slots(uint32_t w, uint32_t lane) {
@@ -910,15 +776,8 @@ __global__ __launch_bounds__(64) void dec_chain_slots_l3(DecParams p) {
 }
 
 // ---------------------------------------------------------------------------------
-// P3: symbolic summaries (lane = segment; private 64-entry symbolic table in LDS,
-// laid out [slot][lane] so a lane always hits its own bank pair)
+// Symbolic words of P3 (dec_summarize_rec) and the private colour table of P4 (dec_segments_rec)
 // ---------------------------------------------------------------------------------
-struct LdsSymTab {
-    sym_t* col;   // &lds[0][lane]
-    __device__ __forceinline__ sym_t get(uint32_t k) const { return col[k * 64u]; }
-    __device__ __forceinline__ void set(uint32_t k, sym_t v) { col[k * 64u] = v; }
-};
-
 // The symbolic table is kept as two LDS arrays, constants (u32) and a one-byte code for source and absolute mask:
 // 20 KiB per wavefront instead of 32, which lets a sixth wavefront onto the CU (this kernel is bound by how many
 // lanes are resident, see dec_segments).  Only three masks occur - nothing absolute, r,g,b absolute (QOI_OP_RGB
@@ -940,279 +799,13 @@ __device__ __forceinline__ uint32_t sym_code_expand(uint32_t code) {       // ->
     return code == kSymCodeAbs ? (15u << 8) : (code >= kSymCodeRgb ? ((code - kSymCodeRgb) | (7u << 8)) : code);
 }
 
-template <bool REFINE>
-__global__ __launch_bounds__(64) void dec_summarize(DecParams p) {
-    __shared__ __attribute__((aligned(4096))) uint32_t s_ring[LaneReader::kSlots * 64];
-    constexpr uint32_t kRows = REFINE ? 65u : 64u;                  // row 64: kSymParkRow (refinement rounds only)
-    __shared__ uint32_t s_tabc[kRows * 64];
-    __shared__ uint8_t s_tabm[kRows * 64];                          // source / mask codes, see sym_code
-    __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 4];
-    __shared__ LdsLut s_lut;
-    const uint32_t lane = lane_id();
-    build_lut(s_lut, lane, 64u);
-    const uint32_t q = blockIdx.x * 64u + lane;
-    bool have = q < p.total_segs;
-    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
-    const DecImage im = p.images[img];
-    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
-    have = have && j >= im.start_seg && j < im.n_active;
-    if (!lanes_where(have)) return;
-    const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
-    const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
-    uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
-    LaneReader R;
-    R.init(lds_addr_of(&s_ring[lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
-    typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    const uint32_t tc_base = lds_addr_of(&s_tabc[lane]);             // slot k at + k*256
-    const uint32_t tm_base = lds_addr_of(&s_tabm[lane]);             // slot k at + k*64
-    const uint32_t lut_base = lds_addr_of(&s_lut.delta[0]);
-    // identity: slot k = entry slot k + 0, pixel = entry pixel + 0 (sym_init)
-    for (uint32_t k = 0; k < 64u; ++k) { *(lds_u32*)(tc_base + k * 256u) = 0u; *(lds_u8*)(tm_base + k * 64u) = (uint8_t)k; }
-    uint32_t pc = 0u, ph = 64u;                                       // ph: code of the running pixel (entry pixel, nothing absolute)
-    uint32_t slot, alpha;
-    if (REFINE) {
-        const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
-        uint32_t epx = 0;
-        if (have) {
-            for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {
-                uint32_t v[16];
-#pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) v[k] = ent[k0 + k];
-#pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) s_hint[(k0 + k) * 64u + lane] = (uint8_t)(v[k] >> 24);
-            }
-            epx = ent[64];
-            s_hint[64u * 64u + lane] = (uint8_t)(epx >> 24);
-        }
-        slot = hash_px(epx); alpha = epx >> 24;
-    } else {
-        slot = have ? p.slot_in[q] : 0u; alpha = have ? p.alpha_in[q] : 0u;
-    }
-    const uint32_t alpha_in0 = alpha;
-    // RUN chunks store nothing new except as a stream's first chunk (SymState); the refinement rounds skip the store
-    // (round 1 keeps it: its entry slots come from S2, not from a possibly spoiled entry pixel, and the three ops
-    // per step cost this kernel 6 %)
-    const uint32_t runmask = (REFINE && j != 0u) ? kLutRunBit : 0u;
-    bool active = have && pos < end;
-    uint32_t w32, b5; R.peek(pos, w32, b5);
-    uint32_t delta0, info;
-    {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); delta0 = lq[0]; info = lq[256]; }
-    // blocks of kPeriod steps: the stream loads issued by refill() are waited for at the NEXT refill only
-    while (lanes_where(active)) {
-        R.refill(pos);
-#pragma unroll
-        for (uint32_t u = 0; u < LaneReader::kPeriod; ++u) {
-            if (active) {
-                const uint32_t b1 = w32 & 0xFFu;
-                const uint32_t t_c = *(const lds_u32*)(tc_base + ((w32 & 63u) << 8));
-                const uint32_t t_m = *(const lds_u8*)(tm_base + ((w32 & 63u) << 6));
-                const uint32_t npos = pos + QOIMI_STEP_LEN(b1, info);
-                uint32_t nw32, nb5; R.peek(npos, nw32, nb5);      // next chunk's bytes travel while this one is executed
-                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)info, 28, 1);        // all ones for LUMA
-                const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
-                uint32_t pc_rel = pc;
-                add_byte0(pc_rel, delta0); add_byte1(pc_rel, delta0); add_byte2(pc_rel, delta0);
-                add_byte0(pc_rel, er); add_byte2_from0(pc_rel, eb);
-                const bool hi = lut_hi(info), lo = lut_lo(info);
-                const uint32_t s_rel = slot + lut_slot_shift(info) + 3u * er + 7u * eb;
-                uint32_t sb = 0, pb = 0, hb = 0;
-                if (lanes_where(hi)) {                       // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
-                    const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);
-                    const uint32_t pc_rgb = (pc & 0xFF000000u) | (rgba & 0x00FFFFFFu);
-                    const uint32_t lrgb = __builtin_amdgcn_udot4(rgba, 0x00070503u, 0u, false);
-                    sb = lrgb + 11u * (lo ? b5 : alpha);
-                    pb = lo ? rgba : pc_rgb; hb = lo ? kSymCodeAbs : (ph < kSymCodeRgb ? ph + kSymCodeRgb : ph);
-                }
-                const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
-                const uint32_t ndelta0 = lq[0], ninfo = lq[256];
-                const uint32_t pa = lo ? t_c : pc_rel, ha = lo ? t_m : ph, sa = lo ? b1 : s_rel;
-                pc = hi ? pb : pa;
-                ph = hi ? hb : ha;
-                slot = (hi ? sb : sa) & 63u;
-                // alpha after the chunk: RGBA sets it, INDEX takes the named entry's (hinted where it is still symbolic)
-                const uint32_t th = REFINE ? (uint32_t)s_hint[(t_m < kSymCodeRgb ? t_m : (t_m - kSymCodeRgb) & 0x7Fu) * 64u + lane] : alpha_in0;
-                const uint32_t ta = t_m == kSymCodeAbs ? (t_c >> 24) : th;
-                alpha = hi ? (lo ? b5 : alpha) : (lo ? ta : alpha);
-                const uint32_t wslot = (info & runmask) ? kSymParkRow : slot;
-                *(lds_u32*)(tc_base + (wslot << 8)) = pc;         // index update after every chunk (qoi.h:577)
-                *(lds_u8*)(tm_base + (wslot << 6)) = (uint8_t)ph;
-                pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
-                active = pos < end;
-            }
-        }
-    }
-    if (have) {
-        sym_t* dst = p.summary + (size_t)q * 65u;
-        for (uint32_t k = 0; k < 64u; ++k)
-            dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)sym_code_expand(*(const lds_u8*)(tm_base + k * 64u)) << 32);
-        dst[64] = (sym_t)pc | ((sym_t)sym_code_expand(ph) << 32);
-    }
-}
 
-// Reader ring and period of the paired kernels.  dec_segments_pair runs as fast with four pairs per CU as with five
-// (measured by padding its LDS: 2 / 3 / 4 / 5 pairs -> 2.82 / 2.14 / 1.70 / 1.80 ms), so the LDS of its fifth pair is
-// better spent on a period of 8 steps (32-dword stream ring, 8 KiB of records): half as many barriers, refills and
-// drains per chunk, -12 %.  dec_summarize_pair does use its fifth pair: it keeps the period of 4.
-typedef LaneReaderT<32, 4, 8> PairReader8;
-typedef LaneReader PairReader4;
-constexpr uint32_t kRecCtlMask = 0xC00001F8u;                  // chunk-table bits kept in a record: pixel count, op class
-constexpr uint32_t kRecSymMask = kRecCtlMask | kLutRunBit;     // dec_summarize_pair: + RUN flag; bits 9..14 carry the slot shift
-
-// The reader wavefront of a pair (dec_segments_pair, dec_summarize_pair): one record per chunk and lane.
-//   value word    byte-wise (dr,dg,db,0) of a relative chunk, LUMA's second byte included; r,g,b,a of QOI_OP_RGB / RGBA
-//   control word  bits 3..8 pixels, 30..31 op class (as in the chunk table), 16..21 the slot an INDEX names;
-//                 SYM: bit 15 RUN and bits 9..14 the slot shift of a relative chunk (QOI_COLOR_HASH is linear mod 64)
-// Runs until no lane has chunks left; the period in which that is noticed carries s_flag = 0.
-template <bool SYM, class READER>
-__device__ __forceinline__ void pair_reader(const DecParams& p, const DecImage& im, uint32_t ring_addr, uint32_t lut_base, uint32_t rec_base,
-                                            uint32_t* s_flag, uint32_t lane, uint32_t pos, uint32_t end, bool active) {
-    constexpr uint32_t kPairPeriod = READER::kPeriod;
-    READER R;
-    R.init(ring_addr, p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
-    uint32_t w32, b5; R.peek(pos, w32, b5);
-    uint32_t delta0, info;
-    {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); delta0 = lq[0]; info = lq[256]; }
-    for (uint32_t it = 0;; ++it) {
-        const bool any = lanes_where(active) != 0;
-        if (any) { R.land(); R.issue(pos); }
-        const uint32_t buf = rec_base + (it & 1u) * (kPairPeriod * 2u * 256u);
-#pragma unroll
-        for (uint32_t u = 0; u < kPairPeriod; ++u) {
-            const uint32_t c_info = active ? info : 0u, c_delta0 = active ? delta0 : 0u;
-            const uint32_t npos = pos + lut_len(c_info);                // null chunk: length 0
-            uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
-            const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
-            const uint32_t ndelta0 = lq[0], ninfo = lq[256];
-            // byte-wise delta of a relative chunk (qoi.h:561-572): table part + the second byte of a LUMA chunk
-            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)c_info, 28, 1);      // all ones for LUMA
-            const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
-            uint32_t v = c_delta0;
-            add_byte0(v, er); add_byte2_from0(v, eb);
-            if (lanes_where(lut_hi(c_info))) {        // some lane stands on QOI_OP_RGB / QOI_OP_RGBA: value word = r,g,b,a
-                const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);
-                v = lut_hi(c_info) ? rgba : v;
-            }
-            uint32_t ctl = (c_info & (SYM ? kRecSymMask : kRecCtlMask)) | ((w32 & 63u) << 16);
-            if (SYM) ctl |= ((lut_slot_shift(c_info) + 3u * er + 7u * eb) & 63u) << 9;
-            lds_u32* rq = (lds_u32*)(buf + u * 512u);
-            rq[0] = v; rq[64] = ctl;
-            pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
-            active = active && pos < end;
-        }
-        if (lane == 0) s_flag[it & 1u] = any ? 1u : 0u;
-        __syncthreads();
-        if (!any) break;
-    }
-}
-
-
-// P3 as a reader / summarizer pair of wavefronts (see dec_segments_pair, which comes later in this file, for the
-// scheme): the reader is the same function, the second wavefront keeps the symbolic tables.  dec_summarize ran at half
-// of the CU's instruction-issue rate with its six wavefronts per CU; a pair needs the tables once: ten per CU.
-template <bool REFINE>
-__global__ __launch_bounds__(128) void dec_summarize_pair(DecParams p) {
-    constexpr uint32_t kRows = REFINE ? 65u : 64u;                  // row 64: kSymParkRow (refinement rounds only)
-    typedef PairReader4 Reader;
-    constexpr uint32_t kPairPeriod = Reader::kPeriod;
-    constexpr uint32_t kRecDw = 2u * kPairPeriod * 2u * 64u;
-    __shared__ __attribute__((aligned(4096))) uint32_t s_ring[Reader::kSlots * 64];
-    __shared__ uint32_t s_tabc[kRows * 64];
-    __shared__ uint32_t s_rec[kRecDw];
-    __shared__ uint8_t s_tabm[kRows * 64];                          // source / mask codes, see sym_code_expand
-    __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 4];
-    __shared__ LdsLut s_lut;
-    __shared__ uint32_t s_flag[2];
-    const uint32_t lane = lane_id();
-    const bool reader = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
-    build_lut(s_lut, threadIdx.x, 128u);
-    const uint32_t q = blockIdx.x * 64u + lane;
-    bool have = q < p.total_segs;
-    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
-    const DecImage im = p.images[img];
-    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
-    have = have && j >= im.start_seg && j < im.n_active;
-    if (!lanes_where(have)) return;
-    const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
-    const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
-    const uint32_t pos0 = base + (have ? p.entry_phase[q] : 0u);
-    const uint32_t rec_base = lds_addr_of(&s_rec[lane]);
-    if (reader) {
-        pair_reader<true, Reader>(p, im, lds_addr_of(&s_ring[lane]), lds_addr_of(&s_lut.delta[0]), rec_base, s_flag, lane, pos0, end, have && pos0 < end);
-        return;
-    }
-    typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    const uint32_t tc_base = lds_addr_of(&s_tabc[lane]);             // slot k at + k*256
-    const uint32_t tm_base = lds_addr_of(&s_tabm[lane]);             // slot k at + k*64
-    // identity: slot k = entry slot k + 0, pixel = entry pixel + 0 (sym_init)
-    for (uint32_t k = 0; k < 64u; ++k) { *(lds_u32*)(tc_base + k * 256u) = 0u; *(lds_u8*)(tm_base + k * 64u) = (uint8_t)k; }
-    uint32_t pc = 0u, ph = 64u;                                       // ph: code of the running pixel (entry pixel, nothing absolute)
-    uint32_t slot, alpha;
-    if (REFINE) {
-        const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
-        uint32_t epx = 0;
-        if (have) {
-            for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {
-                uint32_t v[16];
-#pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) v[k] = ent[k0 + k];
-#pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) s_hint[(k0 + k) * 64u + lane] = (uint8_t)(v[k] >> 24);
-            }
-            epx = ent[64];
-            s_hint[64u * 64u + lane] = (uint8_t)(epx >> 24);
-        }
-        slot = hash_px(epx); alpha = epx >> 24;
-    } else {
-        slot = have ? p.slot_in[q] : 0u; alpha = have ? p.alpha_in[q] : 0u;
-    }
-    const uint32_t alpha_in0 = alpha;
-    const uint32_t runmask = (REFINE && j != 0u) ? kLutRunBit : 0u;      // see dec_summarize
-    for (uint32_t it = 0;; ++it) {
-        if (it > 0u) {
-            const uint32_t buf = rec_base + ((it - 1u) & 1u) * (kPairPeriod * 2u * 256u);
-            uint32_t rv[kPairPeriod], rc[kPairPeriod];
-#pragma unroll
-            for (uint32_t u = 0; u < kPairPeriod; ++u) { const lds_u32* rq = (const lds_u32*)(buf + u * 512u); rv[u] = rq[0]; rc[u] = rq[64]; }
-#pragma unroll
-            for (uint32_t u = 0; u < kPairPeriod; ++u) {
-                const uint32_t v = rv[u], ctl = rc[u];
-                const uint32_t idx = (ctl >> 16) & 63u;
-                const uint32_t t_c = *(const lds_u32*)(tc_base + (idx << 8));
-                const uint32_t t_m = *(const lds_u8*)(tm_base + (idx << 6));
-                uint32_t pc_rel = pc;
-                add_byte0(pc_rel, v); add_byte1(pc_rel, v); add_byte2(pc_rel, v);
-                const bool hi = lut_hi(ctl), lo = lut_lo(ctl);
-                const uint32_t s_rel = slot + ((ctl >> 9) & 63u);
-                uint32_t sb = 0, pb = 0, hb = 0;
-                if (lanes_where(hi)) {                    // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
-                    const uint32_t pc_rgb = (pc & 0xFF000000u) | (v & 0x00FFFFFFu);
-                    const uint32_t lrgb = __builtin_amdgcn_udot4(v, 0x00070503u, 0u, false);
-                    sb = lrgb + 11u * (lo ? (v >> 24) : alpha);
-                    pb = lo ? v : pc_rgb; hb = lo ? kSymCodeAbs : (ph < kSymCodeRgb ? ph + kSymCodeRgb : ph);
-                }
-                const uint32_t pa = lo ? t_c : pc_rel, ha = lo ? t_m : ph, sa = lo ? idx : s_rel;
-                pc = hi ? pb : pa;
-                ph = hi ? hb : ha;
-                slot = (hi ? sb : sa) & 63u;
-                // alpha after the chunk: RGBA sets it, INDEX takes the named entry's (hinted where it is still symbolic)
-                const uint32_t th = REFINE ? (uint32_t)s_hint[(t_m < kSymCodeRgb ? t_m : (t_m - kSymCodeRgb) & 0x7Fu) * 64u + lane] : alpha_in0;
-                const uint32_t ta = t_m == kSymCodeAbs ? (t_c >> 24) : th;
-                alpha = hi ? (lo ? (v >> 24) : alpha) : (lo ? ta : alpha);
-                const uint32_t wslot = (ctl & runmask) ? kSymParkRow : slot;
-                *(lds_u32*)(tc_base + (wslot << 8)) = pc;         // index update after every chunk (qoi.h:577)
-                *(lds_u8*)(tm_base + (wslot << 6)) = (uint8_t)ph;
-            }
-        }
-        __syncthreads();
-        if (s_flag[it & 1u] == 0u) break;
-    }
-    if (have) {
-        sym_t* dst = p.summary + (size_t)q * 65u;
-        for (uint32_t k = 0; k < 64u; ++k)
-            dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)sym_code_expand(*(const lds_u8*)(tm_base + k * 64u)) << 32);
-        dst[64] = (sym_t)pc | ((sym_t)sym_code_expand(ph) << 32);
-    }
-}
+// a lane's private 64-entry colour table in LDS, laid out [slot][lane]: a lane always hits its own bank
+struct LdsTab32 {
+    uint32_t* col;
+    __device__ __forceinline__ uint32_t get(uint32_t k) const { return col[k * 64u]; }
+    __device__ __forceinline__ void set(uint32_t k, uint32_t v) { col[k * 64u] = v; }
+};
 
 // ---------------------------------------------------------------------------------
 // S3: concrete (px, index[64]) at every segment entry.  lane = table slot; the pixel word is
@@ -1354,291 +947,6 @@ __global__ __launch_bounds__(64) void dec_chain_state_l3(DecParams p) {
                     p.entry + (size_t)(im.seg_base + lo) * 65u, lo == im.start_seg ? 1u : 0u);
 }
 
-// ---------------------------------------------------------------------------------
-// P4: genuine decode of every active segment + exit-state check (lane = segment)
-// ---------------------------------------------------------------------------------
-struct LdsTab32 {
-    uint32_t* col;
-    __device__ __forceinline__ uint32_t get(uint32_t k) const { return col[k * 64u]; }
-    __device__ __forceinline__ void set(uint32_t k, uint32_t v) { col[k * 64u] = v; }
-};
-
-// P4 main loop, written for few instructions per step: a wavefront of this kernel runs alone on its SIMD
-// most of the time (the 16 KiB of private colour tables per wavefront bound the residency), so its speed is
-// (instructions per step) x (~9 cycles).  The next chunk's bytes are fetched while the current one executes.
-template <int OCH>
-__global__ __launch_bounds__(64) void dec_segments(DecParams p) {
-    // One LDS block, carved by hand: colour tables at 0 (16 KiB), pixel ring at 16 KiB (4 KiB), stream ring behind
-    // it, chunk table last.  With the tables and rings on 16 KiB / 4 KiB boundaries their addresses are formed with
-    // an OR (the index bits of the base are clear), and the whole is 26 880 bytes: six wavefronts per CU.
-    constexpr uint32_t kTabDw = 64u * 64u, kOutDw = LaneWriter<OCH>::kRing * 64u, kRingDw = LaneReader::kSlots * 64u;
-    static_assert(kOutDw * 4u == 4096u, "pixel ring is one 4 KiB block");
-    __shared__ __attribute__((aligned(16384))) uint32_t s_mem[kTabDw + kOutDw + kRingDw + sizeof(LdsLut) / 4u];
-    uint32_t* const s_tab = s_mem;
-    uint32_t* const s_out = s_mem + kTabDw;
-    uint32_t* const s_ring = s_mem + kTabDw + kOutDw;
-    LdsLut& s_lut = *reinterpret_cast<LdsLut*>(s_mem + kTabDw + kOutDw + kRingDw);
-    const uint32_t lane = lane_id();
-    build_lut(s_lut, lane, 64u);
-    const uint32_t q = blockIdx.x * 64u + lane;
-    bool have = q < p.total_segs;
-    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
-    const DecImage im = p.images[img];
-    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
-    have = have && j >= im.start_seg && j < im.n_active;
-    if (!lanes_where(have)) return;
-    const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
-    const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
-    uint32_t pos = base + (have ? p.entry_phase[q] : 0u);
-    typedef LaneReader Reader;
-    Reader R;
-    R.init(lds_addr_of(&s_ring[lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes);
-    LaneWriter<OCH> W;
-    W.init(lds_addr_of(&s_out[lane]), p.pixels + (size_t)img * p.pixel_stride, have ? p.px_off[q] : 0u);
-    LdsTab32 tab{&s_tab[lane]};
-    const uint32_t tab_base = lds_addr_of(&s_tab[lane]);
-    const uint32_t lut_base = lds_addr_of(&s_lut.delta[0]);
-    const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
-    uint32_t px = 0;
-    if (have) {
-        for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {          // 16 loads in flight, then 16 LDS writes
-            uint32_t v[16];
-#pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k) v[k] = ent[k0 + k];
-#pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k) tab.set(k0 + k, v[k]);
-        }
-        px = ent[64];
-    }
-    const uint32_t limit = im.npx;
-    bool active = have && pos < end && W.ppos < limit;
-    constexpr uint32_t kLongRun = 12;
-    uint32_t w32, b5; R.peek(pos, w32, b5);
-    uint32_t delta0, info;
-    {   const lds_u32* lq = (const lds_u32*)(lut_base + (w32 & 0xFFu) * 4u); delta0 = lq[0]; info = lq[256]; }
-    // Blocks of kPeriod steps; per block: pixel stores first, then the next stream loads (see LaneWriter).
-    // Inside a step the LDS round trips are software-pipelined: the colour-table read of this chunk, the bytes
-    // of the next chunk and the next chunk's table entry are all in flight while this chunk's arithmetic runs
-    // (a wavefront is mostly alone on its SIMD here, nothing else hides the ~100-cycle LDS latency).
-    // Two copies of the loop: only a wavefront that holds a segment which may reach the image's pixel limit (the
-    // last active segment of an image, or one whose successor starts at the limit: truncated / over-long streams)
-    // pays for the clipping of every chunk's pixel count.
-    const bool clip_lane = have && (j + 1u >= im.n_active || p.px_off[q + 1u] >= limit);
-    auto run = [&](auto clip_tag) {
-        constexpr bool CLIP = decltype(clip_tag)::value;
-        while (lanes_where(active)) {
-            R.land();
-            R.issue(pos);
-            W.drain();
-    #pragma unroll
-            for (uint32_t u = 0; u < Reader::kPeriod; ++u) {
-                if (active) {
-                    // colour-table slot the tag byte may name (issued after the previous step's table write)
-                    const uint32_t t = *(const lds_u32*)(tab_base + ((w32 & 63u) << 8));
-                    const uint32_t npos = pos + QOIMI_STEP_LEN(w32 & 0xFFu, info);
-                    uint32_t nw32, nb5; R.peek(npos, nw32, nb5);
-                    // the ways a chunk sets the pixel that need no table (qoi.h:547-575)
-                    const uint32_t rel = apply_relative(px, w32, delta0, info);
-                    const bool hi = lut_hi(info), lo = lut_lo(info);
-                    const uint32_t npx = lut_pixels(info);
-                    uint32_t b = 0;
-                    if (lanes_where(hi)) {                       // some lane stands on QOI_OP_RGB / QOI_OP_RGBA (rare in natural images)
-                        const uint32_t rgba = __builtin_amdgcn_alignbit(b5, w32, 8);                 // r,g,b,a = chunk bytes 1..4
-                        const uint32_t rgbv = (px & 0xFF000000u) | (rgba & 0x00FFFFFFu);
-                        b = lo ? rgba : rgbv;
-                    }
-                    // next chunk's table entry
-                    const lds_u32* lq = (const lds_u32*)(lut_base + (nw32 & 0xFFu) * 4u);
-                    const uint32_t ndelta0 = lq[0], ninfo = lq[256];
-                    const uint32_t a = lo ? t : rel;
-                    px = hi ? b : a;
-                    // index[QOI_COLOR_HASH(px) % 64] = px after every chunk (qoi.h:577)
-                    const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
-                    *(lds_u32*)(tab_base + ((h & 63u) << 8)) = px;
-                    uint32_t rem = CLIP ? min(npx, limit - W.ppos) : npx;     // over-long run clipped (Appendix B item 8)
-                    pos = npos; w32 = nw32; b5 = nb5; delta0 = ndelta0; info = ninfo;
-                    // rem >= 1: the lane was below the pixel limit.  The first two pixels of a chunk go out in straight-line
-                    // code (in a natural image almost every step has SOME lane on a short QOI_OP_RUN, so the branch for
-                    // it was taken in every step: -6 % on photo content, +7 % on flat content whose steps all take the
-                    // rare path); the ring has room - W.drain() left <= 3 pixels, a period adds
-                    // <= 2 * kPeriod here, and the rare path below drains when it leaves more than 8 behind.
-                    W.put2(px, rem > 1u);
-                    rem -= rem > 1u ? 2u : 1u;
-                    if (rem) {                                                 // QOI_OP_RUN of three or more (qoi.h:573-575)
-                        if (rem >= kLongRun) W.splat(px, rem);
-                        while (rem) { W.put(px); --rem; }
-                        if (W.ppos - W.fpos > LaneWriter<OCH>::kRing - 2u * Reader::kPeriod) W.drain();
-                    }
-                    active = pos < end && (!CLIP || W.ppos < limit);
-                }
-            }
-        }
-    };
-    if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
-    if (have) {
-        W.finish();
-        if (j + 1u < im.n_active) {
-            // exit state must equal what the next segment was started from
-            const uint32_t* __restrict__ nxt = ent + 65u;
-            bool same = nxt[64] == px;
-            for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {
-                uint32_t v[16];
-#pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) v[k] = nxt[k0 + k];
-#pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) same = same && (v[k] == tab.get(k0 + k));
-            }
-            if (!same) {
-                uint32_t* fx = p.fix + (size_t)(q + 1u) * 65u;
-                for (uint32_t k = 0; k < 64u; ++k) fx[k] = tab.get(k);
-                fx[64] = px;
-                atomicMin(&p.first_bad[img], j + 1u);
-            }
-        } else {
-            p.images[img].final_px = px;     // pixel repeated when the stream ends early (qoi.h:544)
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// P4 as a pair of wavefronts per 64 segments (one workgroup of 128 threads).  dec_segments is bound by the
-// instructions one wavefront retires (about 100 per chunk step at one instruction per ~9 cycles, with only six
-// wavefronts per CU because of the private colour tables).  The step splits cleanly where no pixel state is needed:
-//   wavefront 0, the reader:   walks the chunk boundaries, fetches bytes, looks up the chunk table and writes one
-//                              two-word record per chunk and lane into LDS - value word (byte-wise delta, or r,g,b,a
-//                              of an RGB / RGBA chunk) and control word (pixel count, op class, slot an INDEX names);
-//   wavefront 1, the decoder:  owns the colour tables and the pixel ring; turns records into pixels.
-// The two run on different SIMDs, each retires about half the instructions, and a pair needs the tables once: ten
-// wavefronts per CU instead of six (eight with the longer period, see PairReader8).  They meet at one barrier per period (records are double
-// buffered: the reader fills period i while the decoder works off period i - 1).  A lane that is through with its
-// segment emits null records (no pixels, delta 0), so neither loop masks lanes off.
-// ---------------------------------------------------------------------------------
-template <int OCH>
-__global__ __launch_bounds__(128) void dec_segments_pair(DecParams p) {
-    typedef PairReader8 Reader;
-    constexpr uint32_t kPairPeriod = Reader::kPeriod;
-    constexpr uint32_t kTabDw = 64u * 64u, kOutDw = LaneWriter<OCH>::kRing * 64u, kRingDw = Reader::kSlots * 64u;
-    constexpr uint32_t kRecDw = 2u * kPairPeriod * 2u * 64u;          // two buffers x steps x two words x lanes
-    static_assert(kOutDw * 4u == 4096u, "pixel ring is one 4 KiB block");
-    __shared__ __attribute__((aligned(16384))) uint32_t s_mem[kTabDw + kOutDw + kRingDw + kRecDw + sizeof(LdsLut) / 4u + 2u];
-    uint32_t* const s_tab = s_mem;
-    uint32_t* const s_out = s_mem + kTabDw;
-    uint32_t* const s_ring = s_mem + kTabDw + kOutDw;
-    uint32_t* const s_rec = s_mem + kTabDw + kOutDw + kRingDw;
-    LdsLut& s_lut = *reinterpret_cast<LdsLut*>(s_mem + kTabDw + kOutDw + kRingDw + kRecDw);
-    uint32_t* const s_flag = s_mem + kTabDw + kOutDw + kRingDw + kRecDw + sizeof(LdsLut) / 4u;
-    const uint32_t lane = lane_id();
-    const bool reader = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
-    build_lut(s_lut, threadIdx.x, 128u);                                // includes a barrier
-    const uint32_t q = blockIdx.x * 64u + lane;
-    bool have = q < p.total_segs;
-    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
-    const DecImage im = p.images[img];
-    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
-    have = have && j >= im.start_seg && j < im.n_active;
-    if (!lanes_where(have)) return;                                     // same answer in both wavefronts
-    const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
-    const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
-    const uint32_t pos0 = base + (have ? p.entry_phase[q] : 0u);
-    const uint32_t limit = im.npx;
-    const uint32_t rec_base = lds_addr_of(&s_rec[lane]);               // record (buffer b, step u, word w) at + ((b*P + u)*2 + w)*256
-
-    if (reader) {                                                       // wavefront 0: chunk records
-        pair_reader<false, Reader>(p, im, lds_addr_of(&s_ring[lane]), lds_addr_of(&s_lut.delta[0]), rec_base, s_flag, lane, pos0, end,
-                           have && pos0 < end && (have ? p.px_off[q] : 0u) < limit);
-        return;
-    }
-
-    // ---------------------------------------------------------------------- wavefront 1: pixels
-    LaneWriter<OCH> W;
-    W.init(lds_addr_of(&s_out[lane]), p.pixels + (size_t)img * p.pixel_stride, have ? p.px_off[q] : 0u);
-    LdsTab32 tab{&s_tab[lane]};
-    const uint32_t tab_base = lds_addr_of(&s_tab[lane]);
-    const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
-    uint32_t px = 0;
-    if (have) {
-        for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {          // 16 loads in flight, then 16 LDS writes
-            uint32_t v[16];
-#pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k) v[k] = ent[k0 + k];
-#pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k) tab.set(k0 + k, v[k]);
-        }
-        px = ent[64];
-    }
-    constexpr uint32_t kLongRun = 12;
-    const bool clip_lane = have && (j + 1u >= im.n_active || p.px_off[q + 1u] >= limit);
-    auto run = [&](auto clip_tag) {
-        constexpr bool CLIP = decltype(clip_tag)::value;
-        for (uint32_t it = 0;; ++it) {
-            if (it > 0u) {
-                W.drain();
-                const uint32_t buf = rec_base + ((it - 1u) & 1u) * (kPairPeriod * 2u * 256u);
-                uint32_t rv[kPairPeriod], rc[kPairPeriod];
-#pragma unroll
-                for (uint32_t u = 0; u < kPairPeriod; ++u) { const lds_u32* rq = (const lds_u32*)(buf + u * 512u); rv[u] = rq[0]; rc[u] = rq[64]; }
-#pragma unroll
-                for (uint32_t u = 0; u < kPairPeriod; ++u) {
-                    if (u != 0u && (u & 3u) == 0u) W.drain();            // the 16-pixel ring takes four steps' worth (see put2n)
-                    const uint32_t v = rv[u], ctl = rc[u];
-                    const uint32_t t = *(const lds_u32*)(tab_base + ((ctl >> 8) & 0x3F00u));     // slot an INDEX names
-                    uint32_t rel = px;
-                    add_byte0(rel, v); add_byte1(rel, v); add_byte2(rel, v);
-                    const bool hi = lut_hi(ctl), lo = lut_lo(ctl);
-                    uint32_t b = 0;
-                    if (lanes_where(hi)) {                   // QOI_OP_RGB keeps the alpha, QOI_OP_RGBA sets it (qoi.h:548-557)
-                        const uint32_t rgbv = (px & 0xFF000000u) | (v & 0x00FFFFFFu);
-                        b = lo ? v : rgbv;
-                    }
-                    const uint32_t a = lo ? t : rel;
-                    uint32_t npxl = hi ? b : a;
-                    if (CLIP) npxl = W.ppos < limit ? npxl : px;             // at the pixel limit the decoder has stopped (qoi.h:540)
-                    px = npxl;
-                    // index[QOI_COLOR_HASH(px) % 64] = px after every chunk (qoi.h:577)
-                    const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
-                    *(lds_u32*)(tab_base + ((h & 63u) << 8)) = px;
-                    uint32_t rem = lut_pixels(ctl);                           // 0: null record
-                    if (CLIP) rem = min(rem, limit - W.ppos);                 // over-long run clipped (Appendix B item 8)
-                    const uint32_t n2 = min(rem, 2u);
-                    W.put2n(px, n2);
-                    rem -= n2;
-                    if (rem) {                                                 // QOI_OP_RUN of three or more (qoi.h:573-575)
-                        if (rem >= kLongRun) W.splat(px, rem);
-                        while (rem) { W.put(px); --rem; }
-                        if (W.ppos - W.fpos > LaneWriter<OCH>::kRing - 2u * 4u) W.drain();
-                    }
-                }
-            }
-            __syncthreads();
-            if (s_flag[it & 1u] == 0u) break;
-        }
-    };
-    if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
-    if (have) {
-        W.finish();
-        if (j + 1u < im.n_active) {
-            // exit state must equal what the next segment was started from
-            const uint32_t* __restrict__ nxt = ent + 65u;
-            bool same = nxt[64] == px;
-            for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {
-                uint32_t v[16];
-#pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) v[k] = nxt[k0 + k];
-#pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) same = same && (v[k] == tab.get(k0 + k));
-            }
-            if (!same) {
-                uint32_t* fx = p.fix + (size_t)(q + 1u) * 65u;
-                for (uint32_t k = 0; k < 64u; ++k) fx[k] = tab.get(k);
-                fx[64] = px;
-                atomicMin(&p.first_bad[img], j + 1u);
-            }
-        } else {
-            p.images[img].final_px = px;     // pixel repeated when the stream ends early (qoi.h:544)
-        }
-    }
-}
-
 // =====================================================================================
 // Chunk records (qoi_decode_core.h "Chunk RECORDS"): dec_transcode writes them once, dec_summarize_rec (P3) and
 // dec_segments_rec (P4) read them.
@@ -1734,7 +1042,7 @@ struct LdsLutT { uint32_t tpl[260], info[260]; };   // record template; chunk-ta
 
 // Parse + P2 + transcode: lane = segment.  Walks every chunk that starts in the segment, writes the chunk records of the
 // segment as 16-byte granules (row g of the wavefront's block, null-padded), counts the pixels and leaves the speculative
-// slot/alpha transfer (slot_rec, same function as dec_slot_walk).  A QOI_OP_RGBA chunk is visited in two consecutive steps
+// slot/alpha transfer (slot_rec).  A QOI_OP_RGBA chunk is visited in two consecutive steps
 // (stash record, alpha record); only the second advances the cursor.
 //
 // MODE 0 - where does the segment's first chunk start?  Chunk length is a function of the first byte (qoi.h:547-575), so
@@ -2563,13 +1871,12 @@ __global__ __launch_bounds__(64) void dec_prepare_restart(DecParams p) {
 void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
     tm->mark(kT_begin, st);
     if (p.total_segs) {
-        if (p.use_rec && !p.sync_all) {
+        if (!p.sync_all) {
             // parse + transcode in one walk (dec_transcode<0>); the five-phase parse only for the segments it flags
             hipLaunchKernelGGL(dec_transcode<0>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
             tm->mark(kT_dec_slot_walk, st);
-            hipLaunchKernelGGL(dec_parse_fine<false>, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
-        } else if (p.fine_per_seg) hipLaunchKernelGGL(dec_parse_fine<true>, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(dec_parse, dim3((p.total_segs + 255u) / 256u), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(dec_parse_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+        } else hipLaunchKernelGGL(dec_parse, dim3((p.total_segs + 255u) / 256u), dim3(256), 0, st, p);   // segment sizes without the piece parse: every segment
         tm->mark(kT_dec_parse, st);
         hipLaunchKernelGGL(dec_chain_parse_l1, dim3(p.total_grps), dim3(64), 0, st, p);
     }
@@ -2581,7 +1888,7 @@ void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
 
 void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipStream_t st, KernelTimer* tm) {
     if (!p.total_segs) return;
-    const uint32_t b256 = (p.total_segs + 255u) / 256u, b64 = (p.total_segs + 63u) / 64u;
+    const uint32_t b64 = (p.total_segs + 63u) / 64u;
     tm->mark(kT_begin, st);
     auto chain_state = [&]() {
         hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
@@ -2596,30 +1903,23 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
         // stretches: 13 rounds, each with a P4 over every open segment).  P3 + S3 are a fraction of P4 on such streams.
         const uint32_t inner = p.refine_inner ? p.refine_inner : 1u;
         for (uint32_t it = 0; it < inner; ++it) {
-            if (p.use_rec) hipLaunchKernelGGL(dec_summarize_rec<true>, dim3(b64), dim3(64), 0, st, p);
-            else if (p.pair & 2u) hipLaunchKernelGGL(dec_summarize_pair<true>, dim3(b64), dim3(128), 0, st, p);
-            else hipLaunchKernelGGL(dec_summarize<true>, dim3(b64), dim3(64), 0, st, p);
+            hipLaunchKernelGGL(dec_summarize_rec<true>, dim3(b64), dim3(64), 0, st, p);
             tm->mark(kT_dec_summarize, st);
             if (it + 1u < inner) chain_state();
         }
     } else {
-    if (p.use_rec) {
         hipLaunchKernelGGL(dec_transcode<1>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
         hipLaunchKernelGGL(dec_slot_tails, dim3(b64), dim3(64), 0, st, p);
-    } else if (p.fine_per_seg) hipLaunchKernelGGL(dec_slot_heads_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(dec_slot_walk, dim3(b256), dim3(256), 0, st, p);
-    tm->mark(kT_dec_slot_walk, st);
-    hipLaunchKernelGGL(dec_chain_slots_l1, dim3(p.total_grps), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(dec_chain_slots_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
-    hipLaunchKernelGGL(dec_chain_slots_l3, dim3(p.total_grps), dim3(64), 0, st, p);
-    tm->mark(kT_dec_chain_slots, st);
-    if (p.use_rec) hipLaunchKernelGGL(dec_summarize_rec<false>, dim3(b64), dim3(64), 0, st, p);
-    else if (p.pair & 2u) hipLaunchKernelGGL(dec_summarize_pair<false>, dim3(b64), dim3(128), 0, st, p);
-    else hipLaunchKernelGGL(dec_summarize<false>, dim3(b64), dim3(64), 0, st, p);
-    tm->mark(kT_dec_summarize, st);
+        tm->mark(kT_dec_slot_walk, st);
+        hipLaunchKernelGGL(dec_chain_slots_l1, dim3(p.total_grps), dim3(64), 0, st, p);
+        hipLaunchKernelGGL(dec_chain_slots_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
+        hipLaunchKernelGGL(dec_chain_slots_l3, dim3(p.total_grps), dim3(64), 0, st, p);
+        tm->mark(kT_dec_chain_slots, st);
+        hipLaunchKernelGGL(dec_summarize_rec<false>, dim3(b64), dim3(64), 0, st, p);
+        tm->mark(kT_dec_summarize, st);
     }
     chain_state();
-    if (!refine && p.use_rec && p.first_inner) {
+    if (!refine && p.first_inner) {
         // Flat images (dec_image_is_flat): their first round nearly always fails at the second or third segment - P2's guess
         // "an INDEX chunk leaves the alpha as it is" is wrong where alpha levels go through the colour table - and a round's P4
         // rewrites every pixel.  A few refinement passes from the speculated entry states settle most of them before it
@@ -2632,14 +1932,8 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
             chain_state();
         }
     }
-    if (p.use_rec) {
-        if (out_channels == 4) hipLaunchKernelGGL(dec_segments_rec<4>, dim3(b64), dim3(64), 0, st, p);
-        else hipLaunchKernelGGL(dec_segments_rec<3>, dim3(b64), dim3(64), 0, st, p);
-    } else if (p.pair & 1u) {
-        if (out_channels == 4) hipLaunchKernelGGL(dec_segments_pair<4>, dim3(b64), dim3(128), 0, st, p);
-        else hipLaunchKernelGGL(dec_segments_pair<3>, dim3(b64), dim3(128), 0, st, p);
-    } else if (out_channels == 4) hipLaunchKernelGGL(dec_segments<4>, dim3(b64), dim3(64), 0, st, p);
-    else hipLaunchKernelGGL(dec_segments<3>, dim3(b64), dim3(64), 0, st, p);
+    if (out_channels == 4) hipLaunchKernelGGL(dec_segments_rec<4>, dim3(b64), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(dec_segments_rec<3>, dim3(b64), dim3(64), 0, st, p);
     tm->mark(kT_dec_segments, st);
     hipLaunchKernelGGL(dec_prepare_restart, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_dec_restart, st);

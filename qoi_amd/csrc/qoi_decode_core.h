@@ -22,7 +22,7 @@
 //
 // Exactness never rests on the speculation: if every check passes, induction over the
 // segments shows the output equals the sequential decoder's; a failed check restarts
-// the chain at that segment from the true exit state (host loop in qoi_host.cpp).
+// the chain at that segment from the true exit state (host loop in qoi_host.hip).
 //
 // The functions are plain sequential code, compiled for the device by hipcc and — by
 // tests/host/decode_host.cpp only — for the host, so their logic is unit-tested on CPU

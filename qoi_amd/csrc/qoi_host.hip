@@ -99,10 +99,9 @@ struct qoimi_ctx {
     std::string enc_debug_dump;         // env QOIMI_ENC_DEBUG_DUMP: file that receives the entry-state arrays of every encode call
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
-    int dec_pair = 3;                   // bit 0: P4, bit 1: P3 run as reader / worker wavefront pairs; 0: one wavefront per 64 segments
+    int dec_p3_plain = 1, dec_inner = 4, dec_inner1 = 3;   // env QOIMI_P3_PLAIN, QOIMI_DEC_INNER, QOIMI_DEC_INNER1 (read once, at creation)
     int dec_max_rounds = kMaxSpecRounds;   // speculation rounds before the sequential last resort (env QOIMI_DEC_MAX_ROUNDS, tests)
     long long dec_seq_images = 0;       // images finished by dec_sequential since the context was created
-    int dec_rec = 1;                    // 1: chunk records (dec_transcode + dec_summarize_rec + dec_segments_rec); 0: the round-1 byte-stream passes
     size_t dec_rec_cap = (size_t)16 << 30;   // largest record arena: a call whose streams need more is decoded in sub-batches
     KernelTimer timer;                  // optional per-kernel HIP-event timing
     double prof_ms[kT_count] = {0};     // accumulated kernel milliseconds since profiling was (re)enabled
@@ -150,8 +149,9 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
-    if (const char* e = getenv("QOIMI_DEC_PAIR")) c->dec_pair = atoi(e);
-    if (const char* e = getenv("QOIMI_DEC_REC")) c->dec_rec = atoi(e);
+    if (const char* e = getenv("QOIMI_P3_PLAIN")) c->dec_p3_plain = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_INNER")) c->dec_inner = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_INNER1")) c->dec_inner1 = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
     if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
     if (const char* e = getenv("QOIMI_SEG_BYTES")) {
@@ -405,16 +405,14 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     memset(&p, 0, sizeof p);
     p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
-    p.pair = (uint32_t)c->dec_pair & 3u;
-    p.use_rec = c->dec_rec ? 1u : 0u;
     p.rec_rows = rec_region_dwords(B) / 4u;
     p.sync_all = 0;
-    p.p3_plain = getenv("QOIMI_P3_PLAIN") ? (uint32_t)atoi(getenv("QOIMI_P3_PLAIN")) : 1u;
-    p.refine_inner = getenv("QOIMI_DEC_INNER") ? (uint32_t)atoi(getenv("QOIMI_DEC_INNER")) : 4u;
+    p.p3_plain = (uint32_t)c->dec_p3_plain;
+    p.refine_inner = (uint32_t)c->dec_inner;
     {   // extra first-round passes only if the call holds a flat image at all
         bool any_flat = false;
         for (int i = 0; i < n_images && !any_flat; ++i) any_flat = sizes[i] > 22 && dec_image_is_flat((uint32_t)sizes[i] - 8u, descs[i].width * descs[i].height);
-        p.first_inner = any_flat ? (getenv("QOIMI_DEC_INNER1") ? (uint32_t)atoi(getenv("QOIMI_DEC_INNER1")) : 3u) : 0u;
+        p.first_inner = any_flat ? (uint32_t)c->dec_inner1 : 0u;
     }
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
     const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
@@ -425,16 +423,13 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.fine_shift = 0;
         while (ok && (1u << p.fine_shift) < g) ++p.fine_shift;
         if ((uint64_t)total * (p.fine_per_seg ? p.fine_per_seg : 1u) > 0xFFFFFF00ull) return fail(QOIMI_E_ARG, "batch too large (piece index overflows 32 bits)");
-        p.sync_all = (p.use_rec && !p.fine_per_seg) ? 1u : 0u;     // no piece parse for this segment size: full parse, then transcode from S1's phases
+        p.sync_all = p.fine_per_seg ? 0u : 1u;     // no piece parse for this segment size: full parse, then transcode from S1's phases
     }
     for (int pass = 0; pass < 2; ++pass) {
         Carver w(pass ? c->dec_ws.base : nullptr);
         p.pending = w.take<uint32_t>(4); p.redo_segs = p.pending ? p.pending + 1 : nullptr; p.sync_fails = p.pending ? p.pending + 2 : nullptr;
         p.images = w.take<DecImage>((size_t)n_images);
         p.first_bad = w.take<uint32_t>((size_t)n_images);
-        p.fine_exit = w.take<uint16_t>(p.fine_per_seg ? Q * p.fine_per_seg : 1);
-        p.fine_tail = w.take<uint32_t>(p.fine_per_seg ? Q * p.fine_per_seg : 1);
-        p.fine_moff = w.take<uint8_t>(p.fine_per_seg ? Q * p.fine_per_seg : 1);
         p.parse = w.take<ParseRec>(Q); p.entry_phase = w.take<uint8_t>(Q); p.px_off = w.take<uint32_t>(Q);
         p.slot_rec = w.take<SlotRec>(Q); p.slot_in = w.take<uint8_t>(Q); p.alpha_in = w.take<uint8_t>(Q);
         p.summary = w.take<u64>(Q * 65); p.entry = w.take<uint32_t>(Q * 65); p.fix = w.take<uint32_t>(Q * 65);
@@ -442,9 +437,9 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.grp_parse = w.take<ParseRec>(NG); p.grp_phase = w.take<uint8_t>(NG); p.grp_off = w.take<uint32_t>(NG);
         p.grp_slot = w.take<SlotRec>(NG); p.grp_slot_in = w.take<uint8_t>(NG); p.grp_alpha_in = w.take<uint8_t>(NG);
         p.grp_summary = w.take<u64>(NG * 65); p.grp_entry = w.take<uint32_t>(NG * 65);
-        p.rec_gran = w.take<uint32_t>(p.use_rec ? Q : 1);
-        p.sync_fail = w.take<uint8_t>(p.use_rec ? Q : 1);
-        p.recs = w.take<uint32_t>(p.use_rec ? ((Q + 63u) / 64u) * p.rec_rows * 256u : 4);
+        p.rec_gran = w.take<uint32_t>(Q);
+        p.sync_fail = w.take<uint8_t>(Q);
+        p.recs = w.take<uint32_t>(((Q + 63u) / 64u) * p.rec_rows * 256u);
         if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }
     }
     {   // image table through pinned staging: no synchronisation (every decode call ends with one, so the
@@ -476,7 +471,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         HIP_TRY(hipStreamSynchronize(st));
         timer_collect(c);
         if (c->host_word[0] == 0) break;
-        if (p.use_rec && rounds >= c->dec_max_rounds) {
+        if (rounds >= c->dec_max_rounds) {
             // bounded: whatever is still open is finished by the linear sequential pass (see dec_sequential)
             launch_decode_sequential(p, och, st, &c->timer);
             launch_decode_fill(p, och, st, &c->timer);
@@ -485,7 +480,6 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
             stats_seq = (long long)c->host_word[0];
             break;
         }
-        if (rounds > (long long)total + 2) return fail(QOIMI_E_INTERNAL, "decode repair loop did not converge");
     }
     HIP_TRY(hipGetLastError());
     timer_collect(c);
@@ -507,7 +501,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     const uint32_t B = choose_seg_bytes(c, sizes, n_images);
     // The chunk records take four bytes per stream byte (worst case) while a call is in flight.  Calls whose streams would
     // need more than dec_rec_cap are decoded as consecutive sub-batches of whole images through the same workspace.
-    const uint64_t cap_stream = c->dec_rec ? (uint64_t)(c->dec_rec_cap / 4u) - (uint64_t)(c->dec_rec_cap / 4u) / 64u : ~0ull;
+    const uint64_t cap_stream = (uint64_t)(c->dec_rec_cap / 4u) - (uint64_t)(c->dec_rec_cap / 4u) / 64u;
     long long acc[4] = {0, 0, 0, 0};
     for (int first = 0; first < n_images;) {
         uint64_t bytes = 0;

@@ -105,15 +105,10 @@ struct DecParams {
     DecImage* images;      // device array [n_images]
     uint32_t n_images, total_segs, total_grps, seg_bytes;
     uint32_t fine_per_seg, fine_shift;   // 128-byte pieces per segment for P1/P2 (8..64, power of two), 0: lane per segment
-    uint32_t pair;                       // bit 0: P4, bit 1: P3 as reader / worker wavefront pairs (dec_segments_pair, dec_summarize_pair)
-    uint32_t use_rec;                    // 1: chunk records - dec_transcode writes them once, P3 / P4 read them (dec_summarize_rec, dec_segments_rec)
     uint32_t rec_rows;                   // granules (4 records) reserved per segment: rec_region_dwords(seg_bytes) / 4
     uint32_t* recs;                      // chunk records (qoi_decode_core.h), [block of 64 segments][granule row][lane = segment & 63] x 16 bytes:
                                          // a wavefront's granule row is one contiguous KiB - every record load / store is fully coalesced
     uint32_t* rec_gran;                  // [total_segs + 1] granules (4 records) written per segment
-    uint16_t* fine_exit;       // P1 fine: exit-phase map of every piece [total_segs * fine_per_seg]
-    uint32_t* fine_tail;       // P1 fine: packed slot transfer of the piece from the chains' meeting point on
-    uint8_t*  fine_moff;       // P1 fine: offset of the meeting point in the piece, 255: the chains never met
     uint8_t* pixels; size_t pixel_stride;
     // workspace, per global segment q
     ParseRec* parse;           // P1
@@ -149,7 +144,7 @@ struct DecParams {
 void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm);
 void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipStream_t st, KernelTimer* tm);
 void launch_decode_fill(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);
-void launch_decode_sequential(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);   // record pipeline only
+void launch_decode_sequential(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);
 constexpr int kMaxSpecRounds = 24;   // speculation rounds before the images still open are finished sequentially
 
 // ---- synthetic frames --------------------------------------------------------------

@@ -257,13 +257,9 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_PROBE": "0"},                             # order-independent colour-table probe (ds_or masks)
     {"QOIMI_DEC_FINE": "0", "QOIMI_SEG_BYTES": "2048"},   # lane-per-segment P1/P2 instead of 128-byte pieces
     {"QOIMI_SEG_BYTES": "1024"},                          # P1/P2 on 8 pieces per segment
-    {"QOIMI_DEC_PAIR": "0"},                              # P3/P4 by one wavefront per 64 segments instead of reader/worker pairs
-    {"QOIMI_DEC_PAIR": "1"},                              # P4 paired, P3 single
     {"QOIMI_SEG_BYTES": "128"},                           # the piece is the segment (single-frame calls choose this)
     {"QOIMI_SEG_BYTES": "512"},                           # lane-per-segment P1/P2 (4 pieces: no piece path)
     {"QOIMI_DEC_REFINE": "0", "QOIMI_SEG_BYTES": "2048"},  # repair rounds without alpha hints
-    {"QOIMI_DEC_REC": "0"},                               # round-1 byte-stream passes instead of the chunk-record pipeline
-    {"QOIMI_DEC_REC": "0", "QOIMI_SEG_BYTES": "2048"},
     {"QOIMI_DEC_REC_CAP_MB": "1"},                        # record arena capped at 1 MiB: the batch is decoded in sub-batches
     {"QOIMI_SEG_BYTES": "320"},                           # a segment size without the 128-byte piece parse: full parse, transcode from S1's phases
     {"QOIMI_P3_PLAIN": "0"},                              # P3 on records in its general form from the first chunk on

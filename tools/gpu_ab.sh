@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of environment knobs inside ONE gpurun call (boxes differ by several per cent): parity tests once, then the bench per arm.
-# usage: ARMS="rec:QOIMI_DEC_REC=1;old:QOIMI_DEC_REC=0" BENCH_ARGS="--frames 64" KINDS="photo" bash tools/gpu_ab.sh name
+# usage: ARMS="b2k:QOIMI_SEG_BYTES=2048;b1k:QOIMI_SEG_BYTES=1024" BENCH_ARGS="--frames 64" KINDS="photo" bash tools/gpu_ab.sh name
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out/${1:-ab}; mkdir -p $OUT; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 if [ "${DO_TESTS:-1}" = 1 ]; then
   timeout 900 python -m pytest tests -m gpu -x -q --timeout 600 ${PYTEST_ARGS:-} > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log; tail -12 $OUT/pytest.log
