@@ -33,6 +33,7 @@ EXPORTS = (
     "qoimi_ctx_create", "qoimi_ctx_destroy", "qoimi_last_error", "qoimi_encode_bound",
     "qoimi_encode_batch", "qoimi_encode_status", "qoimi_decode_batch", "qoimi_synth_frames",
     "qoimi_decode_stats", "qoimi_version", "qoimi_set_profiling", "qoimi_get_profile", "qoimi_kernel_name",
+    "qoimi_encode_suspect_calls",
 )
 
 

@@ -813,7 +813,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 // flagged.  A workgroup serves unit u = (image u % n_images, four consecutive sets u / n_images) so that the
 // sets in flight spread over all images.
 template <int CH, int PROBE, int ENTRY>
-__global__ __launch_bounds__(256, 5) void enc_sets(EncParams p) {
+__global__ __launch_bounds__(256, PROBE == 1 ? 5 : 4) void enc_sets(EncParams p) {
     __shared__ EncLds<PROBE> s_lds[4];
     __shared__ uint32_t s_ticket[2];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();

@@ -77,3 +77,16 @@ def test_python_wrapper_rejects_short_buffers():
     short = np.zeros(100, dtype=np.uint8)
     assert api.qoi_encode(short, api.QoiDesc(64, 64, 4, 0)) is None
     assert api.qoi_write("/tmp/qoi_mi355x_never_written.qoi", short, api.QoiDesc(64, 64, 3, 0)) == 0
+
+
+def test_no_stdio_flavour_lacks_the_file_functions():
+    """qoi.h:51-58,592: a build with QOI_NO_STDIO has no qoi_write / qoi_read.  `make -C qoi_amd/csrc NO_STDIO=1` (run by
+    __graft_entry__.build()) gives libqoi_mi355x_nostdio.so: qoi_encode / qoi_decode and the device API, nothing of stdio."""
+    import subprocess
+    path = os.path.join(ROOT, "qoi_amd", "lib", "libqoi_mi355x_nostdio.so")
+    if not os.path.exists(path):
+        pytest.skip("libqoi_mi355x_nostdio.so not built")
+    syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    names = {l.split()[-1] for l in syms.splitlines() if l.strip()}
+    assert {"qoi_encode", "qoi_decode", "qoimi_encode_batch", "qoimi_decode_batch"} <= names
+    assert not ({"qoi_write", "qoi_read"} & names)
