@@ -51,12 +51,20 @@ __device__ __forceinline__ uint32_t load_px_at(const uint8_t* __restrict__ q, in
 
 __device__ __forceinline__ int msb64(u64 m) { return 63 - __builtin_clzll(m); }
 
-// sum of v over lanes 0..stop (stop >= 63: all lanes)
-__device__ __forceinline__ u64 wave_sum64_upto(u64 v, uint32_t lane, int stop) {
-    u64 x = ((int)lane <= stop) ? v : 0ull;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+// sum of v over lanes 0..stop (stop >= 63: all lanes), the same value for every lane.  Seven DPP adds: within the rows of 16
+// lanes (row_shr 1, 2, 3, then 4 and 8 on the banks that have such a neighbour), then row_bcast 15 / 31 carry the row totals
+// upwards; lane 63 holds the total.
+__device__ __forceinline__ uint32_t wave_sum32_upto(uint32_t v, uint32_t lane, int stop) {
+    const int v0 = (int)lane <= stop ? (int)v : 0;
+    int s = v0;
+    s += __builtin_amdgcn_update_dpp(0, v0, 0x111, 0xf, 0xf, true);      // row_shr:1
+    s += __builtin_amdgcn_update_dpp(0, v0, 0x112, 0xf, 0xf, true);      // row_shr:2
+    s += __builtin_amdgcn_update_dpp(0, v0, 0x113, 0xf, 0xf, true);      // row_shr:3   -> sums of 4
+    s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xe, true);       // row_shr:4, banks 1..3 -> sums of 8
+    s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xc, true);       // row_shr:8, banks 2..3 -> lane 15 of a row: the row's sum
+    s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, true);       // row_bcast:15 into rows 1 and 3
+    s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, true);       // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane(s, 63);
 }
 
 // ---------------------------------------------------------------------------------
@@ -200,7 +208,13 @@ __global__ __launch_bounds__(64) void enc_scan_images(EncParams p) {
 // moves them to their place itself after the look-back.
 constexpr int kGroupSteps = 8;                          // steps whose pixels are loaded together (one register group)
 constexpr uint32_t kGroupPx = 64u * kGroupSteps;
-constexpr uint32_t kStageBytes = 7424u;                 // staging buffer of a wavefront
+#ifndef QOIMI_ENC_STAGE_BYTES
+#define QOIMI_ENC_STAGE_BYTES 6336
+#endif
+#ifndef QOIMI_ENC_WAVES_PER_SIMD
+#define QOIMI_ENC_WAVES_PER_SIMD 6
+#endif
+constexpr uint32_t kStageBytes = QOIMI_ENC_STAGE_BYTES; // staging buffer of a wavefront (6 workgroups of 4 per CU: 4 x 6656 x 6 = 156 KB of LDS)
 constexpr uint32_t kStageSpill = kStageBytes - kGroupSteps * 320u - 16u;   // more staged bytes than this before a group: spill first
 
 template <int PROBE>
@@ -487,8 +501,8 @@ __device__ __forceinline__ void load_pair_guarded(const uint8_t* __restrict__ pi
 
 // Everything a set reads from global memory before its first step besides its first group of pixels.
 struct SetIn {
-    uint32_t warm[8];            // ENTRY 1: the 512 pixels before the set (step k: pixels lo-64(k+1) .. +63), and the one before them
-    uint32_t warm_carry;
+    uint32_t warm[8];            // ENTRY 1: the 512 pixels before the set (step k: pixels lo-64(k+1) .. +63) ...
+    uint32_t warm_prev[8];       // ... and the pixel before each of them
     uint32_t tab_loc, tab_far;   // ENTRY 0: entry colour table: group-local part / image-level part (lane = slot)
     u64 tab_valid;
     int le_loc, le_far;          // ENTRY 0: last edge before the set: group-local / image-level
@@ -516,18 +530,14 @@ __device__ __forceinline__ bool warm_entry_state(const uint8_t* __restrict__ pix
     __builtin_amdgcn_wave_barrier();
     // ---- the 512 pixels right before the set, oldest first: later edge pixels simply overwrite earlier ones
     //      (these loads were issued ahead of the set's own pixels) ------------------------------------------
-    {
-        const uint32_t carry = __builtin_amdgcn_readfirstlane(in.warm_carry);
 #pragma unroll
-        for (int k = kWarmBatch - 1; k >= 0; --k) {
-            const int base = (int)lo - 64 * (k + 1);
-            const uint32_t px = in.warm[k];
-            const uint32_t prev = k + 1 < kWarmBatch ? prev_pixels(px, in.warm[k + 1 < kWarmBatch ? k + 1 : k]) : from_lane_below(px, carry);
-            const u64 E = __ballot(px != prev);               // lanes before the image start hold the start pixel: no edge
-            if (E) {
-                last_edge = base + msb64(E);
-                (void)probe_swap(tbase | slot_byte_offset(px), px, E);
-            }
+    for (int k = kWarmBatch - 1; k >= 0; --k) {
+        const int base = (int)lo - 64 * (k + 1);
+        const uint32_t px = in.warm[k];
+        const u64 E = __ballot(px != in.warm_prev[k]);
+        if (E) {
+            last_edge = base + msb64(E);
+            (void)probe_swap((__builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false) & 0xFCu) | tbase, px, E);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -645,13 +655,14 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     // ---- loads: what the entry state needs first, then the first group of pixels ------------------------------
     SetIn in;
     if (ENTRY == 1) {
+        if (lo != 0u) {                                        // (a set begins on a slab boundary: lo >= 1024, all of these lie inside the image)
+            const uint8_t* __restrict__ q = pix + (size_t)(lo + lane) * (size_t)CH;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = (int)lo - 64 * (k + 1) + (int)lane;
-            in.warm[k] = i >= 0 ? load_px<CH>(pix, (uint32_t)i) : kInitPx;
+            for (int k = 0; k < 8; ++k) {
+                in.warm[k] = load_px_at<CH>(q, -64 * (k + 1));
+                in.warm_prev[k] = load_px_at<CH>(q, -64 * (k + 1) - 1);
+            }
         }
-        const int ci = (int)lo - 64 * 8 - 1;
-        in.warm_carry = ci >= 0 ? load_px<CH>(pix, (uint32_t)ci) : kInitPx;
     } else {
         const uint32_t s = set * p.set_slabs;                  // first slab of the set: its entry state is the set's
         const size_t g = (size_t)img * p.spi + s;
@@ -696,6 +707,17 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     uint32_t spilled = 0;                                      // bytes of the set already moved to its scratch slot
     uint8_t* __restrict__ slot = p.scratch + sg * p.set_stride;
 
+    // Look-back, first poll: the records of the 64 sets before this one are asked for when the set's LAST group begins - the sets
+    // before it started earlier and have mostly published by then - so that the answer travels while that group is encoded
+    // (asked for after it, every set sat idle in its slot for the round trip: 10 % of the kernel).
+    constexpr u64 kRecAgg = 1ull << 62, kRecIncl = 2ull << 62;
+    const u64* const rec_base = p.status + (sg - set);        // look-back record of this image's set 0
+    u64 early_rec = kRecIncl;
+    bool early = false;
+    auto ask_early = [&]() {
+        if (p.lookback && set != 0u) { early_rec = lane < set ? granule_load(&rec_base[set - 1u - lane]) : kRecIncl; early = true; }
+    };
+
     uint32_t g = 0;
     if (nint) {
         u64 E = __ballot(ax[0] != av[0]);
@@ -709,7 +731,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
                 if (spos > kStageSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, bx, bv);
-                else { bx[0] = load_px<CH>(pix, base + kGroupPx); bv[0] = load_px<CH>(pix, base + kGroupPx - 1u); }
+                else { bx[0] = load_px<CH>(pix, base + kGroupPx); bv[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
                 process_group<PROBE, false>(L, C, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
                 if (++g >= nint) break;
             }
@@ -718,7 +740,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
                 if (spos > kStageSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, ax, av);
-                else { ax[0] = load_px<CH>(pix, base + kGroupPx); av[0] = load_px<CH>(pix, base + kGroupPx - 1u); }
+                else { ax[0] = load_px<CH>(pix, base + kGroupPx); av[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
                 process_group<PROBE, false>(L, C, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
                 if (++g >= nint) break;
             }
@@ -734,6 +756,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 #pragma unroll
         for (int t = 0; t < kGroupSteps; ++t) load_pair_guarded<CH>(pix, base + t * 64u + lane, n, ax[t], av[t]);
         load_pair_guarded<CH>(pix, base + kGroupPx + lane, n, nxp, nxv);
+        if (g + 1u == ngroups) ask_early();
         u64 E = __ballot(ax[0] != av[0]);
         process_group<PROBE, true>(L, C, lane, ax, av, nxp, nxv, (int)(n - base), E, ccp, vbase);
     }
@@ -748,24 +771,25 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     }
 
     // ---- set byte count -> offset: decoupled look-back over the earlier sets of the image -----------------
-    u64 excl = 0;
+    // A record is an 8-byte granule: bits 62..63 = 0 nothing yet, 1 the set's own byte count, 2 the byte count of the image up
+    // to and including the set; the count sits in the low dword (a stream is shorter than 2^31 bytes, qoi.h:328-332).
+    uint32_t excl = 0;
     {
-        constexpr u64 kAgg = 1ull << 62, kIncl = 2ull << 62, kVal = (1ull << 62) - 1ull;
         u64* st = p.status;
         if (set == 0) {
-            if (lane == 0) granule_store(&st[sg], kIncl | set_bytes);
+            if (lane == 0) granule_store(&st[sg], kRecIncl | set_bytes);
         } else {
-            if (lane == 0) granule_store(&st[sg], kAgg | set_bytes);
-            const int64_t first = (int64_t)(sg - set);        // global id of this image's set 0
-            int64_t look = (int64_t)sg - 1;                   // newest set of the current window
+            if (lane == 0) granule_store(&st[sg], kRecAgg | set_bytes);
+            uint32_t look = set - 1u;                          // newest set of the current window (index within the image)
             uint32_t spins = 0;
-            bool done = false;
-            while (!done) {
-                const int64_t mine = look - (int64_t)lane;
-                const bool inwin = mine >= first;
-                u64 v = inwin ? granule_load(&st[mine]) : kIncl;   // before set 0: inclusive prefix 0
-                const u64 notready = __ballot((v >> 62) == 0);
-                const u64 incl = __ballot((v >> 62) == 2);
+            for (;;) {
+                const bool inwin = lane <= look;
+                u64 v;
+                if (early) { v = early_rec; early = false; }               // the answer to ask_early(): the same window
+                else v = inwin ? granule_load(&rec_base[look - lane]) : kRecIncl;   // before set 0: inclusive prefix 0
+                const uint32_t flag = (uint32_t)(v >> 62);
+                const u64 notready = __ballot(flag == 0u);
+                const u64 incl = __ballot(flag == 2u);
                 const int stop = incl ? __builtin_ctzll(incl) : 64;       // nearest inclusive record
                 const u64 need = stop >= 64 ? ~0ull : ((1ull << stop) - 1ull);
                 if (notready & need) {                                    // a record we must add is not published yet
@@ -775,11 +799,11 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                     __builtin_amdgcn_s_sleep(2);
                     continue;
                 }
-                const u64 part = wave_sum64_upto(v & kVal, lane, stop);
-                excl += part;
-                if (incl) done = true; else look -= 64;
+                excl += wave_sum32_upto((uint32_t)v, lane, stop);
+                if (incl) break;
+                look -= 64u;                                              // (no inclusive record among 64: look >= 64 here)
             }
-            if (lane == 0) granule_store(&st[sg], kIncl | (excl + set_bytes));
+            if (lane == 0) granule_store(&st[sg], kRecIncl | (u64)(excl + set_bytes));
         }
     }
 
@@ -791,7 +815,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         const u64 hdr_hi = (u64)__builtin_bswap32(h) | ((u64)p.channels << 32) | ((u64)p.colorspace << 40);
         out[lane] = (uint8_t)((lane < 8u ? hdr_lo : hdr_hi) >> (8u * (lane & 7u)));
     }
-    const u64 pos = (u64)kHeaderBytes + excl;
+    const u64 pos = (u64)kHeaderBytes + (u64)excl;
     if (spilled) {                                          // the part that went through the scratch slot: by this wavefront, from this CU
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         copy_global_out(slot, out + pos, spilled, lane);
@@ -813,30 +837,26 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 // flagged.  A workgroup serves unit u = (image u % n_images, four consecutive sets u / n_images) so that the
 // sets in flight spread over all images.
 template <int CH, int PROBE, int ENTRY>
-__global__ __launch_bounds__(256, PROBE == 1 ? 5 : 4) void enc_sets(EncParams p) {
+__global__ __launch_bounds__(256, PROBE == 1 ? QOIMI_ENC_WAVES_PER_SIMD : 4) void enc_sets(EncParams p) {
     __shared__ EncLds<PROBE> s_lds[4];
-    __shared__ uint32_t s_ticket[2];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
-    uint32_t turn = 0;
 #pragma unroll 1
-    for (uint32_t unit = blockIdx.x; unit < p.n_units; unit += gridDim.x, turn ^= 1u) {
+    for (uint32_t unit = blockIdx.x; unit < p.n_units; unit += gridDim.x) {
         const uint32_t img = unit % p.n_images;
-        uint32_t quad = unit / p.n_images;                 // order-free mode: any order will do
         if (p.only_flagged && p.need_generic[img] == 0u) continue;
+        if (ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;   // image already sent to the generic path
+        uint32_t set = (unit / p.n_images) * 4u + wave;    // order-free mode: any order will do
         if (p.use_ticket && p.lookback) {
-            // look-back mode: the four-set units of an image are handed out by the image's ticket counter, i.e. in
-            // START order, hence every predecessor a look-back can wait on is already running or finished (no
-            // reliance on dispatch order; guide G16).  One counter per image keeps the atomics off a single hot word.
-            // (s_ticket alternates between two words: a wavefront may still read the one of the previous turn.)
-            if (threadIdx.x == 0) s_ticket[turn] = atomicAdd(&p.ticket[img], 1u);
-            __syncthreads();
-            quad = __builtin_amdgcn_readfirstlane(s_ticket[turn]);
+            // look-back mode: the sets of an image are handed out by the image's ticket counter, one ticket per WAVEFRONT, i.e.
+            // in START order: every predecessor a look-back can wait on is already running or finished (no reliance on
+            // dispatch order; guide G16).  One counter per image keeps the atomics off a single hot word; no workgroup barrier,
+            // so a wavefront that waits in its look-back does not hold up the other three of its workgroup.
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&p.ticket[img], 1u);
+            set = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         }
-        const uint32_t set = quad * 4u + wave;
-        if (set < p.sets_per_image &&
-            !(ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))   // image already sent to the generic path
-            encode_set<CH, PROBE, ENTRY>(p, img, set, lane, s_lds[wave]);
+        if (set < p.sets_per_image) encode_set<CH, PROBE, ENTRY>(p, img, set, lane, s_lds[wave]);
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -97,7 +97,7 @@ struct qoimi_ctx {
     long long enc_calls_at_check = 0, enc_recheck_every = 256, enc_suspect_calls = 0;   // env QOIMI_ENC_RECHECK_EVERY
     bool recheck_pending = false;       // a repeated self-test is in flight on own_stream, result in host_word[8]
     int enc_ticket = 1, enc_set_slabs = 0, enc_warm = 1;   // tuning / test knobs (env QOIMI_ENC_*)
-    int enc_lookback = 1;               // 1: sets place their bytes themselves (decoupled look-back); 0: order-free (scratch slots + enc_offsets + enc_compact)
+    int enc_lookback = -1;              // 1: sets place their bytes themselves (decoupled look-back); 0: order-free (scratch slots + enc_offsets + enc_compact); -1: by the number of sets per image
     std::string enc_debug_dump;         // env QOIMI_ENC_DEBUG_DUMP: file that receives the entry-state arrays of every encode call
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
@@ -280,19 +280,13 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         launch_lds_order_selftest(d_flag, c->own_stream);
         if (hipMemcpyAsync(&c->host_word[8], d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->own_stream) == hipSuccess) c->recheck_pending = true;
     }
-    // Placement: by default a set finds its place in the stream by decoupled look-back and writes its bytes once, straight from
-    // the LDS (sets of more than ~1.4 bytes per pixel spill to their scratch slot and move that part themselves);
-    // QOIMI_ENC_LOOKBACK=0 selects the order-free form (every set parks its bytes, enc_offsets + enc_compact place them).
-    // Both give the same bytes.
-    const bool lookback = c->enc_lookback != 0;
     p.probe_xchg = c->xchg_ordered ? 1 : 0;
     p.use_ticket = c->enc_ticket ? 1 : 0;
-    p.lookback = lookback ? 1 : 0;
     p.warm = c->enc_warm ? 1 : 0;
     {   // slabs per set: a wavefront carries the colour table and its staged bytes from slab to slab, so the entry-state replay
         // and the look-back are paid once per set - as long as the sets still fill the 256 CUs x 20 wavefronts several times
         const size_t total_slabs = (size_t)n_images * p.spi;
-        uint32_t r = total_slabs >= 4u * 65536u ? 4u : (total_slabs >= 2u * 65536u ? 2u : 1u);
+        uint32_t r = total_slabs >= 3u * 65536u ? 3u : (total_slabs >= 16384u ? 2u : 1u);
         if (c->enc_set_slabs > 0) r = (uint32_t)c->enc_set_slabs;
         if (r > kEncMaxSetSlabs) r = kEncMaxSetSlabs;
         p.set_slabs = r;
@@ -300,6 +294,16 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         p.sets_per_image = (p.spi + r - 1u) / r;
         p.set_stride = r * kEncSlabWorst + 16u;
     }
+    // Placement.  Look-back: a set finds its place in the stream by decoupled look-back over the earlier sets of its image and
+    // writes its bytes once, straight from the LDS (sets of more than ~1.4 bytes per pixel spill to their scratch slot and move
+    // that part themselves).  The inclusive prefixes travel 64 sets per poll (~1 us) through the sets of an image that finish
+    // at about the same time - the ~5000 resident wavefronts divided by the number of images.  With a batch that is a few sets;
+    // with ONE large image it is thousands, and the sets would wait for the prefixes (a 16384 x 16384 image: 0.62 ms against
+    // 0.5): there the order-free form is used (every set parks its bytes, enc_offsets scans the sizes with a whole workgroup,
+    // enc_compact places them; three more launches).  A function of the shapes only; QOIMI_ENC_LOOKBACK=0/1 forces one form.
+    // Both give the same bytes.
+    const bool lookback = c->enc_lookback >= 0 ? c->enc_lookback != 0 : (n_images >= 8 || p.sets_per_image <= 1024u);
+    p.lookback = lookback ? 1 : 0;
     const size_t T = (size_t)p.n_images * p.spi, G = (size_t)p.n_images * p.gpi, S = (size_t)p.n_images * p.sets_per_image;
     if (T > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (slab index overflows 32 bits)");
 
