@@ -266,6 +266,8 @@ __device__ __forceinline__ uint32_t scalar_add64(uint32_t v) {
 // moves.  LDS ops of a wave complete in issue order, so the later (compiler-visible) reads of the staging buffer
 // see these stores.
 __device__ __forceinline__ void stage_short(uint32_t addr, uint32_t w, u64 any, u64 second) {
+    // (the three exec moves cost little: writing with all lanes instead - wrong bytes, timing only - made the kernel 1-2 % faster;
+    // the kernel is bound by its VECTOR instruction count, profiles/r03_s2_sq_counters_encode.txt)
     asm volatile("s_mov_b64 exec, %2\n\t"
                  "ds_write_b8 %0, %1\n\t"
                  "s_mov_b64 exec, %3\n\t"
@@ -875,6 +877,7 @@ __global__ __launch_bounds__(1024) void enc_offsets(EncParams p) {
     __shared__ uint32_t s_turn[16][kStripe + 64u];             // element e of a stripe at e + e/16 (bank spread)
     __shared__ uint32_t s_wave[16];
     const uint32_t img = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (p.only_flagged && (*p.any_generic == 0u || p.need_generic[img] == 0u)) return;     // placement of the generic pass's images only
     const uint32_t* __restrict__ sz = p.set_size + (size_t)img * p.sets_per_image;
     uint32_t* __restrict__ off = p.set_off + (size_t)img * p.sets_per_image;
     const uint32_t n = p.sets_per_image;
@@ -931,12 +934,16 @@ __global__ __launch_bounds__(1024) void enc_offsets(EncParams p) {
 // (one wavefront per set; aligned 16-byte stores, source re-aligned with v_alignbyte).
 __global__ __launch_bounds__(256) void enc_compact(EncParams p) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const size_t sg = (size_t)blockIdx.x * 4u + wave;
-    if (sg >= (size_t)p.n_images * p.sets_per_image) return;
-    const uint32_t img = (uint32_t)(sg / p.sets_per_image);
-    const uint32_t n = p.set_size[sg];
-    if (n == 0) return;
-    copy_global_out(p.scratch + sg * p.set_stride, p.out + (size_t)img * p.out_stride + kHeaderBytes + p.set_off[sg], n, lane);
+    if (p.only_flagged && *p.any_generic == 0u) return;
+    const size_t total = (size_t)p.n_images * p.sets_per_image;
+#pragma unroll 1
+    for (size_t sg = (size_t)blockIdx.x * 4u + wave; sg < total; sg += (size_t)gridDim.x * 4u) {
+        const uint32_t img = (uint32_t)(sg / p.sets_per_image);
+        if (p.only_flagged && p.need_generic[img] == 0u) continue;
+        const uint32_t n = p.set_size[sg];
+        if (n == 0) continue;
+        copy_global_out(p.scratch + sg * p.set_stride, p.out + (size_t)img * p.out_stride + kHeaderBytes + p.set_off[sg], n, lane);
+    }
 }
 
 // Measures whether one ds_wrxchg_rtn_b32 serves same-address lanes in ascending lane order
@@ -1019,17 +1026,20 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     tm->mark(kT_enc_scan_groups, st);
     hipLaunchKernelGGL(enc_scan_images, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_images, st);
-    // look-back mode: the images the first pass gave up on are encoded again from their first set, with look-back records and
-    // tickets of their own (those of the first pass are spent)
-    if (warm && p.lookback) { p.status = p.status2; p.ticket = p.ticket2; }
+    // The images the first pass gave up on (flat content) are encoded again from their first set - ORDER-FREE whatever the first
+    // pass used: their sets are a few bytes each, a look-back per set costs more than the scan + move of the placement passes
+    // (256 flat 4K frames: 9.0 ms with look-back, 7.5 order-free).  The placement passes then serve the flagged images only.
+    const bool first_lookback = p.lookback != 0;
+    if (warm) p.lookback = 0;
     hipLaunchKernelGGL((enc_sets<CH, PROBE, 0>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
     tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
+    p.only_flagged = (warm && first_lookback) ? 1 : 0;
     }
     if (!p.lookback && (phases & kEncPlace)) {
         const uint32_t set_blocks = (p.n_images * p.sets_per_image + 3u) / 4u;
         hipLaunchKernelGGL(enc_offsets, dim3(p.n_images), dim3(1024), 0, st, p);
         tm->mark(kT_enc_offsets, st);
-        hipLaunchKernelGGL(enc_compact, dim3(set_blocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(enc_compact, dim3(p.only_flagged && set_blocks > small ? small : set_blocks), dim3(256), 0, st, p);
         tm->mark(kT_enc_compact, st);
     }
 }

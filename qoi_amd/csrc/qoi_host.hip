@@ -311,7 +311,6 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         Carver w(pass ? c->enc_ws.base : nullptr);
         p.status = w.take<u64>(S); p.ticket = w.take<uint32_t>((size_t)n_images); p.err = w.take<uint32_t>(1);
         p.need_generic = w.take<uint32_t>((size_t)n_images); p.any_generic = w.take<uint32_t>(1);
-        p.status2 = w.take<u64>(S); p.ticket2 = w.take<uint32_t>((size_t)n_images);
         const size_t zero_bytes = w.off;
         p.sum_tab = w.take<uint32_t>(T * 64); p.sum_valid = w.take<u64>(T); p.sum_le = w.take<int>(T);
         p.ent_tab = w.take<uint32_t>(T * 64); p.ent_valid = w.take<u64>(T); p.ent_le = w.take<int>(T);

@@ -60,7 +60,6 @@ struct EncParams {
     uint32_t* gent_tab;  int* gent_le;                     // E2b out       [n_images*gpi]
     u64* status;         // look-back records [n_images*sets_per_image]   -- zeroed before every launch
     uint32_t* ticket;    // per-image ticket counters [n_images]          -- zeroed before every launch
-    u64* status2; uint32_t* ticket2;   // look-back mode: the same two for the second (generic) pass over flagged images
     uint32_t* err;       // liveness-bound flag               -- zeroed before every launch
     uint32_t* need_generic;  // [n_images] image needs the E1/E2 path  -- zeroed before every launch
     uint32_t* any_generic;   // [1]                                    -- zeroed before every launch
