@@ -618,6 +618,10 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_parse_l2(DecParams p)
     __shared__ uint32_t s_in[kL2Waves][2];       // share entry: phase, pixel offset
     const uint32_t img = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const DecImage im = p.images[img];
+    if (wave == kL2Waves - 1u && im.nseg != 0u) {          // the decoder's start state (qoi.h:533-537) at the image's first segment
+        p.entry[(size_t)im.seg_base * 65u + lane] = 0u;
+        if (lane == 0) p.entry[(size_t)im.seg_base * 65u + 64u] = kInitPx;
+    }
     const uint32_t per = (im.ngrp + kL2Waves - 1u) / kL2Waves;
     const uint32_t lo = min(wave * per, im.ngrp), hi = min(lo + per, im.ngrp);
     {   // A: record of the share, 64 groups per fold
@@ -1773,22 +1777,6 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     }
 }
 
-// Pixels the chunks never reach repeat the last pixel (truncated streams, size==22).  One block per (image, slice): the
-// image index travels in blockIdx.x (gridDim.y stops at 65535 - a batch may hold more images than that).
-constexpr uint32_t kFillSlices = 64;
-template <int OCH>
-__global__ __launch_bounds__(256) void dec_fill(DecParams p) {
-    const uint32_t img = blockIdx.x / kFillSlices, slice = blockIdx.x % kFillSlices;
-    const DecImage im = p.images[img];
-    if (im.total_px >= im.npx) return;
-    const uint32_t px = im.n_active ? im.final_px : kInitPx;
-    uint8_t* out = p.pixels + (size_t)img * p.pixel_stride;
-    for (uint32_t i = im.total_px + slice * 256u + threadIdx.x; i < im.npx; i += kFillSlices * 256u) {
-        if (OCH == 4) reinterpret_cast<uint32_t*>(out)[i] = px;
-        else { uint8_t* d = out + (size_t)i * 3u; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
-    }
-}
-
 // Last resort of the repair loop.  Every round verifies at least one more segment per image, so the loop terminates - but a
 // stream built to defeat the speculation (say, QOI_OP_INDEX on slots whose content does not hash there, segment after
 // segment) could ask for as many rounds as it has segments, each a relaunch over all of them: quadratic.  After
@@ -1836,18 +1824,9 @@ __global__ __launch_bounds__(64) void dec_sequential(DecParams p) {
 }
 
 // Concrete start state of every image: {0,0,0,255} and a zeroed table (qoi.h:533-537).
-__global__ __launch_bounds__(64) void dec_init_state(DecParams p) {
-    const uint32_t img = blockIdx.x, lane = lane_id();
-    const DecImage im = p.images[img];
-    if (im.nseg == 0) return;
-    p.entry[(size_t)im.seg_base * 65u + lane] = 0u;
-    if (lane == 0) p.entry[(size_t)im.seg_base * 65u + 64u] = kInitPx;
-}
-
 // After a round: images whose check failed restart at the first bad segment from the
 // TRUE exit state of its predecessor; the others are finished.  Counts pending images.
-__global__ __launch_bounds__(64) void dec_prepare_restart(DecParams p) {
-    const uint32_t img = blockIdx.x, lane = lane_id();
+__device__ __forceinline__ void prepare_restart(const DecParams& p, uint32_t img, uint32_t lane) {
     const DecImage im = p.images[img];
     const uint32_t fb = p.first_bad[img];
     if (fb == 0xFFFFFFFFu) {
@@ -1862,6 +1841,24 @@ __global__ __launch_bounds__(64) void dec_prepare_restart(DecParams p) {
         p.first_bad[img] = 0xFFFFFFFFu;
         atomicAdd(p.pending, 1u);
         atomicAdd(p.redo_segs, im.n_active - fb);
+    }
+}
+
+// Pixels the chunks never reach repeat the last pixel (truncated streams, size==22).  One block per (image, slice): the
+// image index travels in blockIdx.x (gridDim.y stops at 65535 - a batch may hold more images than that).  The first wavefront
+// of an image's first slice also prepares the image's restart (above): one launch less per round.
+constexpr uint32_t kFillSlices = 64;
+template <int OCH>
+__global__ __launch_bounds__(256) void dec_fill(DecParams p) {
+    const uint32_t img = blockIdx.x / kFillSlices, slice = blockIdx.x % kFillSlices;
+    const DecImage im = p.images[img];
+    if (slice == 0u && threadIdx.x < 64u && p.total_segs != 0u) prepare_restart(p, img, threadIdx.x);
+    if (im.total_px >= im.npx) return;
+    const uint32_t px = im.n_active ? im.final_px : kInitPx;
+    uint8_t* out = p.pixels + (size_t)img * p.pixel_stride;
+    for (uint32_t i = im.total_px + slice * 256u + threadIdx.x; i < im.npx; i += kFillSlices * 256u) {
+        if (OCH == 4) reinterpret_cast<uint32_t*>(out)[i] = px;
+        else { uint8_t* d = out + (size_t)i * 3u; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }
     }
 }
 
@@ -1882,7 +1879,6 @@ void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
     }
     hipLaunchKernelGGL(dec_chain_parse_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
     if (p.total_segs) hipLaunchKernelGGL(dec_chain_parse_l3, dim3(p.total_grps), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(dec_init_state, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_dec_chain_parse, st);
 }
 
@@ -1935,8 +1931,7 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     if (out_channels == 4) hipLaunchKernelGGL(dec_segments_rec<4>, dim3(b64), dim3(64), 0, st, p);
     else hipLaunchKernelGGL(dec_segments_rec<3>, dim3(b64), dim3(64), 0, st, p);
     tm->mark(kT_dec_segments, st);
-    hipLaunchKernelGGL(dec_prepare_restart, dim3(p.n_images), dim3(64), 0, st, p);
-    tm->mark(kT_dec_restart, st);
+    // (the restart of the images whose check failed is prepared by dec_fill, which every round ends with)
 }
 
 void launch_decode_sequential(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm) {

@@ -103,6 +103,7 @@ struct qoimi_ctx {
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
     int dec_p3_plain = 1, dec_inner = 4, dec_inner1 = 3;   // env QOIMI_P3_PLAIN, QOIMI_DEC_INNER, QOIMI_DEC_INNER1 (read once, at creation)
     int dec_max_rounds = kMaxSpecRounds;   // speculation rounds before the sequential last resort (env QOIMI_DEC_MAX_ROUNDS, tests)
+    size_t last_drop_len = 0;           // length of the last stream the drop-in qoi_encode returned on this context (page populate-ahead)
     long long dec_seq_images = 0;       // images finished by dec_sequential since the context was created
     size_t dec_rec_cap = (size_t)16 << 30;   // largest record arena: a call whose streams need more is decoded in sub-batches (set from the device's memory at creation)
     KernelTimer timer;                  // optional per-kernel HIP-event timing
@@ -462,24 +463,27 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.recs = w.take<uint32_t>(((Q + 63u) / 64u) * p.rec_rows * 256u);
         if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }
     }
-    {   // image table through pinned staging: no synchronisation (every decode call ends with one, so the
-        // staging buffer is free again when the next call fills it)
-        const size_t bytes = imgs.size() * sizeof(DecImage);
+    {   // image table through pinned staging: no synchronisation (every decode call ends with one, so the staging buffer is free
+        // again when the next call fills it).  The four counter words in front of it (pending, redo_segs, sync_fails: the
+        // arena's first 256 bytes, the table follows them) travel zeroed in the same copy: no memset launches in round one.
+        static_assert(sizeof(DecImage) % 8 == 0, "image table entries keep their alignment behind the counter words");
+        const size_t bytes = 256u + imgs.size() * sizeof(DecImage);
+        if ((uint8_t*)p.images != (uint8_t*)p.pending + 256u) return fail(QOIMI_E_INTERNAL, "decode workspace layout changed");
         if (bytes > c->pin_cap) {
             if (c->pin_buf) (void)hipHostFree(c->pin_buf);
             c->pin_buf = nullptr; c->pin_cap = 0;
             HIP_TRY(hipHostMalloc(&c->pin_buf, bytes + 4096));
             c->pin_cap = bytes + 4096;
         }
-        memcpy(c->pin_buf, imgs.data(), bytes);
-        HIP_TRY(hipMemcpyAsync(p.images, c->pin_buf, bytes, hipMemcpyHostToDevice, st));
+        memset(c->pin_buf, 0, 256);
+        memcpy((uint8_t*)c->pin_buf + 256, imgs.data(), bytes - 256u);
+        HIP_TRY(hipMemcpyAsync(p.pending, c->pin_buf, bytes, hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(hipMemsetAsync(p.redo_segs, 0, 2 * sizeof(uint32_t), st));       // redo_segs, sync_fails
 
     launch_decode_parse(p, st, &c->timer);
     long long rounds = 0, stats_seq = 0;
     for (;;) {
-        HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
+        if (rounds > 0) HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
         launch_decode_round(p, och, rounds > 0 && c->dec_refine, st, &c->timer);
         ++rounds;
         // pixels the chunks never reach (cheap; redone if the round has to be repeated) - before the read-back,
@@ -675,6 +679,15 @@ extern "C" void* qoi_encode(const void* data, const qoi_desc* desc, int* out_len
     const size_t bound = qoimi_encode_bound(desc);                        // qoi.h:374-376
     if (c->io_a.reserve(in_bytes + 16) || c->io_b.reserve(bound + 16) || c->io_c.reserve(256)) return NULL;
     void* result = NULL;
+    uint8_t* bytes = (uint8_t*)malloc(bound);                              // worst case, as qoi.h:379
+    if (!bytes) return NULL;
+    // The result's pages are populated by the thread's parked helpers WHILE the pixels go in and the kernels run: the stream's
+    // length is not known yet, so they take the length of this thread's previous stream (a third of the bound at first) - pages
+    // beyond that are touched by the copy as before (round 2 populated after the kernels: 0.35 ms of a 1.3 ms call).
+    const size_t guess = c->last_drop_len ? c->last_drop_len + c->last_drop_len / 8u : bound / 3u;
+    const size_t ahead = guess < bound ? guess : bound;
+    const bool populate = ahead >= ((size_t)1 << 20);
+    if (populate) t_ctx.pf.start(bytes, ahead);
     do {
         // pixels in (the copy engine reads pageable memory at the link's rate on this platform, tools/ubench/host_copy.cpp),
         // kernels, then ONE read-back of length + liveness flag through pinned words, then exactly `len` bytes out
@@ -688,14 +701,14 @@ extern "C" void* qoi_encode(const void* data, const qoi_desc* desc, int* out_len
             t_error = "encode kernel reported a liveness failure";
             break;
         }
-        uint8_t* bytes = (uint8_t*)malloc(bound);                          // worst case, as qoi.h:379
-        if (!bytes) break;
-        prefault_pages(bytes, (size_t)len);
+        if (populate) { t_ctx.pf.wait(); }
         if (hipMemcpyAsync(bytes, c->io_b.base, (size_t)len, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) { free(bytes); break; }
+            hipStreamSynchronize(st) != hipSuccess) break;
+        c->last_drop_len = (size_t)len;
         *out_len = len;
         result = bytes;
     } while (0);
+    if (!result) { if (populate) t_ctx.pf.wait(); free(bytes); }
     return result;
 }
 
