@@ -1024,6 +1024,19 @@ struct PipeReader {
         sh = (rp & 3u) * 8u;
         w32 = __builtin_amdgcn_alignbit(hi, d0, sh);
     }
+    // the same for a cursor kept RELATIVE to the ring's origin (rp = pos - aoff): the transcoder's walk keeps it that way and
+    // saves the subtraction in every step
+    __device__ __forceinline__ void peek4_rel(uint32_t rp, uint32_t& w32, uint32_t& hi, uint32_t& sh) const {
+        static_assert(RD == 32u, "five bits of ring slot");
+        uint32_t a;                                                       // ring + 256 * ((rp / 4) % 32) in two instructions (hipcc makes it shift, and, add)
+        asm("v_bfe_u32 %0, %1, 2, 5\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(a) : "v"(rp), "v"(ring));
+        const lds_u32* q = (const lds_u32*)a;
+        const uint32_t d0 = q[0]; hi = q[64];
+        sh = rp * 8u;                                                    // v_alignbit takes the shift modulo 32
+        w32 = __builtin_amdgcn_alignbit(hi, d0, sh);
+    }
+    template <int S>
+    __device__ __forceinline__ void turn_rel(uint32_t rp) { turn<S>(rp + aoff); }
     // one period's memory work for register set S (compile-time 0..2): land what S holds (asked for three periods ago), ask again
     template <int S>
     __device__ __forceinline__ void turn(uint32_t pos) {
@@ -1070,7 +1083,9 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     for (uint32_t b = threadIdx.x; b < 256u; b += kTrThreads) {
         uint32_t d, i; lut_entry(b, d, i);
         s_lut.tpl[b] = rec_template(b);
-        s_lut.info[b] = b == 0xFFu ? (i & ~7u) : i;
+        // the transcoder's own info word: bits 0..2 chunk length (0 for QOI_OP_RGBA: visited twice), bits 8..15 all ones for
+        // QOI_OP_LUMA (ANDed onto the chunk bytes it leaves the second byte there, nothing for every other chunk), bits 30..31 class
+        s_lut.info[b] = (b == 0xFFu ? 0u : (i & 7u)) | ((i >> 28) & 1u ? 0x0000FF00u : 0u) | (i & 0xC0000000u);
     }
     if (threadIdx.x < 4u) { s_lut.tpl[256u + threadIdx.x] = 0u; s_lut.info[256u + threadIdx.x] = 0u; }
     __syncthreads();
@@ -1131,9 +1146,17 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         if (fails != 0 && lane == (uint32_t)__builtin_ctzll(fails)) atomicAdd(p.sync_fails, (uint32_t)__builtin_popcountll(fails));
     }
     bool active = have && !failed && pos < end;
-    uint32_t w32, b5hi, b5sh; R.peek4(pos, w32, b5hi, b5sh);
+    // The walk keeps its cursor relative to the ring's origin (rp) and forms the table offset of the byte under it with one
+    // SDWA shift: 20 vector instructions per chunk in the common path (23 with an absolute cursor, round 2).
+    uint32_t rp = pos - R.aoff;
+    const uint32_t end_rel = end - R.aoff;
+    uint32_t two = 2u;
+    asm volatile("" : "+v"(two));                                        // the shift count of byte0_times4 lives in a VGPR (SDWA takes no literal)
+    auto byte0_times4 = [&](uint32_t w) { uint32_t r; asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w)); return r; };
+    uint32_t w32, b5hi, b5sh; R.peek4_rel(rp, w32, b5hi, b5sh);
     uint32_t tpl, info;                        // of the chunk under the cursor; the null entry once the lane is through
-    {   const lds_u32* lq = (const lds_u32*)(lut_base + (active ? (w32 & 0xFFu) : 256u) * 4u); tpl = lq[0]; info = lq[260]; }
+    {   const uint32_t i4 = byte0_times4(w32);
+        const lds_u32* lq = (const lds_u32*)(lut_base + (active ? i4 : 1024u)); tpl = lq[0]; info = lq[260]; }
     uint32_t a_abs = 0u, a_last = 0u;            // a QOI_OP_RGBA occurred in the segment / the alpha of the last one (for dec_slot_tails)
     uint32_t pend = 0u;                          // 1: the stash record of the QOI_OP_RGBA chunk under the cursor is out
     bool any_pend = false;
@@ -1149,16 +1172,17 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                 const uint32_t c_info = info;
                 uint32_t rec = tpl;                                      // null record once the lane is through (LUT entry 256)
                 uint32_t adv = lut_len(c_info);
-                // byte-wise delta of a relative chunk: table part + the second byte of a LUMA chunk (qoi.h:566-571)
-                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)c_info, 28, 1);      // all ones for LUMA
-                const uint32_t er = __builtin_amdgcn_ubfe(w32, 12, 4) & m, eb = __builtin_amdgcn_ubfe(w32, 8, 4) & m;
+                // byte-wise delta of a relative chunk: table part + the second byte of a LUMA chunk (qoi.h:566-571); the info word
+                // keeps that byte (bits 8..15 all ones) for QOI_OP_LUMA only
+                const uint32_t wm = w32 & c_info;
+                const uint32_t er = __builtin_amdgcn_ubfe(wm, 12, 4), eb = __builtin_amdgcn_ubfe(wm, 8, 4);
                 add_byte0(rec, er); add_byte2_from0(rec, eb);
                 uint32_t cnt = (rec >> 24) & 63u;                        // pixels of the chunk (qoi.h:573-575); the stash marker is set right below
                 if (lanes_where(lut_hi(c_info)) != 0 || any_pend) {     // QOI_OP_RGB / QOI_OP_RGBA somewhere in the wavefront (rare in natural images)
                     const bool hi = lut_hi(c_info), lo = lut_lo(c_info);
                     const bool rgba = hi && lo, second = rgba && pend != 0u, first = rgba && pend == 0u;
                     const uint32_t rgb = (w32 >> 8) & 0x00FFFFFFu;
-                    const uint32_t b5 = (b5hi >> b5sh) & 0xFFu;                              // chunk byte 4: the alpha of a QOI_OP_RGBA
+                    const uint32_t b5 = (b5hi >> (b5sh & 24u)) & 0xFFu;                      // chunk byte 4: the alpha of a QOI_OP_RGBA
                     const uint32_t rec_hi = second ? rec_make(3u, 1u, b5) : (rec | rgb);      // rec still is the class-2 template here
                     rec = hi ? rec_hi : rec;
                     adv = second ? 5u : adv;
@@ -1169,13 +1193,14 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                     any_pend = lanes_where(pend != 0u) != 0;
                 }
                 npix += cnt;
-                const uint32_t npos = pos + adv;
-                uint32_t nw32; R.peek4(npos, nw32, b5hi, b5sh);
-                active = active && npos < end;
-                const lds_u32* lq = (const lds_u32*)(lut_base + (active ? (nw32 & 0xFFu) : 256u) * 4u);
+                const uint32_t nrp = rp + adv;
+                uint32_t nw32; R.peek4_rel(nrp, nw32, b5hi, b5sh);
+                active = active && nrp < end_rel;
+                const uint32_t i4 = byte0_times4(nw32);                  // (outside the select: a call in a ?: arm is a branch)
+                const lds_u32* lq = (const lds_u32*)(lut_base + (active ? i4 : 1024u));
                 const uint32_t ntpl = lq[0], ninfo = lq[260];
                 rr[u] = rec;
-                pos = npos; w32 = nw32; tpl = ntpl; info = ninfo;
+                rp = nrp; w32 = nw32; tpl = ntpl; info = ninfo;
             }
             // non-temporal: 13.7 GB of records per 412 frames must not sweep the stream lines out of the L2 between a lane's four
             // 32-byte requests to one 128-byte line (with plain stores FETCH_SIZE was 3.8 x the stream bytes, now 2.5 x)
@@ -1183,10 +1208,11 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         }
     };
     while (lanes_where(active)) {                                 // a period = one granule of four steps; three periods per turn of the register sets
-        R.turn<0>(pos); granule_steps();
-        R.turn<1>(pos); granule_steps();
-        R.turn<2>(pos); granule_steps();
+        R.turn_rel<0>(rp); granule_steps();
+        R.turn_rel<1>(rp); granule_steps();
+        R.turn_rel<2>(rp); granule_steps();
     }
+    pos = rp + R.aoff;
     if (have && !failed) {
         p.rec_gran[q] = ngran;
         SlotRec r; r.hc = 0; r.h_rel = 0; r.h_alpha = 0; r.a_abs = (uint8_t)a_abs; r.ac = (uint8_t)a_last;      // dec_slot_tails completes it
