@@ -517,6 +517,62 @@ def test_set_sizes_and_placements(api, oracle, slabs, lookback):
                 os.environ[k] = v
 
 
+def _mixed_frame(rng, w, h, ch, seed):
+    """A photograph with stretches of noise, flat colour, alpha steps and every-other-pixel noise: bytes per pixel change inside
+    a set, so look-back sets spill part of their bytes and keep the rest staged."""
+    from qoi_amd import synth
+    a = synth.frame_rgba("photo", w, h, seed).reshape(-1, 4).copy()
+    b = synth.frame_rgba("noise", w, h, seed + 1).reshape(-1, 4)
+    n, pos = a.shape[0], 0
+    while pos < n:
+        L, k = int(rng.integers(1, 6000)), int(rng.integers(0, 5))
+        if k == 1:
+            a[pos:pos + L] = b[pos:pos + L]
+        elif k == 2:
+            a[pos:pos + L] = a[pos]
+        elif k == 3:
+            a[pos:pos + L, 3] = rng.integers(0, 256)
+        elif k == 4:
+            a[pos:pos + L:2] = b[pos:pos + L:2]
+        pos += L
+    return np.ascontiguousarray(a.reshape(h, w, 4)[:, :, :ch])
+
+
+@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_SET_SLABS": "3"}, {"QOIMI_ENC_SET_SLABS": "8"}, {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"}])
+def test_mixed_content_partial_spills(api, oracle, env):
+    """Sets whose bytes only partly fit the LDS staging buffer (tools/dev/sweep_enc.py is the long form of this test)."""
+    import torch
+    from gpu_util import DeviceBatch
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = api.Context(0)
+        rng = np.random.default_rng(31)
+        for (w, h, ch) in ((1920, 1080, 4), (1000, 999, 3), (4096, 33, 4)):
+            n = 6
+            frames = [_mixed_frame(rng, w, h, ch, 2000 + i) for i in range(n)]
+            b = DeviceBatch(c, w, h, ch, n)
+            for i in range(n):
+                b.upload(i, frames[i])
+            lens = b.encode()
+            torch.cuda.synchronize()
+            for i in range(n):
+                want = oracle.encode(frames[i], w, h, ch)
+                assert b.stream_bytes(i, lens[i]) == want, (env, w, h, ch, i, int(lens[i]), len(want))
+            out = torch.full((n * b.pixel_stride,), 0xCD, dtype=torch.uint8, device="cuda")
+            stride = b.decode_into(out, lens, ch)
+            got = out.cpu().numpy()
+            for i in range(n):
+                assert np.array_equal(got[i * stride:i * stride + w * h * ch], frames[i].reshape(-1)), (env, w, h, ch, i)
+        c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_one_context_through_changing_content(api, oracle):
     """One context encodes noise, noise, photo, photo, noise, flat frames in turn (workspace layout and placement stay the
     same from call to call); every stream stays byte-identical to the reference's."""
