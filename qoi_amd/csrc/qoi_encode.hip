@@ -343,8 +343,95 @@ __device__ __forceinline__ uint32_t sub_byte2(uint32_t a, uint32_t b) {
     return r;
 }
 
-// chunk word tags (bits 25..26, above the bytes a short chunk stores): length class of the lane
-constexpr uint32_t kLenOne = 0u, kLenTwo = 1u << 25, kLenLong = 1u << 26;   // 1-byte chunks need no tag: nothing tests for them
+// chunk word tags (above the bytes a short chunk stores): length class of the lane.  1-byte chunks need no tag: nothing tests
+// for them.  With QOIMI_ENC_PAIR a QOI_OP_LUMA word comes out of v_perm_b32 with byte 3 = 0xFF (the only constants it offers
+// are 0x00 and 0xFF): two-byte words are the NEGATIVE ones, the long marker is 0x40000000 (the inline constant 2.0).
+#ifndef QOIMI_ENC_PAIR
+#define QOIMI_ENC_PAIR 1
+#endif
+[[maybe_unused]] constexpr uint32_t kLenOne = 0u, kLenTwo = QOIMI_ENC_PAIR ? 0xFF000000u : 1u << 25, kLenLong = QOIMI_ENC_PAIR ? 0x40000000u : 1u << 26;
+__device__ __forceinline__ bool word_is_two(uint32_t w) { return QOIMI_ENC_PAIR ? (int32_t)w < 0 : w >= kLenTwo; }     // (long words excluded by the caller where they can occur)
+__device__ __forceinline__ bool word_is_long(uint32_t w) { return QOIMI_ENC_PAIR ? (int32_t)w >= (int32_t)kLenLong : w >= kLenLong; }
+
+// ---- the literal classes of TWO steps at once (QOIMI_ENC_PAIR) -----------------------------------------------------------
+// The biased deltas of an even step and of the odd step after it share registers as 16-bit halves (the sign-extending SDWA adds
+// that make them anyway write WORD_0 / WORD_1), so the range tests' ORs and shifts, the subtractions for LUMA and the packing of
+// the DIFF / LUMA bytes are ONE packed instruction (v_pk_sub_u16, v_pk_lshrrev_b16, v_pk_mad_u16, v_or3) for both steps: 17
+// vector instructions per step for "deltas, tests, words" instead of 22.  The halves are taken apart again by the consumers'
+// operand selects (v_cmp_*_sdwa WORD_k, v_cndmask_b32_sdwa WORD_k, v_perm_b32), which cost nothing.
+struct PairClass {
+    uint32_t od2;   // tr | tg | tb per half (t = wrapped delta + 2): QOI_OP_DIFF iff < 4          (qoi.h:446-453)
+    uint32_t ol2;   // (ug >> 2) | ur | ub per half: QOI_OP_LUMA iff < 16                             (qoi.h:455-459)
+    uint32_t wd2;   // the DIFF byte 0x40 | tr << 4 | tg << 2 | tb per half
+    uint32_t b0p;   // the LUMA bytes per half: 0x80 | ug ...
+    uint32_t b1p;   // ... and ur << 4 | ub
+};
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_h2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void classify_pair(PairClass& K, uint32_t px0, uint32_t pv0, uint32_t px1, uint32_t pv1) {
+    // wrapped byte deltas in the low byte of d* (upper bits: don't care)
+    const uint32_t d0r = px0 - pv0, d0g = sub_byte1(px0, pv0), d0b = sub_byte2(px0, pv0);
+    const uint32_t d1r = px1 - pv1, d1g = sub_byte1(px1, pv1), d1b = sub_byte2(px1, pv1);
+    uint32_t tr2, tg2, tb2, tg82, ug2;
+    // half k = constant + sign-extended delta byte of step k.  (An instruction that writes part of a register must not be
+    // followed at once by one that reads the register: the five of the even step stand between every pair; s_nop at the end.)
+    asm("v_add_u32_sdwa %0, %5, sext(%8) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %1, %5, sext(%9) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %2, %5, sext(%10) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %3, %6, sext(%9) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %4, %7, sext(%9) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %0, %5, sext(%11) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %1, %5, sext(%12) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %2, %5, sext(%13) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %3, %6, sext(%12) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_add_u32_sdwa %4, %7, sext(%12) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "s_nop 0"
+        : "=&v"(tr2), "=&v"(tg2), "=&v"(tb2), "=&v"(tg82), "=&v"(ug2)
+        : "s"(2u), "s"(0xFFFFFFFAu), "s"(32u), "v"(d0r), "v"(d0g), "v"(d0b), "v"(d1r), "v"(d1g), "v"(d1b));
+    const uint32_t ur2 = as_u32(as_h2(tr2) - as_h2(tg82)), ub2 = as_u32(as_h2(tb2) - as_h2(tg82));    // dr-dg+8, db-dg+8
+    K.od2 = tr2 | tg2 | tb2;
+    K.ol2 = as_u32(as_h2(ug2) >> (u16x2)(2)) | ur2 | ub2;
+    K.wd2 = pk_mad_u16(tr2, 0x00100010u, pk_mad_u16(tg2, 0x00040004u, tb2)) | 0x00400040u;
+    K.b0p = ug2 | 0x00800080u;
+    K.b1p = pk_mad_u16(ur2, 0x00100010u, ub2);
+}
+// The literal chunk word of step HALF of the pair (qoi.h:438-474): QOI_OP_LUMA (byte 0 in bits 0..7, byte 1 in bits 16..23,
+// 0xFF on top) where its test holds, QOI_OP_DIFF where that one holds, the long marker where neither does or the alpha moved.
+// Also returns the lanes whose alpha moved.  Hand-scheduled: a scalar pair written by a vector compare is read two instructions
+// later at the earliest.
+template <int HALF>
+__device__ __forceinline__ uint32_t literal_word(const PairClass& K, uint32_t px, uint32_t prev, u64& m_ad) {
+    uint32_t we;
+    u64 s_luma;
+    if (HALF == 0) {
+        asm("v_cmp_gt_u32_sdwa %1, %3, %5 src0_sel:DWORD src1_sel:WORD_0\n\t"
+            "v_cmp_gt_u32_sdwa vcc, %4, %6 src0_sel:DWORD src1_sel:WORD_0\n\t"
+            "v_perm_b32 %0, %8, %7, %9\n\t"
+            "v_cmp_ne_u32_sdwa %2, %10, %11 src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+            "v_cndmask_b32 %0, 2.0, %0, %1\n\t"
+            "v_cndmask_b32_sdwa %0, %0, %12, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+            "v_cndmask_b32 %0, %0, 2.0, %2"
+            : "=&v"(we), "=&s"(s_luma), "=&s"(m_ad)
+            : "s"(16u), "s"(4u), "v"(K.ol2), "v"(K.od2), "v"(K.b0p), "v"(K.b1p), "s"(0x0D040C00u), "v"(px), "v"(prev), "v"(K.wd2) : "vcc");
+    } else {
+        asm("v_cmp_gt_u32_sdwa %1, %3, %5 src0_sel:DWORD src1_sel:WORD_1\n\t"
+            "v_cmp_gt_u32_sdwa vcc, %4, %6 src0_sel:DWORD src1_sel:WORD_1\n\t"
+            "v_perm_b32 %0, %8, %7, %9\n\t"
+            "v_cmp_ne_u32_sdwa %2, %10, %11 src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+            "v_cndmask_b32 %0, 2.0, %0, %1\n\t"
+            "v_cndmask_b32_sdwa %0, %0, %12, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+            "v_cndmask_b32 %0, %0, 2.0, %2"
+            : "=&v"(we), "=&s"(s_luma), "=&s"(m_ad)
+            : "s"(16u), "s"(4u), "v"(K.ol2), "v"(K.od2), "v"(K.b0p), "v"(K.b1p), "s"(0x0D060C02u), "v"(px), "v"(prev), "v"(K.wd2) : "vcc");
+    }
+    return we;
+}
 
 // per-lane constants of the step
 struct LaneConst {
@@ -358,8 +445,8 @@ struct LaneConst {
 // pixel after lane 63 is an edge.  GEN only: V valid lanes, lastbit the lane of the image's last pixel.
 // ccp (scalar) = 63 + (first pixel of the step - last edge before the step): stands in for clz(edges below the lane).
 // vbase (same value in every lane): LDS address of the next staged byte.
-template <int PROBE, bool GEN>
-__device__ __forceinline__ void encode_step(EncLds<PROBE>& L, const LaneConst& C, uint32_t lane, uint32_t px, uint32_t prev,
+template <int PROBE, bool GEN, int HALF>
+__device__ __forceinline__ void encode_step(EncLds<PROBE>& L, const LaneConst& C, uint32_t lane, uint32_t px, uint32_t prev, const PairClass& K,
                                             u64 Ec, u64 nb63, u64 V, u64 lastbit, uint32_t& ccp, uint32_t& vbase) {
     const u64 En = (Ec >> 1) | nb63 | lastbit;             // lanes whose successor is an edge (or that end the image)
     const u64 NE = GEN ? (~Ec & V) : ~Ec;                  // repeat pixels
@@ -408,29 +495,37 @@ __device__ __forceinline__ void encode_step(EncLds<PROBE>& L, const LaneConst& C
             __builtin_amdgcn_wave_barrier();
         }
         // ---- chunk of an edge pixel (qoi.h:432-474): INDEX, else RGBA if alpha moved, else DIFF, LUMA, RGB ----
-        // wrapped byte deltas live in the low byte of d*; consumers sign-extend that byte (SDWA)
-        const uint32_t d_r = px - prev, d_g = sub_byte1(px, prev), d_b = sub_byte2(px, prev);
-        const uint32_t tr = (int)(int8_t)d_r + 2, tg = (int)(int8_t)d_g + 2, tb = (int)(int8_t)d_b + 2;
-        const uint32_t tg8 = (int)(int8_t)d_g - 6, ug = (int)(int8_t)d_g + 32;
-        const uint32_t ur = tr - tg8, ub = tb - tg8;       // dr-dg+8, db-dg+8
-        const bool is_diff = (tr | tg | tb) < 4u;
-        const bool is_luma = ((ug >> 2) | ur | ub) < 16u;
-        const u64 m_ad = alpha_differs(px, prev);          // lanes whose alpha differs from the previous pixel's
-        const bool is_ad = in_mask(m_ad);
-        const uint32_t w_diff = (kTagDiff | kLenOne) | (tr << 4) | (tg << 2) | tb;
-        const uint32_t w_luma = (kTagLuma | kLenTwo | ug) | (ur << 20) | (ub << 16);
-        uint32_t we = is_luma ? w_luma : kLenLong;
-        we = is_diff ? w_diff : we;
-        we = is_ad ? kLenLong : we;
-        asm volatile("" : "+v"(we));                       // keep the literal classes branch-free (no sinking under !hit)
+        u64 m_ad;                                          // lanes whose alpha differs from the previous pixel's
+        uint32_t we;
+#if QOIMI_ENC_PAIR
+        we = literal_word<HALF>(K, px, prev, m_ad);
+#else
+        {
+            // wrapped byte deltas live in the low byte of d*; consumers sign-extend that byte (SDWA)
+            const uint32_t d_r = px - prev, d_g = sub_byte1(px, prev), d_b = sub_byte2(px, prev);
+            const uint32_t tr = (int)(int8_t)d_r + 2, tg = (int)(int8_t)d_g + 2, tb = (int)(int8_t)d_b + 2;
+            const uint32_t tg8 = (int)(int8_t)d_g - 6, ug = (int)(int8_t)d_g + 32;
+            const uint32_t ur = tr - tg8, ub = tb - tg8;       // dr-dg+8, db-dg+8
+            const bool is_diff = (tr | tg | tb) < 4u;
+            const bool is_luma = ((ug >> 2) | ur | ub) < 16u;
+            m_ad = alpha_differs(px, prev);
+            const bool is_ad = in_mask(m_ad);
+            const uint32_t w_diff = (kTagDiff | kLenOne) | (tr << 4) | (tg << 2) | tb;
+            const uint32_t w_luma = (kTagLuma | kLenTwo | ug) | (ur << 20) | (ub << 16);
+            we = is_luma ? w_luma : kLenLong;
+            we = is_diff ? w_diff : we;
+            we = is_ad ? kLenLong : we;
+            asm volatile("" : "+v"(we));                       // keep the literal classes branch-free (no sinking under !hit)
+        }
+#endif
         // QOI_OP_INDEX (qoi.h:432-434) where the slot held the pixel; the edge lanes take their chunk word, the others keep
         // their run byte (one v_cndmask under exec = edges instead of two)
         select_edge_word(w, we, (hsh >> 2) & 63u, seen, px, Ec);
-        const u64 lng = __ballot(w >= kLenLong);
+        const u64 lng = __ballot(word_is_long(w));
         if (__builtin_expect(lng != 0ull, 0)) {
             // rare in natural images: some lane carries QOI_OP_RGB / QOI_OP_RGBA (qoi.h:461-474): tag r g b (a)
             const u64 five = lng & m_ad;
-            const u64 two = __ballot(w >= kLenTwo) & ~lng;
+            const u64 two = __ballot(word_is_two(w)) & ~lng;
             const u64 b0 = (any & ~(two | lng)) | five;            // odd lengths: 1-byte chunks and RGBA
             const uint32_t off = vbase + count_below(b0) + 2u * count_below(two) + 4u * count_below(lng);
             const bool is_long = in_mask(lng);
@@ -443,7 +538,7 @@ __device__ __forceinline__ void encode_step(EncLds<PROBE>& L, const LaneConst& C
     }
     // ---- common case: chunk lengths 1 and 2 only.  offset = #chunks below + #LUMA chunks below ----
     {
-        const u64 two = __ballot(w >= kLenTwo) & any;
+        const u64 two = __ballot(word_is_two(w)) & any;
         const uint32_t off = count_below_from(two, count_below_from(any, vbase));
         stage_short(off, w, any, two);
         vbase += (uint32_t)__builtin_popcountll(any) + (uint32_t)__builtin_popcountll(two);
@@ -462,6 +557,7 @@ __device__ __forceinline__ void process_group(EncLds<PROBE>& L, const LaneConst&
                                               const uint32_t (&px)[kGroupSteps], const uint32_t (&pv)[kGroupSteps],
                                               uint32_t nx_px, uint32_t nx_pv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase) {
     if (GEN) E &= lanes_upto(rem);                         // (the group before this one does not know where the image ends)
+    PairClass K = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
     for (int t = 0; t < kGroupSteps; ++t) {
         const u64 Ec = E;
@@ -476,8 +572,12 @@ __device__ __forceinline__ void process_group(EncLds<PROBE>& L, const LaneConst&
         else E = __ballot(nx_px != nx_pv);
         if (GEN) E &= lanes_upto(rem - (t + 1) * 64);
         const u64 nb63 = E << 63;
+#if QOIMI_ENC_PAIR
+        if ((t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);   // this step and the next one
+#endif
         if (GEN && V == 0ull) continue;
-        encode_step<PROBE, GEN>(L, C, lane, px[t], pv[t], Ec, nb63, V, lastbit, ccp, vbase);
+        if (t & 1) encode_step<PROBE, GEN, 1>(L, C, lane, px[t], pv[t], K, Ec, nb63, V, lastbit, ccp, vbase);
+        else encode_step<PROBE, GEN, 0>(L, C, lane, px[t], pv[t], K, Ec, nb63, V, lastbit, ccp, vbase);
     }
 }
 
