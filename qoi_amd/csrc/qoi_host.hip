@@ -373,14 +373,16 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, int n_ima
         //     the three chains, 16 wavefronts per image in two sweeps plus a 16-step hand-over:
         //     t_chain ~ (groups / 8 + 16) * 0.5 us with groups = largest stream / B / 64
         // Small batches therefore get small segments (more lanes), a single large image not too small ones.
-        // Large batches end at 2 KiB (the 520-byte symbolic summary per segment is then a quarter of the stream).
+        // Large batches end at 4 KiB: the 520-byte symbolic summary and the two 260-byte entry states per segment are then an
+        // eighth of the stream (256 x 4K photographs: decode 10.3 ms at 2 KiB, 9.9 at 4 KiB - P3 -10 %, S3 halved; at 8 KiB the
+        // transcoder's 64 lanes read 512 KiB apart and lose 15 %).
         uint64_t bytes = 0, largest = 0;
         for (int i = 0; i < n_images; ++i) {
             const uint64_t sz = (uint64_t)(sizes[i] > 0 ? sizes[i] : 0);
             bytes += sz; if (sz > largest) largest = sz;
         }
         double best = 1e30;
-        for (uint32_t cand = 128; cand <= 2048u; cand <<= 1) {
+        for (uint32_t cand = 128; cand <= 4096u; cand <<= 1) {
             const double lanes = (double)bytes / cand;
             const double rounds = lanes <= 98304.0 ? 1.0 : lanes / 98304.0;
             const double t = (cand / 1.2) * 0.6 * rounds + ((double)largest / cand / 64.0 / 8.0 + 16.0) * 0.5;

@@ -227,7 +227,7 @@ def dense_record_streams():
     its records belong to this one) - B + 1 records from B bytes.  Round 2's first record pipeline reserved B and lost pixels on
     1 frame in 60 of the `uiflat` content at 512-byte segments.  Yields (name, B, stream, width, height)."""
     import struct
-    for B in (64, 128, 256, 512, 1024, 2048):
+    for B in (64, 128, 256, 512, 1024, 2048, 4096):
         for lead in (0, 1, 3):                      # the dense segment as segment 0 / after a few other chunks
             body = bytearray()
             body += bytes([0xFE, 10, 20, 30])       # an RGB first, so runs and INDEX have something to repeat

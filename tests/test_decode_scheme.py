@@ -52,7 +52,7 @@ def test_scheme_matches_golden(host_lib, golden, encoded_streams):
         desc = golden[f"dec/{c['name']}/desc"]
         och = c["channels"] if c["channels"] else int(desc[2])
         want = golden[f"dec/{c['name']}/pixels"]
-        for B, grp in ((5, 3), (7, 64), (16, 2), (64, 5), (333, 64), (2048, 64)):
+        for B, grp in ((5, 3), (7, 64), (16, 2), (64, 5), (333, 64), (2048, 64), (4096, 64)):
             for fast in (False, True, "rec"):     # readable primitives, the lean LUT-driven ones, the record pipeline of the kernels
                 got, stats = run(host_lib, c["stream"], och, B, grp, fast)
                 assert np.array_equal(got, want), (c["name"], B, grp, fast, stats)
@@ -121,4 +121,4 @@ def test_record_dense_segments(host_lib, port):
             got, stats = run(host_lib, stream, 4, B, 64, fast)
             assert np.array_equal(got, want), (name, fast, stats)
         n += 1
-    assert n == 18
+    assert n == 21

@@ -257,6 +257,7 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_PROBE": "0"},                             # order-independent colour-table probe (ds_or masks)
     {"QOIMI_DEC_FINE": "0", "QOIMI_SEG_BYTES": "2048"},   # lane-per-segment P1/P2 instead of 128-byte pieces
     {"QOIMI_SEG_BYTES": "1024"},                          # P1/P2 on 8 pieces per segment
+    {"QOIMI_SEG_BYTES": "4096"},                          # what large batches choose: 32 pieces per segment
     {"QOIMI_SEG_BYTES": "128"},                           # the piece is the segment (single-frame calls choose this)
     {"QOIMI_SEG_BYTES": "512"},                           # lane-per-segment P1/P2 (4 pieces: no piece path)
     {"QOIMI_DEC_REFINE": "0", "QOIMI_SEG_BYTES": "2048"},  # repair rounds without alpha hints
