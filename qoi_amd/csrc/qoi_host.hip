@@ -484,6 +484,10 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
 
     launch_decode_parse(p, st, &c->timer);
     long long rounds = 0, stats_seq = 0;
+    // A round that re-opens nearly as many segments as the one before it is not getting anywhere (a stream built against the
+    // speculation: one verified segment per image and round): two such rounds in a row and the rest goes to the sequential
+    // pass at once instead of after dec_max_rounds relaunches over everything (redo_segs accumulates over the rounds).
+    uint32_t redo_cum = 0, open_prev = 0xFFFFFFFFu; int stalled = 0;
     for (;;) {
         if (rounds > 0) HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
         launch_decode_round(p, och, rounds > 0 && c->dec_refine, st, &c->timer);
@@ -497,7 +501,13 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         HIP_TRY(hipStreamSynchronize(st));
         timer_collect(c);
         if (c->host_word[0] == 0) break;
-        if (rounds >= c->dec_max_rounds) {
+        {
+            const uint32_t open_now = c->host_word[1] - redo_cum;
+            redo_cum = c->host_word[1];
+            stalled = (rounds >= 3 && (uint64_t)open_now * 16u > (uint64_t)open_prev * 15u) ? stalled + 1 : 0;
+            open_prev = open_now;
+        }
+        if (rounds >= c->dec_max_rounds || stalled >= 2) {
             // bounded: whatever is still open is finished by the linear sequential pass (see dec_sequential)
             launch_decode_sequential(p, och, st, &c->timer);
             launch_decode_fill(p, och, st, &c->timer);

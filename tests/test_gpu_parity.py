@@ -644,7 +644,7 @@ def test_hostile_stream_finishes_in_bounded_rounds(api, ctx, oracle):
     buf = torch.from_numpy(np.frombuffer(s + b"\0" * 8, dtype=np.uint8).copy()).cuda()
     out = torch.full((w * h * 4 + 8,), 0xCD, dtype=torch.uint8, device="cuda")
     ctx.decode_batch(buf.data_ptr(), buf.numel(), [len(s)], [api.QoiDesc(w, h, 4, 0)], 4, out.data_ptr(), w * h * 4)
-    assert ctx.decode_stats()["rounds"] <= 24
+    assert ctx.decode_stats()["rounds"] <= 6          # two rounds in a row without progress: the rest is decoded sequentially
     want, _ = oracle.decode(s, 4)
     assert np.array_equal(out[:w * h * 4].cpu().numpy(), want)
 
