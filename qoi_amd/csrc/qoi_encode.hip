@@ -313,12 +313,6 @@ __device__ __forceinline__ uint32_t probe_swap_all(uint32_t addr, uint32_t px) {
 }
 __device__ __forceinline__ void probe_wait(uint32_t& seen) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(seen) : : "memory"); }
 
-// lanes where byte 3 (alpha) of a and b differ: one compare on the two bytes (SDWA)
-__device__ __forceinline__ u64 alpha_differs(uint32_t a, uint32_t b) {
-    u64 m;
-    asm("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3" : "=s"(m) : "v"(a), "v"(b));
-    return m;
-}
 // w = (seen == px ? idx : we) in the lanes of `edges`, unchanged elsewhere.  Waits for the probe's LDS result first.
 // (The scalar instructions between the compare and the select are also the two wait states gfx950 wants between a VALU
 // write of vcc and a VALU read of it.)
@@ -344,16 +338,13 @@ __device__ __forceinline__ uint32_t sub_byte2(uint32_t a, uint32_t b) {
 }
 
 // chunk word tags (above the bytes a short chunk stores): length class of the lane.  1-byte chunks need no tag: nothing tests
-// for them.  With QOIMI_ENC_PAIR a QOI_OP_LUMA word comes out of v_perm_b32 with byte 3 = 0xFF (the only constants it offers
-// are 0x00 and 0xFF): two-byte words are the NEGATIVE ones, the long marker is 0x40000000 (the inline constant 2.0).
-#ifndef QOIMI_ENC_PAIR
-#define QOIMI_ENC_PAIR 1
-#endif
-[[maybe_unused]] constexpr uint32_t kLenOne = 0u, kLenTwo = QOIMI_ENC_PAIR ? 0xFF000000u : 1u << 25, kLenLong = QOIMI_ENC_PAIR ? 0x40000000u : 1u << 26;
-__device__ __forceinline__ bool word_is_two(uint32_t w) { return QOIMI_ENC_PAIR ? (int32_t)w < 0 : w >= kLenTwo; }     // (long words excluded by the caller where they can occur)
-__device__ __forceinline__ bool word_is_long(uint32_t w) { return QOIMI_ENC_PAIR ? (int32_t)w >= (int32_t)kLenLong : w >= kLenLong; }
+// for them.  A QOI_OP_LUMA word comes out of v_perm_b32 with byte 3 = 0xFF (the only constants it offers are 0x00 and 0xFF):
+// two-byte words are the NEGATIVE ones, the long marker is 0x40000000 (the inline constant 2.0).
+constexpr uint32_t kLenLong = 0x40000000u;
+__device__ __forceinline__ bool word_is_two(uint32_t w) { return (int32_t)w < 0; }     // (long words excluded by the caller where they can occur)
+__device__ __forceinline__ bool word_is_long(uint32_t w) { return (int32_t)w >= (int32_t)kLenLong; }
 
-// ---- the literal classes of TWO steps at once (QOIMI_ENC_PAIR) -----------------------------------------------------------
+// ---- the literal classes of TWO steps at once ------------------------------------------------------------------------------
 // The biased deltas of an even step and of the odd step after it share registers as 16-bit halves (the sign-extending SDWA adds
 // that make them anyway write WORD_0 / WORD_1), so the range tests' ORs and shifts, the subtractions for LUMA and the packing of
 // the DIFF / LUMA bytes are ONE packed instruction (v_pk_sub_u16, v_pk_lshrrev_b16, v_pk_mad_u16, v_or3) for both steps: 17
@@ -497,27 +488,7 @@ __device__ __forceinline__ void encode_step(EncLds<PROBE>& L, const LaneConst& C
         // ---- chunk of an edge pixel (qoi.h:432-474): INDEX, else RGBA if alpha moved, else DIFF, LUMA, RGB ----
         u64 m_ad;                                          // lanes whose alpha differs from the previous pixel's
         uint32_t we;
-#if QOIMI_ENC_PAIR
         we = literal_word<HALF>(K, px, prev, m_ad);
-#else
-        {
-            // wrapped byte deltas live in the low byte of d*; consumers sign-extend that byte (SDWA)
-            const uint32_t d_r = px - prev, d_g = sub_byte1(px, prev), d_b = sub_byte2(px, prev);
-            const uint32_t tr = (int)(int8_t)d_r + 2, tg = (int)(int8_t)d_g + 2, tb = (int)(int8_t)d_b + 2;
-            const uint32_t tg8 = (int)(int8_t)d_g - 6, ug = (int)(int8_t)d_g + 32;
-            const uint32_t ur = tr - tg8, ub = tb - tg8;       // dr-dg+8, db-dg+8
-            const bool is_diff = (tr | tg | tb) < 4u;
-            const bool is_luma = ((ug >> 2) | ur | ub) < 16u;
-            m_ad = alpha_differs(px, prev);
-            const bool is_ad = in_mask(m_ad);
-            const uint32_t w_diff = (kTagDiff | kLenOne) | (tr << 4) | (tg << 2) | tb;
-            const uint32_t w_luma = (kTagLuma | kLenTwo | ug) | (ur << 20) | (ub << 16);
-            we = is_luma ? w_luma : kLenLong;
-            we = is_diff ? w_diff : we;
-            we = is_ad ? kLenLong : we;
-            asm volatile("" : "+v"(we));                       // keep the literal classes branch-free (no sinking under !hit)
-        }
-#endif
         // QOI_OP_INDEX (qoi.h:432-434) where the slot held the pixel; the edge lanes take their chunk word, the others keep
         // their run byte (one v_cndmask under exec = edges instead of two)
         select_edge_word(w, we, (hsh >> 2) & 63u, seen, px, Ec);
@@ -572,9 +543,7 @@ __device__ __forceinline__ void process_group(EncLds<PROBE>& L, const LaneConst&
         else E = __ballot(nx_px != nx_pv);
         if (GEN) E &= lanes_upto(rem - (t + 1) * 64);
         const u64 nb63 = E << 63;
-#if QOIMI_ENC_PAIR
         if ((t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);   // this step and the next one
-#endif
         if (GEN && V == 0ull) continue;
         if (t & 1) encode_step<PROBE, GEN, 1>(L, C, lane, px[t], pv[t], K, Ec, nb63, V, lastbit, ccp, vbase);
         else encode_step<PROBE, GEN, 0>(L, C, lane, px[t], pv[t], K, Ec, nb63, V, lastbit, ccp, vbase);
