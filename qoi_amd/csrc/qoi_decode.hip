@@ -938,6 +938,76 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2(DecParams p)
     sym_sweep_range(gs, hi - lo, lane, tabv, pxv, p.grp_entry + (size_t)(im.grp_base + lo) * 65u, 0u);
 }
 
+// The same level for a call of one to four large images (one 4K frame at 128-byte segments: 1250 groups): l2_wgs workgroups
+// per image, kL2Waves shares each.  A workgroup composes its shares into ONE symbolic summary, publishes it (tag of the
+// launch in its flag word), applies the summaries of the workgroups in front of it to the image's concrete start state and goes
+// on as dec_chain_state_l2 does: serial depth 2 * ngrp / (16 * wgs) + 32 + wgs instead of 2 * ngrp / 16 + 16 (45 -> 18 us for
+// the 4K frame).  A workgroup's place in its image is the order in which the workgroups STARTED (a ticket), so the ones it waits
+// for are running whatever order the dispatcher chose.
+__global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2m(DecParams p, uint32_t tag) {
+    __shared__ sym_t s_sum[kL2Waves + 1][65];    // symbolic summary of every share; [kL2Waves]: scratch of the hand-over
+    __shared__ uint32_t s_ent[kL2Waves][65];     // concrete state at every share's entry
+    __shared__ uint32_t s_k;
+    const uint32_t W = p.l2_wgs;
+    const uint32_t img = blockIdx.x / W, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) s_k = atomicAdd(&p.l2_ticket[img], 1u) & (W - 1u);      // every launch takes W tickets per image
+    __syncthreads();
+    const uint32_t k = s_k;
+    const DecImage im = p.images[img];
+    if (im.start_seg >= im.n_active) return;                                      // (all W workgroups of the image)
+    const uint32_t gfirst = im.start_seg / kGrp, gend = (im.n_active + kGrp - 1u) / kGrp;
+    const uint32_t per = (gend - gfirst + W * kL2Waves - 1u) / (W * kL2Waves);
+    const uint32_t lo = min(gfirst + (k * kL2Waves + wave) * per, gend), hi = min(lo + per, gend);
+    const sym_t* __restrict__ gs = p.grp_summary + (size_t)(im.grp_base + lo) * 65u;
+    {   // A: compose the share's group summaries
+        sym_t P_tab = sym_make(0u, lane, 0u), P_px = sym_make(0u, 64u, 0u);          // identity
+        sym_compose_range(gs, hi - lo, lane, P_tab, P_px);
+        s_sum[wave][lane] = P_tab;
+        if (lane == 0) s_sum[wave][64] = P_px;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        {   // B1: the workgroup's summary, for the workgroups behind it
+            sym_t P_tab = sym_make(0u, lane, 0u), P_px = sym_make(0u, 64u, 0u);
+            sym_compose_range(&s_sum[0][0], kL2Waves, lane, P_tab, P_px);
+            sym_t* out = p.l2_sum + (size_t)(img * W + k) * 65u;
+            out[lane] = P_tab;
+            if (lane == 0) out[64] = P_px;
+            __threadfence();
+            if (lane == 0) __hip_atomic_store(&p.l2_flag[img * W + k], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // B2: concrete state at this workgroup's entry, then at every share's entry
+        const size_t q0 = (size_t)im.seg_base + im.start_seg;
+        uint32_t tabv = p.entry[q0 * 65u + lane];        // concrete entry state of start_seg is given
+        uint32_t pxv = p.entry[q0 * 65u + 64u];
+        for (uint32_t c = 0; c < k; ++c) {
+            while (__hip_atomic_load(&p.l2_flag[img * W + c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
+            const sym_t* in = p.l2_sum + (size_t)(img * W + c) * 65u;
+            const sym_t c_tab = __hip_atomic_load(&in[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const sym_t c_px = __hip_atomic_load(&in[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px);
+            const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = gather_lane(tabv, src_p & 63u);
+            const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
+            const uint32_t npx = sym_eval(c_px, src_p == 64u ? pxv : g_p);
+            tabv = ntab; pxv = npx;
+        }
+        for (uint32_t c = 0; c < kL2Waves; ++c) {
+            s_ent[c][lane] = tabv;
+            if (lane == 0) s_ent[c][64] = pxv;
+            const sym_t c_tab = s_sum[c][lane], c_px = s_sum[c][64];
+            const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px);
+            const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = gather_lane(tabv, src_p & 63u);
+            const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
+            const uint32_t npx = sym_eval(c_px, src_p == 64u ? pxv : g_p);
+            tabv = ntab; pxv = npx;
+        }
+    }
+    __syncthreads();
+    // C: sweep the share
+    uint32_t tabv = s_ent[wave][lane], pxv = s_ent[wave][64];
+    sym_sweep_range(gs, hi - lo, lane, tabv, pxv, p.grp_entry + (size_t)(im.grp_base + lo) * 65u, 0u);
+}
+
 __global__ __launch_bounds__(64) void dec_chain_state_l3(DecParams p) {
     const uint32_t G = blockIdx.x, lane = lane_id();
     const uint32_t img = find_image_by_group(p.images, p.n_images, G);
@@ -1912,9 +1982,11 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     if (!p.total_segs) return;
     const uint32_t b64 = (p.total_segs + 63u) / 64u;
     tm->mark(kT_begin, st);
+    uint32_t l2_seq = 0;
     auto chain_state = [&]() {
         hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
-        hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
+        if (p.l2_wgs > 1u) hipLaunchKernelGGL(dec_chain_state_l2m, dim3(p.n_images * p.l2_wgs), dim3(64 * kL2Waves), 0, st, p, p.l2_tag_base + l2_seq++);
+        else hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
         hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);
         tm->mark(kT_dec_chain_state, st);
     };

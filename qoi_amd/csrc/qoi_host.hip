@@ -102,6 +102,7 @@ struct qoimi_ctx {
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
     int dec_p3_plain = 1, dec_inner = 4, dec_inner1 = 3;   // env QOIMI_P3_PLAIN, QOIMI_DEC_INNER, QOIMI_DEC_INNER1 (read once, at creation)
+    int dec_l2_wgs = 1;          // dec_chain_state_l2m: 0 never, 1 for calls of up to four images of 128 groups or more, 2 for every call of up to four images (env QOIMI_DEC_L2M, tests)
     int dec_max_rounds = kMaxSpecRounds;   // speculation rounds before the sequential last resort (env QOIMI_DEC_MAX_ROUNDS, tests)
     size_t last_drop_len = 0;           // length of the last stream the drop-in qoi_encode returned on this context (page populate-ahead)
     long long dec_seq_images = 0;       // images finished by dec_sequential since the context was created
@@ -163,6 +164,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_P3_PLAIN")) c->dec_p3_plain = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_INNER")) c->dec_inner = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_INNER1")) c->dec_inner1 = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_L2M")) c->dec_l2_wgs = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
     if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
     if (const char* e = getenv("QOIMI_SEG_BYTES")) {
@@ -448,9 +450,15 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         if ((uint64_t)total * (p.fine_per_seg ? p.fine_per_seg : 1u) > 0xFFFFFF00ull) return fail(QOIMI_E_ARG, "batch too large (piece index overflows 32 bits)");
         p.sync_all = p.fine_per_seg ? 0u : 1u;     // no piece parse for this segment size: full parse, then transcode from S1's phases
     }
+    {   // a few large images: the per-image level of the state chain as several workgroups per image (dec_chain_state_l2m)
+        uint64_t most = 0;
+        for (const DecImage& im : imgs) most = im.ngrp > most ? im.ngrp : most;
+        p.l2_wgs = (c->dec_l2_wgs && n_images <= 4 && (most >= 128u || c->dec_l2_wgs == 2)) ? 8u : 1u;                    // (4 images x 8 flags fit the counter header)
+    }
     for (int pass = 0; pass < 2; ++pass) {
         Carver w(pass ? c->dec_ws.base : nullptr);
         p.pending = w.take<uint32_t>(4); p.redo_segs = p.pending ? p.pending + 1 : nullptr; p.sync_fails = p.pending ? p.pending + 2 : nullptr;
+        p.l2_ticket = p.pending ? p.pending + 8 : nullptr; p.l2_flag = p.pending ? p.pending + 16 : nullptr;       // words 8..11 and 16..47 of the zeroed 256-byte header
         p.images = w.take<DecImage>((size_t)n_images);
         p.first_bad = w.take<uint32_t>((size_t)n_images);
         p.parse = w.take<ParseRec>(Q); p.entry_phase = w.take<uint8_t>(Q); p.px_off = w.take<uint32_t>(Q);
@@ -460,6 +468,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.grp_parse = w.take<ParseRec>(NG); p.grp_phase = w.take<uint8_t>(NG); p.grp_off = w.take<uint32_t>(NG);
         p.grp_slot = w.take<SlotRec>(NG); p.grp_slot_in = w.take<uint8_t>(NG); p.grp_alpha_in = w.take<uint8_t>(NG);
         p.grp_summary = w.take<u64>(NG * 65); p.grp_entry = w.take<uint32_t>(NG * 65);
+        p.l2_sum = w.take<u64>((size_t)n_images * p.l2_wgs * 65);
         p.rec_gran = w.take<uint32_t>(Q);
         p.sync_fail = w.take<uint8_t>(Q);
         p.recs = w.take<uint32_t>(((Q + 63u) / 64u) * p.rec_rows * 256u);
@@ -490,6 +499,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     uint32_t redo_cum = 0, open_prev = 0xFFFFFFFFu; int stalled = 0;
     for (;;) {
         if (rounds > 0) HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
+        p.l2_tag_base = (uint32_t)rounds * 64u + 1u;               // (a round launches S3 at most 1 + first_inner / refine_inner times)
         launch_decode_round(p, och, rounds > 0 && c->dec_refine, st, &c->timer);
         ++rounds;
         // pixels the chunks never reach (cheap; redone if the round has to be repeated) - before the read-back,

@@ -134,6 +134,12 @@ struct DecParams {
     uint32_t refine_inner;     // refinement rounds: repetitions of P3 + S3 before P4 (env QOIMI_DEC_INNER)
     uint32_t first_inner;      // first round: refinement passes (P3 from the speculated entry states + S3) appended for flat images (env QOIMI_DEC_INNER1)
     uint32_t only_flat;        // set by the launcher for those passes: dec_summarize_rec<true> serves flat images only
+    // calls of a few large images: the per-image level of the state chain (S3 l2) runs as l2_wgs workgroups per image
+    uint32_t  l2_wgs;          // 1: dec_chain_state_l2; 8: dec_chain_state_l2m (ticket / flag words live in the counter header)
+    uint32_t  l2_tag_base;     // first tag of this round's S3 launches (a launch's flags carry its tag: nothing to reset)
+    u64*      l2_sum;          // [n_images * l2_wgs][65] symbolic summary of a workgroup's groups
+    uint32_t* l2_ticket;       // [n_images] workgroups take their place in the image in start order
+    uint32_t* l2_flag;         // [n_images * l2_wgs] tag of the launch whose summary stands in l2_sum
     uint32_t p3_plain;         // 1: dec_summarize_rec starts in its one-dword plain form (QOIMI_P3_PLAIN=0 turns it off: diagnostics)
     uint32_t sync_all;         // 1: no look-back synchronisation - every segment takes the full parse (segment sizes the 128-byte piece parse does not cover)
     uint32_t* sync_fails;      // [1] segments whose look-back synchronisation failed in dec_transcode (they take the full parse)

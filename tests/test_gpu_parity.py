@@ -76,10 +76,12 @@ def test_decode_golden_bit_exact(api, golden, encoded_streams):
     assert n > 150
 
 
-@pytest.mark.parametrize("seg", [64, 333])
-def test_decode_small_segments(api, golden, encoded_streams, seg):
-    """Same golden streams with tiny decode segments: every segment boundary case + restart loop."""
+@pytest.mark.parametrize("seg,l2m", [(64, "1"), (333, "1"), (64, "2")])
+def test_decode_small_segments(api, golden, encoded_streams, seg, l2m):
+    """Same golden streams with tiny decode segments: every segment boundary case + restart loop (l2m 2: with the
+    multi-workgroup state chain that calls of a few large images use)."""
     os.environ["QOIMI_SEG_BYTES"] = str(seg)
+    os.environ["QOIMI_DEC_L2M"] = l2m
     try:
         import torch
         c = api.Context(0)
@@ -99,6 +101,7 @@ def test_decode_small_segments(api, golden, encoded_streams, seg):
         c.close()
     finally:
         del os.environ["QOIMI_SEG_BYTES"]
+        del os.environ["QOIMI_DEC_L2M"]
 
 
 def test_decode_record_dense_segments(api, oracle):
@@ -264,6 +267,9 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_DEC_REC_CAP_MB": "1"},                        # record arena capped at 1 MiB: the batch is decoded in sub-batches
     {"QOIMI_SEG_BYTES": "320"},                           # a segment size without the 128-byte piece parse: full parse, transcode from S1's phases
     {"QOIMI_P3_PLAIN": "0"},                              # P3 on records in its general form from the first chunk on
+    {"QOIMI_DEC_L2M": "2"},                               # the per-image level of the state chain as eight workgroups per image (calls of a few large images take it)
+    {"QOIMI_DEC_L2M": "2", "QOIMI_SEG_BYTES": "128"},     # ... with many groups per image, several rounds (uiflat)
+    {"QOIMI_DEC_L2M": "0"},                               # ... never
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
