@@ -30,6 +30,7 @@ Extra objects on the JSON line (rank 0, N = 1 unless noted):
   encode_1080p_batch   BASELINE configs[2]: 1024 x 1920x1080, encode only
   single_16k           BASELINE configs[3]: one 16384 x 16384 image, encode + decode
   other_content        the batch with noise / constant / uiflat content
+  rgb_input            a quarter of the batch as 3-channel input and output
   cpu_baseline         the unmodified reference (oracle/_ref, else our C port) timed on this
                        host with qoibench.c's BENCHMARK_FN semantics on a bounded sample.
 """
@@ -403,6 +404,38 @@ def main() -> None:
                            "stream_bytes_per_px": round(sum(ksizes) / (F * npx), 4), "decode_rounds": ctx.decode_stats()["rounds"],
                            "verified_bit_exact": kok, "reference_check": kchk}
 
+    # the same photographs as 3-channel input and output (qoi.h:406-413, 580-586: channels = 3), a quarter of the batch
+    rgb = None
+    if world == 1 and rank == 0 and not args.encode_only and not args.no_others:
+        F3 = max(1, min(F, 256))
+        ps3 = (npx * 3 + 255) // 256 * 256
+        d3 = api.QoiDesc(w, h, 3, api.QOI_SRGB)
+        ctx.synth_frames(synth.KIND_ID["photo"], synth.DEFAULT_SEED, 0, F3, w, h, pixels.data_ptr(), pstride, stream)
+        torch.cuda.synchronize()
+        src3 = decoded[:F3 * ps3].view(F3, ps3)
+        for lo in range(0, F3, 16):                                    # r,g,b of every pixel, tightly packed (no batch-sized temporary)
+            hi3 = min(F3, lo + 16)
+            src3[lo:hi3, :npx * 3] = pixels[lo * pstride:hi3 * pstride].view(hi3 - lo, pstride)[:, :npx * 4].view(hi3 - lo, npx, 4)[:, :, :3].reshape(hi3 - lo, npx * 3)
+        out3 = pixels[:F3 * ps3]
+        ctx.encode_batch(decoded.data_ptr(), ps3, d3, F3, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+        ctx.encode_status(stream)
+        s3 = [int(x) for x in lens[:F3].cpu().numpy()]
+        ctx.decode_batch(streams.data_ptr(), sstride, s3, [d3] * F3, 3, out3.data_ptr(), ps3, stream)                  # warm-up
+        e3 = lambda: ctx.encode_batch(decoded.data_ptr(), ps3, d3, F3, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+        x3 = lambda: ctx.decode_batch(streams.data_ptr(), sstride, s3, [d3] * F3, 3, out3.data_ptr(), ps3, stream)
+        te, td = timed(e3, 3), timed(x3, 3)
+        ok3 = equal_batches(torch, out3, decoded[:F3 * ps3], F3, ps3, npx * 3)
+        from oracle import oracle_py
+        lib3 = oracle_py.load_ref() or oracle_py.load_port()
+        ident3 = True
+        for fr in sorted({0, F3 - 1}):
+            px3 = decoded[fr * ps3:fr * ps3 + npx * 3].cpu().numpy()
+            ident3 = ident3 and streams[fr * sstride:fr * sstride + s3[fr]].cpu().numpy().tobytes() == lib3.encode(px3, w, h, 3)
+        rgb = {"workload": f"{F3} x {w}x{h} photo frames with 3 channels in and out, encode + decode, HBM-resident",
+               "mpixels_per_s": round(F3 * npx / (te + td) / 1e6, 1), "encode_ms": round(te * 1e3, 3), "decode_ms": round(td * 1e3, 3),
+               "encode_mpixels_per_s": round(F3 * npx / te / 1e6, 1), "decode_mpixels_per_s": round(F3 * npx / td / 1e6, 1),
+               "stream_bytes_per_px": round(sum(s3) / (F3 * npx), 4), "verified_bit_exact": bool(ok3), "streams_byte_identical_to_reference": bool(ident3)}
+
     # BASELINE configs[2]: 1024 x 1920x1080 RGBA, encode only (the HBM-bound roofline run) and configs[3]: one 16384 x 16384
     # image, encode + decode - in the buffers of the main batch where they fit
     cfg2 = cfg3 = None
@@ -546,6 +579,8 @@ def main() -> None:
             out["single_16k"] = cfg3
         if other:
             out["other_content"] = other
+        if rgb:
+            out["rgb_input"] = rgb
         if args.encode_only:
             out["config"]["workload"] += " [ENCODE ONLY - diagnostic run, not the benchmark]"
         if world == 1 and not args.no_cpu:
