@@ -162,8 +162,8 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
     if (const char* e = getenv("QOIMI_P3_PLAIN")) c->dec_p3_plain = atoi(e);
-    if (const char* e = getenv("QOIMI_DEC_INNER")) c->dec_inner = atoi(e);
-    if (const char* e = getenv("QOIMI_DEC_INNER1")) c->dec_inner1 = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_INNER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner = v; }
+    if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
     if (const char* e = getenv("QOIMI_DEC_L2M")) c->dec_l2_wgs = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
     if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
@@ -499,7 +499,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     uint32_t redo_cum = 0, open_prev = 0xFFFFFFFFu; int stalled = 0;
     for (;;) {
         if (rounds > 0) HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
-        p.l2_tag_base = (uint32_t)rounds * 64u + 1u;               // (a round launches S3 at most 1 + first_inner / refine_inner times)
+        p.l2_tag_base = (uint32_t)rounds * 65536u + 1u;            // (a round launches S3 1 + first_inner / refine_inner times: far fewer than 65536)
         launch_decode_round(p, och, rounds > 0 && c->dec_refine, st, &c->timer);
         ++rounds;
         // pixels the chunks never reach (cheap; redone if the round has to be repeated) - before the read-back,
