@@ -235,6 +235,9 @@ __device__ __forceinline__ uint32_t apply_relative(uint32_t px, uint32_t w32, ui
 // with 6.9 KB between the lanes' streams): 16 bytes per drain, the pieces of a line several hundred cycles apart - 1.0-1.4
 // TB/s (the L2 no longer merges them); 64 bytes per lane in one burst - 3.6 TB/s; 4 lanes x 16 bytes to one line - the same.
 // dec_segments_rec therefore drains groups of 16 pixels from a ring of 32.
+#ifndef QOIMI_SPLAT_ALIGN_IN_RING
+#define QOIMI_SPLAT_ALIGN_IN_RING 1
+#endif
 template <int OCH, uint32_t RING_ = 16, uint32_t GROUP_ = QOIMI_DRAIN_GROUP>
 struct LaneWriter {
     static constexpr uint32_t kRing = RING_;
@@ -300,6 +303,11 @@ struct LaneWriter {
     }
     // n copies of px from ppos on, not through the ring; n is reduced to the < 4 copies that remain for put()
     __device__ __forceinline__ void splat(uint32_t px, uint32_t& n) {
+#if QOIMI_SPLAT_ALIGN_IN_RING
+        // up to the next multiple of four through the ring: what finish() then writes are whole 16-byte pieces (it took
+        // up to three single-pixel stores for the ring's last pixels and up to three more to align the run)
+        while ((ppos & 3u) != 0u && n) { put(px); --n; }
+#endif
         finish();                                                         // ring out first: [fpos, ppos) stays contiguous
         while ((ppos & 3u) != 0u && n) { store_one(ppos, px); ++ppos; --n; }
         while (n >= 4u) {
