@@ -185,20 +185,22 @@ __global__ __launch_bounds__(64) void enc_scan_images(EncParams p) {
 //      FIRST set and for the group of steps that holds the image's last pixel; every other
 //      step runs the plain form (all 64 lanes valid, see probe_swap_all).
 //
-// Instruction budget (profiles/r01_s3_issue_rates.txt): a wave64 VALU op costs ~1.25-1.75 ns of a
-// SIMD, an SALU op ~1.8 ns (one scalar unit per CU) and overlaps with VALU only up to about half
-// the VALU count, a DS op 4 LDS cycles of the CU whatever its width.  So the step below is written
-// for few instructions of every kind:
+// Instruction budget (profiles/r03_s3_sq_counters_encode.txt): a wave64 vector instruction
+// occupies its SIMD for 4 cycles whatever it is, scalar instructions ride along almost for free (a third of a vector
+// instruction's cost at most), a DS op takes 4 LDS cycles of the CU whatever its width.  The kernel is bound by its
+// vector instruction count (49 per 64 pixels), so the step below is written for few of them:
 //   * every pixel emits at most ONE chunk: a repeat pixel carries the run byte of the run it
 //     closes (qoi.h:417-421,425-428 put that byte in front of the next edge's chunk, which is
 //     the same stream position), so chunk length is in {0,1,2,4,5} per lane;
-//   * the previous pixel of every lane is LOADED (a second, 4-byte-shifted request to the lines the
-//     pixels themselves come from, served by the L1) instead of moved across lanes;
+//   * the previous pixel of every lane is LOADED with the pixel (one 8-byte request per lane, 4 bytes - 3 for 3-channel
+//     input - in front of the pixel's address) instead of moved across lanes;
 //   * per-lane predicates live as 64-bit lane masks in SGPRs (ballot results); the few mask
 //     combinations are explicit scalar ops and come back as exec / v_cndmask masks through
 //     inverse_ballot;
 //   * chunk words keep byte 0 in bits 0..7 and byte 1 in bits 16..23 (ds_write_b8 /
-//     ds_write_b8_d16_hi take them from there), the length class in bits 25..26;
+//     ds_write_b8_d16_hi take them from there); two-byte words are the negative ones, 0x40000000 marks a long chunk;
+//   * the DIFF / LUMA classification of an edge pixel is worked out for two consecutive steps at once in the 16-bit
+//     halves of the registers (classify_pair);
 //   * work that a step does not need is skipped by wave-uniform branches (no edges: no
 //     hash/probe/deltas; no 4/5-byte chunk: no third offset count).
 // Chunk bytes go to a per-wave LDS staging buffer; when the set is done its byte offset in the
