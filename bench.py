@@ -522,7 +522,7 @@ def main() -> None:
                 f_prof = float(json.load(open(TRAFFIC_FILE)).get("frames", F))
             except (OSError, ValueError):
                 f_prof = float(F)
-            traffic, traffic_src = measured_traffic("qoimi::enc_sets<4, 1, 1>", -1, F / f_prof)
+            traffic, traffic_src = measured_traffic("qoimi::enc_sets<4, 1, 1", -1, F / f_prof)   # (any CLS instantiation: the committed passes name one)
         roof = lambda kernel, nbytes, ms, **kw: dict({"bound": "hbm", "kernel": kernel, "achieved": round(gbs(nbytes, ms), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                       "frac": round(gbs(nbytes, ms) / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 4)}, **kw)
         out = {
@@ -543,6 +543,8 @@ def main() -> None:
             "decode_mpps_kernels": round(F * npx * launches / (dec_ms * 1e3), 1) if dec_ms else None,
             "decode_rounds": dstats["rounds"], "decode_redo_segments": dstats["redo_segments"], "decode_sync_fallback_segments": dstats.get("sync_fallback_segments"),
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
+            "encoder_classes": {"0": "vector pipe (paired 16-bit halves)", "1": "matrix pipe (3 x v_mfma_i32_16x16x32_i8 per step)",
+                                "2": "matrix pipe, five wavefronts per SIMD"}.get(os.environ.get("QOIMI_ENC_CLS", "0"), "vector pipe (paired 16-bit halves)"),
             "roofline": roof("enc_sets (+ entry-state passes)", alg_bytes, per_launch_ms, traffic=traffic, traffic_source=traffic_src,
                              note="the kernel of the north star's 4K-encode roofline target; the kernel with the largest share of the step is in roofline_dominant"),
         }

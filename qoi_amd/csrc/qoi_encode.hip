@@ -426,6 +426,85 @@ __device__ __forceinline__ uint32_t literal_word(const PairClass& K, uint32_t px
     return we;
 }
 
+// ---- the literal classes of one step from the MATRIX pipe (CLS 1) ----------------------------------------------------------
+// Every quantity the classification of qoi.h:438-474 needs is an integer-linear form of the eight bytes (previous pixel, pixel)
+// a lane holds, taken modulo 256: the wrapped channel deltas plus their range-test bias, the 4 x QOI_COLOR_HASH slot offset
+// (qoi.h:322), and - where the range tests hold - the QOI_OP_DIFF byte 0x40 | (vr+2) << 4 | (vg+2) << 2 | (vb+2) =
+// 16 vr + 4 vg + vb + 106 and the QOI_OP_LUMA bytes 0x80 | (vg+32) = vg + 160 and (vg_r+8) << 4 | (vg_b+8) = 16 vr - 17 vg + vb + 136.
+// The kernel is bound by its VECTOR instruction count while the matrix pipe of the SIMD idles, so these byte dot products go
+// there: v_mfma_i32_16x16x32_i8 takes eight bytes per lane as its B operand - exactly the (previous pixel, pixel) register pair
+// of the step - and hands every lane four rows of a 16 x 32 coefficient matrix times those bytes.  Output lane l holds rows
+// 4 (l / 16) + r of column l % 16, and the K range of lane group l / 16 is that group's own eight bytes: with the coefficient
+// matrix block-diagonal (row 4 g + r non-zero only in the K range of group g) a lane's four results are four linear forms of ITS
+// OWN eight bytes.  Three such instructions per step (12 forms, 10 used) replace the byte subtractions, the sign-extending
+// adds, the packed multiply-adds and the v_dot4 of the vector-pipe form: 10 vector instructions per step for "deltas, tests,
+// words, hash" instead of 21.  No contraction across pixels takes place - the matrix pipe is used as a 12-way byte dot-product
+// unit with constant coefficients.  The bytes are read as SIGNED by the instruction: every form is only used modulo 256 (its
+// low byte, or bits 2..7 of it), where signed and unsigned readings agree (256 c = 0 mod 256).
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+struct MatConst {
+    long a1, a2, a3;   // this lane's piece of the three coefficient matrices (A operands)
+    v4i32 c3;          // the biases of the third one (C operand); the first two take an inline constant
+};
+struct StepClass {
+    uint32_t xr, xg, xb, h4;      // vr + 2, vg + 2, vb + 2 (QOI_OP_DIFF iff all three < 4 mod 256, qoi.h:446-453); 4 * hash + 2
+    uint32_t ur, ub, sp0, sp1;    // vg_r + 8, vg_b + 8                      (qoi.h:455-459); the two rows of that matrix that carry nothing
+    uint32_t b0, b1, wd, ug;      // LUMA byte 0, LUMA byte 1, DIFF byte, vg + 32
+};
+__device__ __forceinline__ uint32_t coef4(int c0, int c1, int c2, int c3) {
+    return (uint32_t)(c0 & 0xFF) | ((uint32_t)(c1 & 0xFF) << 8) | ((uint32_t)(c2 & 0xFF) << 16) | ((uint32_t)(c3 & 0xFF) << 24);
+}
+// row r of a coefficient matrix over (previous pixel r g b a, pixel r g b a): difference forms have opposite signs on the two
+__device__ __forceinline__ long coef_row(uint32_t on_prev, uint32_t on_px) { return (long)(((u64)on_px << 32) | (u64)on_prev); }
+__device__ __forceinline__ void mat_const_init(MatConst& M, uint32_t lane) {
+    // A operand of lane l: row l % 16 of the matrix, K range l / 16.  Non-zero only where row / 4 == l / 16 (block diagonal).
+    const uint32_t row = lane & 15u, grp = lane >> 4;
+    const bool on = (row >> 2) == grp;
+    const uint32_t r = row & 3u;
+    const uint32_t dr = coef4(1, 0, 0, 0), dg = coef4(0, 1, 0, 0), db = coef4(0, 0, 1, 0);
+    const uint32_t ndr = coef4(-1, 0, 0, 0), ndg = coef4(0, -1, 0, 0), ndb = coef4(0, 0, -1, 0);
+    // matrix 1 (+2): vr + 2, vg + 2, vb + 2, 12 r + 20 g + 28 b + 44 a + 2
+    const long m1 = r == 0u ? coef_row(ndr, dr) : r == 1u ? coef_row(ndg, dg) : r == 2u ? coef_row(ndb, db) : coef_row(0u, coef4(12, 20, 28, 44));
+    // matrix 2 (+8): vr - vg + 8, vb - vg + 8, -, -
+    const long m2 = r == 0u ? coef_row(coef4(-1, 1, 0, 0), coef4(1, -1, 0, 0)) : r == 1u ? coef_row(coef4(0, 1, -1, 0), coef4(0, -1, 1, 0)) : 0l;
+    // matrix 3: vg + 160, 16 vr - 17 vg + vb + 136, 16 vr + 4 vg + vb + 106, vg + 32
+    const long m3 = r == 0u ? coef_row(ndg, dg) : r == 1u ? coef_row(coef4(-16, 17, -1, 0), coef4(16, -17, 1, 0))
+                  : r == 2u ? coef_row(coef4(-16, -4, -1, 0), coef4(16, 4, 1, 0)) : coef_row(ndg, dg);
+    M.a1 = on ? m1 : 0l; M.a2 = on ? m2 : 0l; M.a3 = on ? m3 : 0l;
+    M.c3 = (v4i32){160, 136, 106, 32};
+    asm volatile("" : "+v"(M.a1), "+v"(M.a2), "+v"(M.a3), "+v"(M.c3));     // materialised once, not re-derived per step
+}
+__device__ __forceinline__ void mat_classify(StepClass& S, const MatConst& M, uint32_t px, uint32_t prev) {
+    const long b = (long)(((u64)px << 32) | (u64)prev);       // the register pair as loaded
+    const v4i32 d1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(M.a1, b, (v4i32){2, 2, 2, 2}, 0, 0, 0);
+    const v4i32 d3 = __builtin_amdgcn_mfma_i32_16x16x32_i8(M.a3, b, M.c3, 0, 0, 0);
+    const v4i32 d2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(M.a2, b, (v4i32){8, 8, 8, 8}, 0, 0, 0);
+    S.xr = (uint32_t)d1[0]; S.xg = (uint32_t)d1[1]; S.xb = (uint32_t)d1[2]; S.h4 = (uint32_t)d1[3];
+    S.ur = (uint32_t)d2[0]; S.ub = (uint32_t)d2[1]; S.sp0 = (uint32_t)d2[2]; S.sp1 = (uint32_t)d2[3];
+    S.b0 = (uint32_t)d3[0]; S.b1 = (uint32_t)d3[1]; S.wd = (uint32_t)d3[2]; S.ug = (uint32_t)d3[3];
+}
+// The literal chunk word from those forms (the same word literal_word<HALF> makes from the packed halves): the tests read the
+// low bytes through SDWA selects.
+__device__ __forceinline__ uint32_t range_word_diff(const StepClass& S) { return S.xr | S.xg | S.xb; }                                  // DIFF iff low byte < 4
+__device__ __forceinline__ uint32_t range_word_luma(const StepClass& S) { return __builtin_amdgcn_ubfe(S.ug, 2u, 6u) | S.ur | S.ub; }   // LUMA iff low byte < 16 (vg + 32 < 64, the others < 16)
+__device__ __forceinline__ uint32_t literal_word_mat(const StepClass& S, uint32_t od, uint32_t ol, uint32_t px, uint32_t prev, u64& m_ad) {
+    uint32_t we;
+    u64 s_luma;
+    asm("v_cmp_gt_u32_sdwa %1, %3, %5 src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa vcc, %4, %6 src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_perm_b32 %0, %8, %7, %9\n\t"
+        "v_cmp_ne_u32_sdwa %2, %10, %11 src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+        "v_cndmask_b32 %0, 2.0, %0, %1\n\t"
+        "v_cndmask_b32_sdwa %0, %0, %12, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_cndmask_b32 %0, %0, 2.0, %2"
+        : "=&v"(we), "=&s"(s_luma), "=&s"(m_ad)
+        : "s"(16u), "s"(4u), "v"(ol), "v"(od), "v"(S.b0), "v"(S.b1), "s"(0x0D040C00u), "v"(px), "v"(prev), "v"(S.wd),
+          // (the idle rows of the second matrix stay allocated up to here: handed out as temporaries right behind the instruction
+          // that writes them, they make the wavefront wait for it at once)
+          "v"(S.sp0), "v"(S.sp1) : "vcc");
+    return we;
+}
+
 // per-lane constants of the step
 struct LaneConst {
     uint32_t below_lo, below_hi;   // masks of the lanes below this one
@@ -438,9 +517,11 @@ struct LaneConst {
 // pixel after lane 63 is an edge.  GEN only: V valid lanes, lastbit the lane of the image's last pixel.
 // ccp (scalar) = 63 + (first pixel of the step - last edge before the step): stands in for clz(edges below the lane).
 // vbase (same value in every lane): LDS address of the next staged byte.
-template <int PROBE, bool GEN, int HALF>
+// CLS 0: the literal classes come from classify_pair (K, vector pipe); CLS 1, 2: from mat_classify (S, matrix pipe; 2 is the same
+// code compiled for five wavefronts per SIMD instead of six - 96 registers, no spill around the pipelined loop).
+template <int PROBE, bool GEN, int HALF, int CLS>
 __device__ __forceinline__ void encode_step(EncLds<PROBE>& L, const LaneConst& C, uint32_t lane, uint32_t px, uint32_t prev, const PairClass& K,
-                                            u64 Ec, u64 nb63, u64 V, u64 lastbit, uint32_t& ccp, uint32_t& vbase) {
+                                            const StepClass& S, u64 Ec, u64 nb63, u64 V, u64 lastbit, uint32_t& ccp, uint32_t& vbase) {
     const u64 En = (Ec >> 1) | nb63 | lastbit;             // lanes whose successor is an edge (or that end the image)
     const u64 NE = GEN ? (~Ec & V) : ~Ec;                  // repeat pixels
     u64 RB = NE & En;                                      // repeat pixels that close a run: they carry its run byte
@@ -467,8 +548,11 @@ __device__ __forceinline__ void encode_step(EncLds<PROBE>& L, const LaneConst& C
     if (Ec) {
         ccp = clz64_plus64(Ec);
         // ---- colour-table probe/update (qoi.h:430-436) for edge pixels ---------------------
-        const uint32_t hsh = __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);   // 4 * QOI_COLOR_HASH (qoi.h:322)
+        // 4 * QOI_COLOR_HASH (qoi.h:322); CLS 1: the same modulo 256 with 2 on top (only bits 2..7 are looked at)
+        const uint32_t hsh = CLS != 0 ? S.h4 : __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);
         uint32_t seen = ~px;
+        uint32_t od = 0u, ol = 0u;
+        if (CLS != 0) { od = range_word_diff(S); ol = range_word_luma(S); }
         if (PROBE == 1) {
             seen = GEN ? probe_swap((hsh & 0xFCu) | C.tbase, px, Ec) : probe_swap_all((hsh & 0xFCu) | C.tbase, px);
         } else {
@@ -490,7 +574,8 @@ __device__ __forceinline__ void encode_step(EncLds<PROBE>& L, const LaneConst& C
         // ---- chunk of an edge pixel (qoi.h:432-474): INDEX, else RGBA if alpha moved, else DIFF, LUMA, RGB ----
         u64 m_ad;                                          // lanes whose alpha differs from the previous pixel's
         uint32_t we;
-        we = literal_word<HALF>(K, px, prev, m_ad);
+        if (CLS != 0) we = literal_word_mat(S, od, ol, px, prev, m_ad);
+        else we = literal_word<HALF>(K, px, prev, m_ad);
         // QOI_OP_INDEX (qoi.h:432-434) where the slot held the pixel; the edge lanes take their chunk word, the others keep
         // their run byte (one v_cndmask under exec = edges instead of two)
         select_edge_word(w, we, (hsh >> 2) & 63u, seen, px, Ec);
@@ -525,8 +610,8 @@ __device__ __forceinline__ u64 lanes_upto(int r) { return r >= 64 ? ~0ull : (r <
 // E: edges of the group's first step on entry, of the first step AFTER the group on exit (from nx_px / nx_pv: the first
 // step of the next group, or the two pixels around the end of the set).  GEN: rem = pixels of the image left at the
 // group's first pixel.
-template <int PROBE, bool GEN>
-__device__ __forceinline__ void process_group(EncLds<PROBE>& L, const LaneConst& C, uint32_t lane,
+template <int PROBE, bool GEN, int CLS>
+__device__ __forceinline__ void process_group(EncLds<PROBE>& L, const LaneConst& C, const MatConst& M, uint32_t lane,
                                               const uint32_t (&px)[kGroupSteps], const uint32_t (&pv)[kGroupSteps],
                                               uint32_t nx_px, uint32_t nx_pv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase) {
     if (GEN) E &= lanes_upto(rem);                         // (the group before this one does not know where the image ends)
@@ -545,10 +630,14 @@ __device__ __forceinline__ void process_group(EncLds<PROBE>& L, const LaneConst&
         else E = __ballot(nx_px != nx_pv);
         if (GEN) E &= lanes_upto(rem - (t + 1) * 64);
         const u64 nb63 = E << 63;
-        if ((t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);   // this step and the next one
+        if (CLS == 0 && (t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);   // this step and the next one
+        // CLS 1: this step's forms are asked of the matrix pipe here, ahead of the run-length work of the step (their first
+        // use, the slot address of the probe, comes after it)
+        StepClass S;                                           // (only looked at under the same condition: no merge with a value for the other case)
+        if (CLS != 0 && Ec != 0ull) mat_classify(S, M, px[t], pv[t]);
         if (GEN && V == 0ull) continue;
-        if (t & 1) encode_step<PROBE, GEN, 1>(L, C, lane, px[t], pv[t], K, Ec, nb63, V, lastbit, ccp, vbase);
-        else encode_step<PROBE, GEN, 0>(L, C, lane, px[t], pv[t], K, Ec, nb63, V, lastbit, ccp, vbase);
+        if (t & 1) encode_step<PROBE, GEN, 1, CLS>(L, C, lane, px[t], pv[t], K, S, Ec, nb63, V, lastbit, ccp, vbase);
+        else encode_step<PROBE, GEN, 0, CLS>(L, C, lane, px[t], pv[t], K, S, Ec, nb63, V, lastbit, ccp, vbase);
     }
 }
 
@@ -729,7 +818,7 @@ __device__ __forceinline__ uint32_t spill_stage(EncLds<PROBE>& L, uint8_t* __res
     return spos & 15u;
 }
 
-template <int CH, int PROBE, int ENTRY>
+template <int CH, int PROBE, int ENTRY, int CLS>
 __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, EncLds<PROBE>& L) {
     const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
     const uint32_t n = p.npx;
@@ -771,6 +860,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     C.lane_run = lane + 128u;
     C.tbase = lds_addr(L.table);                               // 256-byte aligned
     asm volatile("" : "+v"(C.tbase));                          // keep in a VGPR
+    MatConst M = {0l, 0l, 0l, (v4i32){0, 0, 0, 0}};
+    if (CLS != 0) mat_const_init(M, lane);
     int last_edge;
     if (ENTRY == 1) {
         if (!warm_entry_state<CH, PROBE>(pix, lo, lane, L, C.tbase, in, last_edge)) {
@@ -816,7 +907,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 if (spos > kStageSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, bx, bv);
                 else { bx[0] = load_px<CH>(pix, base + kGroupPx); bv[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
-                process_group<PROBE, false>(L, C, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
+                process_group<PROBE, false, CLS>(L, C, M, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
                 if (++g >= nint) break;
             }
             {   // group g sits in b*; fetch g+1 into a*
@@ -825,7 +916,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 if (spos > kStageSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, ax, av);
                 else { ax[0] = load_px<CH>(pix, base + kGroupPx); av[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
-                process_group<PROBE, false>(L, C, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
+                process_group<PROBE, false, CLS>(L, C, M, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
                 if (++g >= nint) break;
             }
         }
@@ -842,7 +933,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         load_pair_guarded<CH>(pix, base + kGroupPx + lane, n, nxp, nxv);
         if (g + 1u == ngroups) ask_early();
         u64 E = __ballot(ax[0] != av[0]);
-        process_group<PROBE, true>(L, C, lane, ax, av, nxp, nxv, (int)(n - base), E, ccp, vbase);
+        process_group<PROBE, true, CLS>(L, C, M, lane, ax, av, nxp, nxv, (int)(n - base), E, ccp, vbase);
     }
     uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
     const uint32_t set_bytes = spilled + spos;
@@ -920,8 +1011,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 // the ENTRY 0 passes with only_flagged set: small grid-stride grids that return at once when nothing was
 // flagged.  A workgroup serves unit u = (image u % n_images, four consecutive sets u / n_images) so that the
 // sets in flight spread over all images.
-template <int CH, int PROBE, int ENTRY>
-__global__ __launch_bounds__(256, PROBE == 1 ? QOIMI_ENC_WAVES_PER_SIMD : 4) void enc_sets(EncParams p) {
+template <int CH, int PROBE, int ENTRY, int CLS>
+__global__ __launch_bounds__(256, PROBE == 1 ? (CLS == 2 ? QOIMI_ENC_WAVES_PER_SIMD - 1 : QOIMI_ENC_WAVES_PER_SIMD) : 4) void enc_sets(EncParams p) {
     __shared__ EncLds<PROBE> s_lds[4];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
@@ -940,7 +1031,7 @@ __global__ __launch_bounds__(256, PROBE == 1 ? QOIMI_ENC_WAVES_PER_SIMD : 4) voi
             if (lane == 0) t = atomicAdd(&p.ticket[img], 1u);
             set = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         }
-        if (set < p.sets_per_image) encode_set<CH, PROBE, ENTRY>(p, img, set, lane, s_lds[wave]);
+        if (set < p.sets_per_image) encode_set<CH, PROBE, ENTRY, CLS>(p, img, set, lane, s_lds[wave]);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1083,7 +1174,7 @@ __global__ __launch_bounds__(64 * WAVES) void lds_order_selftest(uint32_t* out) 
 // ---------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------
-template <int CH, int PROBE>
+template <int CH, int PROBE, int CLS>
 static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int phases) {
     const uint32_t total_slabs = p.n_images * p.spi;
     const uint32_t slab_blocks = (total_slabs + 3u) / 4u;
@@ -1095,7 +1186,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     if (phases & kEncSlabs) {
     if (warm) {
         p.only_flagged = 0;
-        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1>), dim3(p.n_units), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, CLS>), dim3(p.n_units), dim3(256), 0, st, p);
         tm->mark(kT_enc_slabs, st);
         p.only_flagged = 1;
     } else {
@@ -1113,7 +1204,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     // (256 flat 4K frames: 9.0 ms with look-back, 7.5 order-free).  The placement passes then serve the flagged images only.
     const bool first_lookback = p.lookback != 0;
     if (warm) p.lookback = 0;
-    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0, CLS>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
     tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
     p.only_flagged = (warm && first_lookback) ? 1 : 0;
     }
@@ -1127,12 +1218,18 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
 }
 
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phases) {
+    // (the matrix-pipe classes exist for the exchange probe only: the order-independent probe is the fall-back path)
     if (p.channels == 3) {
-        if (p.probe_xchg) launch_encode_t<3, 1>(p, st, tm, phases); else launch_encode_t<3, 0>(p, st, tm, phases);
+        if (!p.probe_xchg) launch_encode_t<3, 0, 0>(p, st, tm, phases);
+        else if (p.cls_mat == 2) launch_encode_t<3, 1, 2>(p, st, tm, phases);
+        else if (p.cls_mat) launch_encode_t<3, 1, 1>(p, st, tm, phases);
+        else launch_encode_t<3, 1, 0>(p, st, tm, phases);
         return;
     }
-    if (!p.probe_xchg) { launch_encode_t<4, 0>(p, st, tm, phases); return; }
-    launch_encode_t<4, 1>(p, st, tm, phases);
+    if (!p.probe_xchg) { launch_encode_t<4, 0, 0>(p, st, tm, phases); return; }
+    if (p.cls_mat == 2) launch_encode_t<4, 1, 2>(p, st, tm, phases);
+    else if (p.cls_mat) launch_encode_t<4, 1, 1>(p, st, tm, phases);
+    else launch_encode_t<4, 1, 0>(p, st, tm, phases);
 }
 
 // returns the number of mismatching patterns of the LDS exchange-order self-test (0 = ordered)

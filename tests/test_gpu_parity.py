@@ -270,6 +270,10 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_DEC_L2M": "2"},                               # the per-image level of the state chain as eight workgroups per image (calls of a few large images take it)
     {"QOIMI_DEC_L2M": "2", "QOIMI_SEG_BYTES": "128"},     # ... with many groups per image, several rounds (uiflat)
     {"QOIMI_DEC_L2M": "0"},                               # ... never
+    {"QOIMI_ENC_CLS": "1"},                               # literal classes of a step from the matrix pipe (three v_mfma_i32_16x16x32_i8 per step)
+    {"QOIMI_ENC_CLS": "2"},                               # ... at five wavefronts per SIMD
+    {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_WARM": "0"},        # ... with the entry states from the summary passes
+    {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
@@ -451,7 +455,8 @@ def test_flat_frames_byte_identical(api, oracle, env):
                 os.environ[k] = v
 
 
-def test_random_sweep_of_contents_and_shapes(api, oracle):
+@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_CLS": "1"}, {"QOIMI_ENC_CLS": "2"}])
+def test_random_sweep_of_contents_and_shapes(api, oracle, env):
     """A seeded sweep over every synthetic content kind at shapes from a few pixels to several 64-slab groups, 3 and 4 channels:
     encode byte-identical to the reference, decode of that stream bit-identical to the pixels.  (The fixed shapes of the other
     tests never put hash slot 31 into the entry path that lost its upper mask half; a sweep would have.)"""
@@ -460,7 +465,16 @@ def test_random_sweep_of_contents_and_shapes(api, oracle):
     from qoi_amd import synth
     rng = np.random.default_rng(20260923)
     shapes = [(1, 1), (3, 2), (64, 16), (65, 17), (1023, 1), (1, 1025), (257, 255), (640, 360), (1024, 600), (1400, 900), (2048, 130)]
-    c = api.Context(0)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)                      # (read when the context is created)
+    try:
+        c = api.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     checked = 0
     for (w, h) in shapes:
         for ch in (4, 3):
@@ -545,7 +559,8 @@ def _mixed_frame(rng, w, h, ch, seed):
     return np.ascontiguousarray(a.reshape(h, w, 4)[:, :, :ch])
 
 
-@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_SET_SLABS": "3"}, {"QOIMI_ENC_SET_SLABS": "8"}, {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"}])
+@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_SET_SLABS": "3"}, {"QOIMI_ENC_SET_SLABS": "8"}, {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
+                                 {"QOIMI_ENC_CLS": "1"}, {"QOIMI_ENC_CLS": "2", "QOIMI_ENC_SET_SLABS": "3"}])
 def test_mixed_content_partial_spills(api, oracle, env):
     """Sets whose bytes only partly fit the LDS staging buffer (tools/dev/sweep_enc.py is the long form of this test)."""
     import torch
