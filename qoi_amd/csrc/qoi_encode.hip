@@ -217,15 +217,18 @@ constexpr uint32_t kGroupPx = 64u * kGroupSteps;
 #define QOIMI_ENC_WAVES_PER_SIMD 6
 #endif
 constexpr uint32_t kStageBytes = QOIMI_ENC_STAGE_BYTES; // staging buffer of a wavefront (6 workgroups of 4 per CU: 4 x 6656 x 6 = 156 KB of LDS)
-constexpr uint32_t kStageSpill = kStageBytes - kGroupSteps * 320u - 16u;   // more staged bytes than this before a group: spill first
+constexpr uint32_t kStageBytesBig = 7616;              // ... of the five-wavefront form (CLS 2): 5 x 4 x 7936 = 155 KB
 
-template <int PROBE>
+template <int PROBE, uint32_t STAGE>
 struct EncLds {
-    static constexpr uint32_t kStageDwords = kStageBytes / 4u + 8u;
+    static constexpr uint32_t kStageDwords = STAGE / 4u + 8u;
+    static constexpr uint32_t kSpill = STAGE - kGroupSteps * 320u - 16u;   // more staged bytes than this before a group: spill first
     alignas(256) uint32_t table[64];   // 256-byte aligned: slot address = base | (4*slot)
     alignas(16) uint32_t stage[kStageDwords];
     u64 mask[PROBE == 0 ? 64 : 1];     // PROBE 0 only
 };
+
+template <int PROBE, int CLS> using EncLdsFor = EncLds<PROBE, CLS == 2 ? kStageBytesBig : kStageBytes>;
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -519,8 +522,8 @@ struct LaneConst {
 // vbase (same value in every lane): LDS address of the next staged byte.
 // CLS 0: the literal classes come from classify_pair (K, vector pipe); CLS 1, 2: from mat_classify (S, matrix pipe; 2 is the same
 // code compiled for five wavefronts per SIMD instead of six - 96 registers, no spill around the pipelined loop).
-template <int PROBE, bool GEN, int HALF, int CLS>
-__device__ __forceinline__ void encode_step(EncLds<PROBE>& L, const LaneConst& C, uint32_t lane, uint32_t px, uint32_t prev, const PairClass& K,
+template <int PROBE, bool GEN, int HALF, int CLS, class LDS>
+__device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, uint32_t lane, uint32_t px, uint32_t prev, const PairClass& K,
                                             const StepClass& S, u64 Ec, u64 nb63, u64 V, u64 lastbit, uint32_t& ccp, uint32_t& vbase) {
     const u64 En = (Ec >> 1) | nb63 | lastbit;             // lanes whose successor is an edge (or that end the image)
     const u64 NE = GEN ? (~Ec & V) : ~Ec;                  // repeat pixels
@@ -610,8 +613,8 @@ __device__ __forceinline__ u64 lanes_upto(int r) { return r >= 64 ? ~0ull : (r <
 // E: edges of the group's first step on entry, of the first step AFTER the group on exit (from nx_px / nx_pv: the first
 // step of the next group, or the two pixels around the end of the set).  GEN: rem = pixels of the image left at the
 // group's first pixel.
-template <int PROBE, bool GEN, int CLS>
-__device__ __forceinline__ void process_group(EncLds<PROBE>& L, const LaneConst& C, const MatConst& M, uint32_t lane,
+template <int PROBE, bool GEN, int CLS, class LDS>
+__device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, const MatConst& M, uint32_t lane,
                                               const uint32_t (&px)[kGroupSteps], const uint32_t (&pv)[kGroupSteps],
                                               uint32_t nx_px, uint32_t nx_pv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase) {
     if (GEN) E &= lanes_upto(rem);                         // (the group before this one does not know where the image ends)
@@ -696,9 +699,9 @@ constexpr int kWarmSteps = 128;      // look-back window: 8192 pixels (natural c
 constexpr int kWarmBatch = 8;        // 64-pixel steps loaded together
 constexpr int kWarmMinFilled = 48;   // slots that must be known after the first batch (512 pixels), else the content is flat: give up
 
-template <int CH, int PROBE>
+template <int CH, int PROBE, class LDS>
 __device__ __forceinline__ bool warm_entry_state(const uint8_t* __restrict__ pix, uint32_t lo, uint32_t lane,
-                                                 EncLds<PROBE>& L, uint32_t tbase, const SetIn& in, int& last_edge) {
+                                                 LDS& L, uint32_t tbase, const SetIn& in, int& last_edge) {
     last_edge = -1;
     if (lo == 0u) { L.table[lane] = 0u; return true; }       // qoi.h:393: zeroed table, no edge yet
     const uint32_t sent = lane + 1u;
@@ -779,7 +782,7 @@ __device__ __forceinline__ void copy_global_out(const uint8_t* __restrict__ src,
     const uint32_t done = head + (n16 << 4);
     if (lane < n - done) dst[done + lane] = src[done + lane];
 }
-// the same from the wavefront's LDS staging buffer (n <= kStageBytes)
+// the same from the wavefront's LDS staging buffer
 __device__ __forceinline__ void copy_stage_out(const uint32_t* stage, uint8_t* __restrict__ dst, uint32_t n, uint32_t lane) {
     const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
     const uint32_t mis = (uint32_t)(uintptr_t)dst & 15u;
@@ -802,8 +805,8 @@ __device__ __forceinline__ void copy_stage_out(const uint32_t* stage, uint8_t* _
 
 // Moves the staged bytes [0, spos) to the set's scratch slot behind the `spilled` bytes already there (a multiple of 16).
 // all = false: whole 16-byte pieces only, the remainder moves to the front of the staging buffer.  Returns the bytes left staged.
-template <int PROBE>
-__device__ __forceinline__ uint32_t spill_stage(EncLds<PROBE>& L, uint8_t* __restrict__ slot, uint32_t& spilled, uint32_t spos, bool all, uint32_t lane) {
+template <int PROBE, class LDS>
+__device__ __forceinline__ uint32_t spill_stage(LDS& L, uint8_t* __restrict__ slot, uint32_t& spilled, uint32_t spos, bool all, uint32_t lane) {
     const uint32_t n16 = all ? (spos + 15u) >> 4 : spos >> 4;
     uint4* __restrict__ dst = reinterpret_cast<uint4*>(slot + spilled);
     const uint4* src = reinterpret_cast<const uint4*>(L.stage);
@@ -818,8 +821,8 @@ __device__ __forceinline__ uint32_t spill_stage(EncLds<PROBE>& L, uint8_t* __res
     return spos & 15u;
 }
 
-template <int CH, int PROBE, int ENTRY, int CLS>
-__device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, EncLds<PROBE>& L) {
+template <int CH, int PROBE, int ENTRY, int CLS, class LDS>
+__device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, LDS& L) {
     const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
     const uint32_t n = p.npx;
     const uint32_t lo = set * p.set_px;                        // first pixel of the set (a slab boundary)
@@ -904,7 +907,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
             {   // group g sits in a*; fetch g+1 into b*
                 const uint32_t base = lo + g * kGroupPx;
                 const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-                if (spos > kStageSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+                if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, bx, bv);
                 else { bx[0] = load_px<CH>(pix, base + kGroupPx); bv[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
                 process_group<PROBE, false, CLS>(L, C, M, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
@@ -913,7 +916,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
             {   // group g sits in b*; fetch g+1 into a*
                 const uint32_t base = lo + g * kGroupPx;
                 const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-                if (spos > kStageSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+                if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, ax, av);
                 else { ax[0] = load_px<CH>(pix, base + kGroupPx); av[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
                 process_group<PROBE, false, CLS>(L, C, M, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
@@ -926,7 +929,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     for (; g < ngroups; ++g) {
         const uint32_t base = lo + g * kGroupPx;
         const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-        if (spos > kStageSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+        if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
         uint32_t nxp, nxv;
 #pragma unroll
         for (int t = 0; t < kGroupSteps; ++t) load_pair_guarded<CH>(pix, base + t * 64u + lane, n, ax[t], av[t]);
@@ -1013,7 +1016,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 // sets in flight spread over all images.
 template <int CH, int PROBE, int ENTRY, int CLS>
 __global__ __launch_bounds__(256, PROBE == 1 ? (CLS == 2 ? QOIMI_ENC_WAVES_PER_SIMD - 1 : QOIMI_ENC_WAVES_PER_SIMD) : 4) void enc_sets(EncParams p) {
-    __shared__ EncLds<PROBE> s_lds[4];
+    __shared__ EncLdsFor<PROBE, CLS> s_lds[4];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
 #pragma unroll 1
