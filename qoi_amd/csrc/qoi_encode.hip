@@ -429,82 +429,93 @@ __device__ __forceinline__ uint32_t literal_word(const PairClass& K, uint32_t px
     return we;
 }
 
-// ---- the literal classes of one step from the MATRIX pipe (CLS 1) ----------------------------------------------------------
+// ---- the literal classes of one step from the MATRIX pipe (CLS 1, 2) -------------------------------------------------------
 // Every quantity the classification of qoi.h:438-474 needs is an integer-linear form of the eight bytes (previous pixel, pixel)
 // a lane holds, taken modulo 256: the wrapped channel deltas plus their range-test bias, the 4 x QOI_COLOR_HASH slot offset
 // (qoi.h:322), and - where the range tests hold - the QOI_OP_DIFF byte 0x40 | (vr+2) << 4 | (vg+2) << 2 | (vb+2) =
 // 16 vr + 4 vg + vb + 106 and the QOI_OP_LUMA bytes 0x80 | (vg+32) = vg + 160 and (vg_r+8) << 4 | (vg_b+8) = 16 vr - 17 vg + vb + 136.
 // The kernel is bound by its VECTOR instruction count while the matrix pipe of the SIMD idles, so these byte dot products go
-// there: v_mfma_i32_16x16x32_i8 takes eight bytes per lane as its B operand - exactly the (previous pixel, pixel) register pair
-// of the step - and hands every lane four rows of a 16 x 32 coefficient matrix times those bytes.  Output lane l holds rows
-// 4 (l / 16) + r of column l % 16, and the K range of lane group l / 16 is that group's own eight bytes: with the coefficient
-// matrix block-diagonal (row 4 g + r non-zero only in the K range of group g) a lane's four results are four linear forms of ITS
-// OWN eight bytes.  Three such instructions per step (12 forms, 10 used) replace the byte subtractions, the sign-extending
-// adds, the packed multiply-adds and the v_dot4 of the vector-pipe form: 10 vector instructions per step for "deltas, tests,
-// words, hash" instead of 21.  No contraction across pixels takes place - the matrix pipe is used as a 12-way byte dot-product
-// unit with constant coefficients.  The bytes are read as SIGNED by the instruction: every form is only used modulo 256 (its
-// low byte, or bits 2..7 of it), where signed and unsigned readings agree (256 c = 0 mod 256).
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-struct MatConst {
-    long a1, a2, a3;   // this lane's piece of the three coefficient matrices (A operands)
-    v4i32 c3;          // the biases of the third one (C operand); the first two take an inline constant
-};
+// there: v_mfma_i32_32x32x16_i8 takes eight bytes per lane as its B operand - exactly the (previous pixel, pixel) register pair
+// of the step - and hands every lane sixteen rows of a 32 x 16 coefficient matrix times those bytes.  Output lane l holds rows
+// 8 q + 4 (l / 32) + r (q, r = 0..3) of column l % 32, and the K range of lane half l / 32 is that half's own eight bytes: with
+// the coefficient matrix block-diagonal (row i non-zero only in the K range of half (i / 4) % 2) a lane's sixteen results are
+// sixteen linear forms of ITS OWN eight bytes (ten are used).  No contraction across pixels takes place - the matrix pipe serves
+// as a byte dot-product unit with constant coefficients.  The instruction reads the bytes as SIGNED: every form is only used modulo
+// 256 (its low byte, or bits 2..7 of it), where signed and unsigned readings agree (256 c = 0 mod 256).  The constant terms of
+// the forms ride on the alpha byte of the previous pixel, which no form needs: it is overwritten with 0xFF (= -1) before the pair
+// goes to the matrix pipe (the alpha comparison of qoi.h:468 is made first).
+// What a matrix instruction costs a vector-bound wavefront was measured first (tools/ubench/mfma_mix.hip):
+// ONE such instruction per step whose results are read 16+ vector instructions later costs ~1.3 issue slots; three shorter ones
+// back to back with their results read eight instructions later - the first form of this experiment - cost 9-14 (a matrix
+// instruction that finds the pipe busy, or a read that finds its result not ready, holds the SIMD's vector issue port).  So the
+// step asks for the NEXT step's forms when it has consumed its own (software pipeline of depth one, a single set of result
+// registers), and 10 vector instructions per step remain of "deltas, tests, words, hash" (21 in the vector-pipe form).
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+struct MatConst { long a; };   // this lane's piece of the coefficient matrix (A operand)
 struct StepClass {
-    uint32_t xr, xg, xb, h4;      // vr + 2, vg + 2, vb + 2 (QOI_OP_DIFF iff all three < 4 mod 256, qoi.h:446-453); 4 * hash + 2
-    uint32_t ur, ub, sp0, sp1;    // vg_r + 8, vg_b + 8                      (qoi.h:455-459); the two rows of that matrix that carry nothing
-    uint32_t b0, b1, wd, ug;      // LUMA byte 0, LUMA byte 1, DIFF byte, vg + 32
+    v16i32 d;                  // rows 0..3: vr + 2, vg + 2, vb + 2 (QOI_OP_DIFF iff all three < 4 mod 256, qoi.h:446-453), 4 * hash;
+                               // 4, 5: vg_r + 8, vg_b + 8 (qoi.h:455-459); 8..11: LUMA byte 0, LUMA byte 1, DIFF byte, vg + 32
+    u64 alpha_moved;           // lanes whose alpha differs from the previous pixel's (qoi.h:468), taken before the alpha byte is overwritten
 };
 __device__ __forceinline__ uint32_t coef4(int c0, int c1, int c2, int c3) {
     return (uint32_t)(c0 & 0xFF) | ((uint32_t)(c1 & 0xFF) << 8) | ((uint32_t)(c2 & 0xFF) << 16) | ((uint32_t)(c3 & 0xFF) << 24);
 }
-// row r of a coefficient matrix over (previous pixel r g b a, pixel r g b a): difference forms have opposite signs on the two
-__device__ __forceinline__ long coef_row(uint32_t on_prev, uint32_t on_px) { return (long)(((u64)on_px << 32) | (u64)on_prev); }
-__device__ __forceinline__ void mat_const_init(MatConst& M, uint32_t lane) {
-    // A operand of lane l: row l % 16 of the matrix, K range l / 16.  Non-zero only where row / 4 == l / 16 (block diagonal).
-    const uint32_t row = lane & 15u, grp = lane >> 4;
-    const bool on = (row >> 2) == grp;
-    const uint32_t r = row & 3u;
-    const uint32_t dr = coef4(1, 0, 0, 0), dg = coef4(0, 1, 0, 0), db = coef4(0, 0, 1, 0);
-    const uint32_t ndr = coef4(-1, 0, 0, 0), ndg = coef4(0, -1, 0, 0), ndb = coef4(0, 0, -1, 0);
-    // matrix 1 (+2): vr + 2, vg + 2, vb + 2, 12 r + 20 g + 28 b + 44 a + 2
-    const long m1 = r == 0u ? coef_row(ndr, dr) : r == 1u ? coef_row(ndg, dg) : r == 2u ? coef_row(ndb, db) : coef_row(0u, coef4(12, 20, 28, 44));
-    // matrix 2 (+8): vr - vg + 8, vb - vg + 8, -, -
-    const long m2 = r == 0u ? coef_row(coef4(-1, 1, 0, 0), coef4(1, -1, 0, 0)) : r == 1u ? coef_row(coef4(0, 1, -1, 0), coef4(0, -1, 1, 0)) : 0l;
-    // matrix 3: vg + 160, 16 vr - 17 vg + vb + 136, 16 vr + 4 vg + vb + 106, vg + 32
-    const long m3 = r == 0u ? coef_row(ndg, dg) : r == 1u ? coef_row(coef4(-16, 17, -1, 0), coef4(16, -17, 1, 0))
-                  : r == 2u ? coef_row(coef4(-16, -4, -1, 0), coef4(16, 4, 1, 0)) : coef_row(ndg, dg);
-    M.a1 = on ? m1 : 0l; M.a2 = on ? m2 : 0l; M.a3 = on ? m3 : 0l;
-    M.c3 = (v4i32){160, 136, 106, 32};
-    asm volatile("" : "+v"(M.a1), "+v"(M.a2), "+v"(M.a3), "+v"(M.c3));     // materialised once, not re-derived per step
+// a row over (previous pixel r g b, the constant -1, pixel r g b a) with constant term `bias`
+__device__ __forceinline__ long coef_row(int pr, int pg, int pb, int bias, int r, int g, int b, int a) {
+    return (long)(((u64)coef4(r, g, b, a) << 32) | (u64)coef4(pr, pg, pb, -bias));
 }
+__device__ __forceinline__ void mat_const_init(MatConst& M, uint32_t lane) {
+    // A operand of lane l: row l % 32 of the matrix, K range l / 32.  Non-zero only where (row / 4) % 2 == l / 32 (block diagonal);
+    // such a row is form number 4 (row / 8) + row % 4 of the lanes that read it.
+    const uint32_t row = lane & 31u, half = lane >> 5;
+    const bool on = ((row >> 2) & 1u) == half;
+    const uint32_t f = 4u * (row >> 3) + (row & 3u);
+    long c = 0l;
+    switch (f) {
+    case 0:  c = coef_row(-1, 0, 0, 2, 1, 0, 0, 0); break;            // vr + 2
+    case 1:  c = coef_row(0, -1, 0, 2, 0, 1, 0, 0); break;            // vg + 2
+    case 2:  c = coef_row(0, 0, -1, 2, 0, 0, 1, 0); break;            // vb + 2
+    case 3:  c = coef_row(0, 0, 0, 0, 12, 20, 28, 44); break;         // 4 * (3 r + 5 g + 7 b + 11 a)
+    case 4:  c = coef_row(-1, 1, 0, 8, 1, -1, 0, 0); break;           // vr - vg + 8
+    case 5:  c = coef_row(0, 1, -1, 8, 0, -1, 1, 0); break;           // vb - vg + 8
+    case 8:  c = coef_row(0, -1, 0, 160 - 256, 0, 1, 0, 0); break;    // vg + 160                (mod 256)
+    case 9:  c = coef_row(-16, 17, -1, 136 - 256, 16, -17, 1, 0); break;   // 16 vr - 17 vg + vb + 136   (mod 256)
+    case 10: c = coef_row(-16, -4, -1, 106, 16, 4, 1, 0); break;      // 16 vr + 4 vg + vb + 106
+    case 11: c = coef_row(0, -1, 0, 32, 0, 1, 0, 0); break;           // vg + 32
+    default: break;
+    }
+    M.a = on ? c : 0l;
+    asm volatile("" : "+v"(M.a));     // materialised once, not re-derived per step
+}
+// Asks the matrix pipe for the forms of (prev, px).
 __device__ __forceinline__ void mat_classify(StepClass& S, const MatConst& M, uint32_t px, uint32_t prev) {
-    const long b = (long)(((u64)px << 32) | (u64)prev);       // the register pair as loaded
-    const v4i32 d1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(M.a1, b, (v4i32){2, 2, 2, 2}, 0, 0, 0);
-    const v4i32 d3 = __builtin_amdgcn_mfma_i32_16x16x32_i8(M.a3, b, M.c3, 0, 0, 0);
-    const v4i32 d2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(M.a2, b, (v4i32){8, 8, 8, 8}, 0, 0, 0);
-    S.xr = (uint32_t)d1[0]; S.xg = (uint32_t)d1[1]; S.xb = (uint32_t)d1[2]; S.h4 = (uint32_t)d1[3];
-    S.ur = (uint32_t)d2[0]; S.ub = (uint32_t)d2[1]; S.sp0 = (uint32_t)d2[2]; S.sp1 = (uint32_t)d2[3];
-    S.b0 = (uint32_t)d3[0]; S.b1 = (uint32_t)d3[1]; S.wd = (uint32_t)d3[2]; S.ug = (uint32_t)d3[3];
+    asm("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3" : "=s"(S.alpha_moved) : "v"(px), "v"(prev));
+    uint32_t pm;
+    asm("v_perm_b32 %0, %1, %1, %2" : "=v"(pm) : "v"(prev), "s"(0x0D020100u));     // r, g, b as they are, 0xFF on top
+    const long b = (long)(((u64)px << 32) | (u64)pm);                     // the register pair as loaded
+    S.d = __builtin_amdgcn_mfma_i32_32x32x16_i8(M.a, b, (v16i32)(0), 0, 0, 0);
 }
 // The literal chunk word from those forms (the same word literal_word<HALF> makes from the packed halves): the tests read the
 // low bytes through SDWA selects.
-__device__ __forceinline__ uint32_t range_word_diff(const StepClass& S) { return S.xr | S.xg | S.xb; }                                  // DIFF iff low byte < 4
-__device__ __forceinline__ uint32_t range_word_luma(const StepClass& S) { return __builtin_amdgcn_ubfe(S.ug, 2u, 6u) | S.ur | S.ub; }   // LUMA iff low byte < 16 (vg + 32 < 64, the others < 16)
-__device__ __forceinline__ uint32_t literal_word_mat(const StepClass& S, uint32_t od, uint32_t ol, uint32_t px, uint32_t prev, u64& m_ad) {
+__device__ __forceinline__ uint32_t range_word_diff(const StepClass& S) { return (uint32_t)S.d[0] | (uint32_t)S.d[1] | (uint32_t)S.d[2]; }     // DIFF iff low byte < 4
+__device__ __forceinline__ uint32_t range_word_luma(const StepClass& S) {                                                                      // LUMA iff low byte < 16
+    return __builtin_amdgcn_ubfe((uint32_t)S.d[11], 2u, 6u) | (uint32_t)S.d[4] | (uint32_t)S.d[5];                                             // (vg + 32 < 64, the others < 16)
+}
+__device__ __forceinline__ uint32_t literal_word_mat(const StepClass& S, uint32_t od, uint32_t ol) {
     uint32_t we;
     u64 s_luma;
-    asm("v_cmp_gt_u32_sdwa %1, %3, %5 src0_sel:DWORD src1_sel:BYTE_0\n\t"
-        "v_cmp_gt_u32_sdwa vcc, %4, %6 src0_sel:DWORD src1_sel:BYTE_0\n\t"
-        "v_perm_b32 %0, %8, %7, %9\n\t"
-        "v_cmp_ne_u32_sdwa %2, %10, %11 src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"
+    asm("v_cmp_gt_u32_sdwa %1, %2, %4 src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_cmp_gt_u32_sdwa vcc, %3, %5 src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_perm_b32 %0, %7, %6, %8\n\t"
+        "s_nop 0\n\t"
         "v_cndmask_b32 %0, 2.0, %0, %1\n\t"
-        "v_cndmask_b32_sdwa %0, %0, %12, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-        "v_cndmask_b32 %0, %0, 2.0, %2"
-        : "=&v"(we), "=&s"(s_luma), "=&s"(m_ad)
-        : "s"(16u), "s"(4u), "v"(ol), "v"(od), "v"(S.b0), "v"(S.b1), "s"(0x0D040C00u), "v"(px), "v"(prev), "v"(S.wd),
-          // (the idle rows of the second matrix stay allocated up to here: handed out as temporaries right behind the instruction
+        "v_cndmask_b32_sdwa %0, %0, %9, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_cndmask_b32 %0, %0, 2.0, %10"
+        : "=&v"(we), "=&s"(s_luma)
+        : "s"(16u), "s"(4u), "v"(ol), "v"(od), "v"((uint32_t)S.d[8]), "v"((uint32_t)S.d[9]), "s"(0x0D040C00u), "v"((uint32_t)S.d[10]), "s"(S.alpha_moved),
+          // (the six rows that carry nothing stay allocated up to here: handed out as temporaries right behind the instruction
           // that writes them, they make the wavefront wait for it at once)
-          "v"(S.sp0), "v"(S.sp1) : "vcc");
+          "v"(S.d[6]), "v"(S.d[7]), "v"(S.d[12]), "v"(S.d[13]), "v"(S.d[14]), "v"(S.d[15]) : "vcc");
     return we;
 }
 
@@ -520,11 +531,13 @@ struct LaneConst {
 // pixel after lane 63 is an edge.  GEN only: V valid lanes, lastbit the lane of the image's last pixel.
 // ccp (scalar) = 63 + (first pixel of the step - last edge before the step): stands in for clz(edges below the lane).
 // vbase (same value in every lane): LDS address of the next staged byte.
-// CLS 0: the literal classes come from classify_pair (K, vector pipe); CLS 1, 2: from mat_classify (S, matrix pipe; 2 is the same
-// code compiled for five wavefronts per SIMD instead of six - 96 registers, no spill around the pipelined loop).
+// CLS 0: the literal classes come from classify_pair (K, vector pipe); CLS 1, 2: from the matrix pipe (S holds this step's forms
+// on entry; once they are consumed the step asks for the forms of the NEXT step - next_px / next_pv, edges next_E - into the same
+// registers; 2 is the same code compiled for five wavefronts per SIMD instead of six with a larger staging buffer).
 template <int PROBE, bool GEN, int HALF, int CLS, class LDS>
-__device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, uint32_t lane, uint32_t px, uint32_t prev, const PairClass& K,
-                                            const StepClass& S, u64 Ec, u64 nb63, u64 V, u64 lastbit, uint32_t& ccp, uint32_t& vbase) {
+__device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const MatConst& M, uint32_t lane, uint32_t px, uint32_t prev, const PairClass& K,
+                                            StepClass& S, bool has_next, u64 next_E, uint32_t next_px, uint32_t next_pv,
+                                            u64 Ec, u64 nb63, u64 V, u64 lastbit, uint32_t& ccp, uint32_t& vbase) {
     const u64 En = (Ec >> 1) | nb63 | lastbit;             // lanes whose successor is an edge (or that end the image)
     const u64 NE = GEN ? (~Ec & V) : ~Ec;                  // repeat pixels
     u64 RB = NE & En;                                      // repeat pixels that close a run: they carry its run byte
@@ -551,8 +564,8 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, uint32_t
     if (Ec) {
         ccp = clz64_plus64(Ec);
         // ---- colour-table probe/update (qoi.h:430-436) for edge pixels ---------------------
-        // 4 * QOI_COLOR_HASH (qoi.h:322); CLS 1: the same modulo 256 with 2 on top (only bits 2..7 are looked at)
-        const uint32_t hsh = CLS != 0 ? S.h4 : __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);
+        // 4 * QOI_COLOR_HASH (qoi.h:322); CLS 1: the same modulo 256 (only bits 2..7 are looked at)
+        const uint32_t hsh = CLS != 0 ? (uint32_t)S.d[3] : __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);
         uint32_t seen = ~px;
         uint32_t od = 0u, ol = 0u;
         if (CLS != 0) { od = range_word_diff(S); ol = range_word_luma(S); }
@@ -577,7 +590,7 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, uint32_t
         // ---- chunk of an edge pixel (qoi.h:432-474): INDEX, else RGBA if alpha moved, else DIFF, LUMA, RGB ----
         u64 m_ad;                                          // lanes whose alpha differs from the previous pixel's
         uint32_t we;
-        if (CLS != 0) we = literal_word_mat(S, od, ol, px, prev, m_ad);
+        if (CLS != 0) { we = literal_word_mat(S, od, ol); m_ad = S.alpha_moved; }
         else we = literal_word<HALF>(K, px, prev, m_ad);
         // QOI_OP_INDEX (qoi.h:432-434) where the slot held the pixel; the edge lanes take their chunk word, the others keep
         // their run byte (one v_cndmask under exec = edges instead of two)
@@ -597,6 +610,9 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, uint32_t
             any = 0ull;                                            // nothing left for the tail below
         }
     }
+    // (this step's forms are consumed: the matrix pipe works on the next step's while the offsets below and the run lengths of
+    // the next step are worked out)
+    if (CLS != 0 && has_next && next_E != 0ull) mat_classify(S, M, next_px, next_pv);
     // ---- common case: chunk lengths 1 and 2 only.  offset = #chunks below + #LUMA chunks below ----
     {
         const u64 two = __ballot(word_is_two(w)) & any;
@@ -619,6 +635,10 @@ __device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, const 
                                               uint32_t nx_px, uint32_t nx_pv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase) {
     if (GEN) E &= lanes_upto(rem);                         // (the group before this one does not know where the image ends)
     PairClass K = {0u, 0u, 0u, 0u, 0u};
+    // CLS 1, 2: the forms of the step at hand (only looked at under the condition they were asked for under: no value for the
+    // other case).  The group's first step asks for its own, every step then for the next one's.
+    StepClass S;
+    if (CLS != 0 && E != 0ull) mat_classify(S, M, px[0], pv[0]);
 #pragma unroll
     for (int t = 0; t < kGroupSteps; ++t) {
         const u64 Ec = E;
@@ -634,13 +654,12 @@ __device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, const 
         if (GEN) E &= lanes_upto(rem - (t + 1) * 64);
         const u64 nb63 = E << 63;
         if (CLS == 0 && (t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);   // this step and the next one
-        // CLS 1: this step's forms are asked of the matrix pipe here, ahead of the run-length work of the step (their first
-        // use, the slot address of the probe, comes after it)
-        StepClass S;                                           // (only looked at under the same condition: no merge with a value for the other case)
-        if (CLS != 0 && Ec != 0ull) mat_classify(S, M, px[t], pv[t]);
         if (GEN && V == 0ull) continue;
-        if (t & 1) encode_step<PROBE, GEN, 1, CLS>(L, C, lane, px[t], pv[t], K, S, Ec, nb63, V, lastbit, ccp, vbase);
-        else encode_step<PROBE, GEN, 0, CLS>(L, C, lane, px[t], pv[t], K, S, Ec, nb63, V, lastbit, ccp, vbase);
+        constexpr int kLast = kGroupSteps - 1;
+        const bool has_next = t < kLast;
+        const int tn = t < kLast ? t + 1 : t;                  // (the last step asks for nothing: the next group's first step does that itself)
+        if (t & 1) encode_step<PROBE, GEN, 1, CLS>(L, C, M, lane, px[t], pv[t], K, S, has_next, E, px[tn], pv[tn], Ec, nb63, V, lastbit, ccp, vbase);
+        else encode_step<PROBE, GEN, 0, CLS>(L, C, M, lane, px[t], pv[t], K, S, has_next, E, px[tn], pv[tn], Ec, nb63, V, lastbit, ccp, vbase);
     }
 }
 
@@ -863,7 +882,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     C.lane_run = lane + 128u;
     C.tbase = lds_addr(L.table);                               // 256-byte aligned
     asm volatile("" : "+v"(C.tbase));                          // keep in a VGPR
-    MatConst M = {0l, 0l, 0l, (v4i32){0, 0, 0, 0}};
+    MatConst M = {0l};
     if (CLS != 0) mat_const_init(M, lane);
     int last_edge;
     if (ENTRY == 1) {

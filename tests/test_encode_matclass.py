@@ -1,5 +1,5 @@
-"""Host rehearsal of the encoder's matrix-pipe classes (enc_sets CLS 1): the twelve linear forms three
-v_mfma_i32_16x16x32_i8 hand every lane, evaluated as the ISA defines the instruction, give the chunk words of qoi.h:438-474."""
+"""Host rehearsal of the encoder's matrix-pipe classes (enc_sets CLS 1, 2): the linear forms one v_mfma_i32_32x32x16_i8 hands
+every lane, evaluated as the ISA defines the instruction, give the chunk words of qoi.h:438-474."""
 import numpy as np
 
 from tools import matclass_model as MM
