@@ -543,8 +543,7 @@ def main() -> None:
             "decode_mpps_kernels": round(F * npx * launches / (dec_ms * 1e3), 1) if dec_ms else None,
             "decode_rounds": dstats["rounds"], "decode_redo_segments": dstats["redo_segments"], "decode_sync_fallback_segments": dstats.get("sync_fallback_segments"),
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
-            "encoder_classes": {"0": "vector pipe (paired 16-bit halves)", "1": "matrix pipe (3 x v_mfma_i32_16x16x32_i8 per step)",
-                                "2": "matrix pipe, five wavefronts per SIMD"}.get(os.environ.get("QOIMI_ENC_CLS", "0"), "vector pipe (paired 16-bit halves)"),
+            "encoder_classes": "matrix pipe (one v_mfma_i32_32x32x16_i8 per step; experimental)" if os.environ.get("QOIMI_ENC_CLS") == "1" else "vector pipe (paired 16-bit halves)",
             "roofline": roof("enc_sets (+ entry-state passes)", alg_bytes, per_launch_ms, traffic=traffic, traffic_source=traffic_src,
                              note="the kernel of the north star's 4K-encode roofline target; the kernel with the largest share of the step is in roofline_dominant"),
         }

@@ -217,7 +217,7 @@ constexpr uint32_t kGroupPx = 64u * kGroupSteps;
 #define QOIMI_ENC_WAVES_PER_SIMD 6
 #endif
 constexpr uint32_t kStageBytes = QOIMI_ENC_STAGE_BYTES; // staging buffer of a wavefront (6 workgroups of 4 per CU: 4 x 6656 x 6 = 156 KB of LDS)
-constexpr uint32_t kStageBytesBig = 7616;              // ... of the five-wavefront form (CLS 2): 5 x 4 x 7936 = 155 KB
+constexpr uint32_t kStageBytesBig = 7616;              // ... of the matrix-pipe form (CLS 1, five wavefronts per SIMD): 5 x 4 x 7936 = 155 KB
 
 template <int PROBE, uint32_t STAGE>
 struct EncLds {
@@ -228,7 +228,7 @@ struct EncLds {
     u64 mask[PROBE == 0 ? 64 : 1];     // PROBE 0 only
 };
 
-template <int PROBE, int CLS> using EncLdsFor = EncLds<PROBE, CLS == 2 ? kStageBytesBig : kStageBytes>;
+template <int PROBE, int CLS> using EncLdsFor = EncLds<PROBE, CLS == 1 ? kStageBytesBig : kStageBytes>;
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -429,7 +429,7 @@ __device__ __forceinline__ uint32_t literal_word(const PairClass& K, uint32_t px
     return we;
 }
 
-// ---- the literal classes of one step from the MATRIX pipe (CLS 1, 2) -------------------------------------------------------
+// ---- the literal classes of one step from the MATRIX pipe (CLS 1; selectable, NOT the default: measured no faster) ----------
 // Every quantity the classification of qoi.h:438-474 needs is an integer-linear form of the eight bytes (previous pixel, pixel)
 // a lane holds, taken modulo 256: the wrapped channel deltas plus their range-test bias, the 4 x QOI_COLOR_HASH slot offset
 // (qoi.h:322), and - where the range tests hold - the QOI_OP_DIFF byte 0x40 | (vr+2) << 4 | (vg+2) << 2 | (vb+2) =
@@ -449,7 +449,10 @@ __device__ __forceinline__ uint32_t literal_word(const PairClass& K, uint32_t px
 // back to back with their results read eight instructions later - the first form of this experiment - cost 9-14 (a matrix
 // instruction that finds the pipe busy, or a read that finds its result not ready, holds the SIMD's vector issue port).  So the
 // step asks for the NEXT step's forms when it has consumed its own (software pipeline of depth one, a single set of result
-// registers), and 10 vector instructions per step remain of "deltas, tests, words, hash" (21 in the vector-pipe form).
+// registers), and 10 vector instructions per step remain of "deltas, tests, words, hash" (21 in the vector-pipe form): 40.1
+// vector instructions per 64 pixels instead of 49.4 (SQ counters, profiles/r03_s7_sq_counters_encode_cls.txt).  The kernel is
+// no faster for it (1024 4K photographs: 12.80 ms against 12.48): with fewer vector instructions the wavefronts spend a larger
+// share of their time in s_waitcnt, and five wavefronts per SIMD (16 result registers) hide less of it than six.
 typedef int v16i32 __attribute__((ext_vector_type(16)));
 struct MatConst { long a; };   // this lane's piece of the coefficient matrix (A operand)
 struct StepClass {
@@ -490,10 +493,16 @@ __device__ __forceinline__ void mat_const_init(MatConst& M, uint32_t lane) {
 // Asks the matrix pipe for the forms of (prev, px).
 __device__ __forceinline__ void mat_classify(StepClass& S, const MatConst& M, uint32_t px, uint32_t prev) {
     asm("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3" : "=s"(S.alpha_moved) : "v"(px), "v"(prev));
-    uint32_t pm;
-    asm("v_perm_b32 %0, %1, %1, %2" : "=v"(pm) : "v"(prev), "s"(0x0D020100u));     // r, g, b as they are, 0xFF on top
+    // r, g, b as they are, 0xFF on top.  (Through the builtin, not inline assembly: the compiler has to see which instruction
+    // writes the register the matrix instruction reads - it keeps the distance the hardware asks for between the two; an
+    // assembly block in front of it made the matrix pipe read the register as it was BEFORE the write.)
+    const uint32_t pm = __builtin_amdgcn_perm(prev, prev, 0x0D020100u);
     const long b = (long)(((u64)px << 32) | (u64)pm);                     // the register pair as loaded
+#ifdef QOIMI_EXP_NOMFMA   // timing experiment only (wrong bytes): the step without its matrix instruction
+    S.d = (v16i32)((int)(px ^ pm ^ (uint32_t)M.a));
+#else
     S.d = __builtin_amdgcn_mfma_i32_32x32x16_i8(M.a, b, (v16i32)(0), 0, 0, 0);
+#endif
 }
 // The literal chunk word from those forms (the same word literal_word<HALF> makes from the packed halves): the tests read the
 // low bytes through SDWA selects.
@@ -531,14 +540,14 @@ struct LaneConst {
 // pixel after lane 63 is an edge.  GEN only: V valid lanes, lastbit the lane of the image's last pixel.
 // ccp (scalar) = 63 + (first pixel of the step - last edge before the step): stands in for clz(edges below the lane).
 // vbase (same value in every lane): LDS address of the next staged byte.
-// CLS 0: the literal classes come from classify_pair (K, vector pipe); CLS 1, 2: from the matrix pipe (S holds this step's forms
+// CLS 0: the literal classes come from classify_pair (K, vector pipe); CLS 1: from the matrix pipe (S holds this step's forms
 // on entry; once they are consumed the step asks for the forms of the NEXT step - next_px / next_pv, edges next_E - into the same
-// registers; 2 is the same code compiled for five wavefronts per SIMD instead of six with a larger staging buffer).
+// registers; compiled for five wavefronts per SIMD instead of six, with a larger staging buffer).
 template <int PROBE, bool GEN, int HALF, int CLS, class LDS>
 __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const MatConst& M, uint32_t lane, uint32_t px, uint32_t prev, const PairClass& K,
                                             StepClass& S, bool has_next, u64 next_E, uint32_t next_px, uint32_t next_pv,
                                             u64 Ec, u64 nb63, u64 V, u64 lastbit, uint32_t& ccp, uint32_t& vbase) {
-    const u64 En = (Ec >> 1) | nb63 | lastbit;             // lanes whose successor is an edge (or that end the image)
+        const u64 En = (Ec >> 1) | nb63 | lastbit;             // lanes whose successor is an edge (or that end the image)
     const u64 NE = GEN ? (~Ec & V) : ~Ec;                  // repeat pixels
     u64 RB = NE & En;                                      // repeat pixels that close a run: they carry its run byte
 
@@ -635,7 +644,7 @@ __device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, const 
                                               uint32_t nx_px, uint32_t nx_pv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase) {
     if (GEN) E &= lanes_upto(rem);                         // (the group before this one does not know where the image ends)
     PairClass K = {0u, 0u, 0u, 0u, 0u};
-    // CLS 1, 2: the forms of the step at hand (only looked at under the condition they were asked for under: no value for the
+    // CLS 1: the forms of the step at hand (only looked at under the condition they were asked for under: no value for the
     // other case).  The group's first step asks for its own, every step then for the next one's.
     StepClass S;
     if (CLS != 0 && E != 0ull) mat_classify(S, M, px[0], pv[0]);
@@ -689,6 +698,39 @@ __device__ __forceinline__ void load_group(const uint8_t* __restrict__ pix, uint
 #pragma unroll
     for (int t = 0; t < kGroupSteps; ++t) load_pair_at<CH>(q, t * 64, px[t], pv[t]);
 }
+// ---- the same with a ROLLING register ring (CLS 1) ---------------------------------------------------------------------
+// The two-group form above keeps 32 registers of pixels: the group at hand and the whole next one, asked for when the group
+// begins.  The matrix-pipe form needs 16 registers for its results; with the two-group ring the compiler paid for them with
+// scratch spills around the loop whose reloads - each one a wait for EVERY load in flight, ~500 quad-cycles of s_waitcnt per
+// reload - cost far more than the matrix pipe saves.  Here a step's two registers are refilled with the
+// same step of the NEXT group as soon as the step is through: every load is still asked for eight steps ahead of its use, in
+// 16 registers instead of 32, and the last step of a group can ask the matrix pipe for the next group's first step like any
+// other.  (The vector-pipe form gains nothing from the ring: 71 registers instead of 78, 6.45 against 6.38 ms per 512 frames,
+// and a seventh wavefront per SIMD with the registers it frees - 5.3 KB of staging, two slabs per set - 6.68.)
+// q: this lane's pixel of the group's first step.  MORE: another interior group follows (its pixels are asked for here); else
+// end_px / end_pv are the two pixels around the end of the group (only "is the next pixel an edge" is taken from them).
+template <int CH, int PROBE, int CLS, bool MORE, class LDS>
+__device__ __forceinline__ void process_group_roll(LDS& L, const LaneConst& C, const MatConst& M, uint32_t lane,
+                                                   uint32_t (&px)[kGroupSteps], uint32_t (&pv)[kGroupSteps], const uint8_t* __restrict__ q,
+                                                   uint32_t end_px, uint32_t end_pv, StepClass& S, u64& E, uint32_t& ccp, uint32_t& vbase) {
+    PairClass K = {0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < kGroupSteps; ++t) {
+        const u64 Ec = E;
+        // edges of the next step (its lane 0 tells lane 63 whether its run ends here); px[0] / pv[0] already hold the next group's
+        if (t + 1 < kGroupSteps) E = __ballot(px[t + 1] != pv[t + 1]);
+        else E = MORE ? __ballot(px[0] != pv[0]) : __ballot(end_px != end_pv);
+        const u64 nb63 = E << 63;
+        if (CLS == 0 && (t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);
+        const bool has_next = MORE || t + 1 < kGroupSteps;
+        constexpr int kMask = kGroupSteps - 1;
+        const int tn = (t + 1) & kMask;
+        if (t & 1) encode_step<PROBE, false, 1, CLS>(L, C, M, lane, px[t], pv[t], K, S, has_next, E, px[tn], pv[tn], Ec, nb63, ~0ull, 0ull, ccp, vbase);
+        else encode_step<PROBE, false, 0, CLS>(L, C, M, lane, px[t], pv[t], K, S, has_next, E, px[tn], pv[tn], Ec, nb63, ~0ull, 0ull, ccp, vbase);
+        if (MORE) load_pair_at<CH>(q, (kGroupSteps + t) * 64, px[t], pv[t]);      // this step's registers: the same step of the next group
+    }
+}
+
 // pixel i and the one before it, any i: lanes beyond the image's last pixel get 0, the pixel before the image's first one is
 // the start value of qoi.h:396-399
 template <int CH>
@@ -916,7 +958,28 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     };
 
     uint32_t g = 0;
-    if (nint) {
+    if (CLS != 0 && nint) {
+        // ---- rolling ring (process_group_roll): a* holds the eight steps at hand, each refilled for the next group as it is used up ----
+        u64 E = __ballot(ax[0] != av[0]);
+        StepClass S;
+        if (E != 0ull) mat_classify(S, M, ax[0], av[0]);       // the set's first step; every step then asks for the one after it
+#pragma unroll 1
+        for (; g + 1u < nint; ++g) {
+            const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
+            if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+            process_group_roll<CH, PROBE, CLS, true>(L, C, M, lane, ax, av, pix + (size_t)(lo + g * kGroupPx + lane) * (size_t)CH, 0u, 0u, S, E, ccp, vbase);
+        }
+        {   // the last group inside the image: nothing to refill, the two pixels around its end stand in for the next step
+            const uint32_t base = lo + g * kGroupPx;
+            const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
+            if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+            const uint32_t ex = load_px<CH>(pix, base + kGroupPx), ev = load_px<CH>(pix, base + kGroupPx - 1u);
+            if (!last_set) ask_early();
+            process_group_roll<CH, PROBE, CLS, false>(L, C, M, lane, ax, av, pix, ex, ev, S, E, ccp, vbase);
+            ++g;
+        }
+    }
+    if (CLS == 0 && nint) {
         u64 E = __ballot(ax[0] != av[0]);
         // ---- two groups per turn: while one is encoded the loads of the next are in flight ----------------------------
         // (the pair loaded when no group follows inside the loop: the two pixels around the end of the set, or around the
@@ -1034,7 +1097,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 // flagged.  A workgroup serves unit u = (image u % n_images, four consecutive sets u / n_images) so that the
 // sets in flight spread over all images.
 template <int CH, int PROBE, int ENTRY, int CLS>
-__global__ __launch_bounds__(256, PROBE == 1 ? (CLS == 2 ? QOIMI_ENC_WAVES_PER_SIMD - 1 : QOIMI_ENC_WAVES_PER_SIMD) : 4) void enc_sets(EncParams p) {
+__global__ __launch_bounds__(256, PROBE == 1 ? (CLS == 1 ? QOIMI_ENC_WAVES_PER_SIMD - 1 : QOIMI_ENC_WAVES_PER_SIMD) : 4) void enc_sets(EncParams p) {
     __shared__ EncLdsFor<PROBE, CLS> s_lds[4];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
@@ -1243,14 +1306,12 @@ void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phas
     // (the matrix-pipe classes exist for the exchange probe only: the order-independent probe is the fall-back path)
     if (p.channels == 3) {
         if (!p.probe_xchg) launch_encode_t<3, 0, 0>(p, st, tm, phases);
-        else if (p.cls_mat == 2) launch_encode_t<3, 1, 2>(p, st, tm, phases);
         else if (p.cls_mat) launch_encode_t<3, 1, 1>(p, st, tm, phases);
         else launch_encode_t<3, 1, 0>(p, st, tm, phases);
         return;
     }
     if (!p.probe_xchg) { launch_encode_t<4, 0, 0>(p, st, tm, phases); return; }
-    if (p.cls_mat == 2) launch_encode_t<4, 1, 2>(p, st, tm, phases);
-    else if (p.cls_mat) launch_encode_t<4, 1, 1>(p, st, tm, phases);
+    if (p.cls_mat) launch_encode_t<4, 1, 1>(p, st, tm, phases);
     else launch_encode_t<4, 1, 0>(p, st, tm, phases);
 }
 

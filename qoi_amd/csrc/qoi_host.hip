@@ -98,7 +98,7 @@ struct qoimi_ctx {
     bool recheck_pending = false;       // a repeated self-test is in flight on own_stream, result in host_word[8]
     int enc_ticket = 1, enc_set_slabs = 0, enc_warm = 1;   // tuning / test knobs (env QOIMI_ENC_*)
     int enc_cls = 0;                    // env QOIMI_ENC_CLS: 0 the literal classes of a step from the vector pipe (paired 16-bit halves), 1 from the matrix
-                                        // pipe (three v_mfma_i32_16x16x32_i8 per step), 2 the same at five wavefronts per SIMD
+                                        // pipe (one v_mfma_i32_32x32x16_i8 per step, five wavefronts per SIMD; measured: no faster - DESIGN.md section 3)
     int enc_lookback = -1;              // 1: sets place their bytes themselves (decoupled look-back); 0: order-free (scratch slots + enc_offsets + enc_compact); -1: by the number of sets per image
     std::string enc_debug_dump;         // env QOIMI_ENC_DEBUG_DUMP: file that receives the entry-state arrays of every encode call
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
@@ -161,7 +161,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_DEBUG_DUMP")) c->enc_debug_dump = e;
     if (const char* e = getenv("QOIMI_ENC_WARM")) c->enc_warm = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
-    if (const char* e = getenv("QOIMI_ENC_CLS")) { const int v = atoi(e); if (v >= 0 && v <= 2) c->enc_cls = v; }
+    if (const char* e = getenv("QOIMI_ENC_CLS")) { const int v = atoi(e); if (v >= 0 && v <= 1) c->enc_cls = v; }
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
     if (const char* e = getenv("QOIMI_P3_PLAIN")) c->dec_p3_plain = atoi(e);
@@ -294,6 +294,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         // and the look-back are paid once per set - as long as the sets still fill the 256 CUs x 20 wavefronts several times
         const size_t total_slabs = (size_t)n_images * p.spi;
         uint32_t r = total_slabs >= 3u * 65536u ? 3u : (total_slabs >= 16384u ? 2u : 1u);
+        if (r == 3u && c->enc_cls == 1 && c->xchg_ordered) r = 4u;     // (the matrix-pipe form stages 7.6 KB per wavefront: four slabs fit)
         if (c->enc_set_slabs > 0) r = (uint32_t)c->enc_set_slabs;
         if (r > kEncMaxSetSlabs) r = kEncMaxSetSlabs;
         p.set_slabs = r;

@@ -32,6 +32,10 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint64_t* cyc, uint32_t 
     int a1 = (int)lane * 0x01010101, pb1 = (int)seed * 0x01020304;
     asm volatile("" : "+v"(a), "+v"(a2), "+v"(a3), "+v"(pb), "+v"(a4), "+v"(pb4), "+v"(a1), "+v"(pb1));
     v4i d1 = {0, 0, 0, 0}, d2 = d1, d3 = d1;
+    __shared__ uint32_t lds[4][128];
+    const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&lds[threadIdx.x >> 6][0] + lane;
+    uint64_t m1 = 0x5555555555555555ull + seed, m2 = 0x0F0F0F0F0F0F0F0Full + seed, sm = 0;
+    asm volatile("" : "+s"(m1), "+s"(m2));
     v16i e = {0};
     const uint64_t t0 = __builtin_readcyclecounter();
     for (int it = 0; it < kIters; ++it) {
@@ -53,6 +57,20 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint64_t* cyc, uint32_t 
         if (T == 23) { asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(pbl) : "s"(0x00FFFFFFu), "v"(c)); pb = (long)(((unsigned long)pbh << 32) | pbl);
                        M32(e, a) V8 V8 V8 asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r0) : "v"(e[0]), "v"(e[15])); V8 }   // B operand fresh from a VALU
         if (T == 24) { M32(e, a) V8 V8 V8 asm volatile("v_or3_b32 %0, %1, %2, %3\n v_or3_b32 %0, %4, %5, %0\n v_perm_b32 %0, %6, %7, %0\n v_add3_u32 %0, %0, %8, %9" : "+v"(r0) : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[4]), "v"(e[5]), "v"(e[8]), "v"(e[9]), "v"(e[10]), "v"(e[15])); V8 }   // several reads
+        // what follows the matrix instruction in the encoder's step: exec switches around LDS byte stores, v_mbcnt, compares into SGPRs
+#define EXECSW asm volatile("s_mov_b64 exec, %2\n v_add3_u32 %0, %0, %1, %1\n s_mov_b64 exec, %3\n v_add3_u32 %0, %0, %1, %1\n s_mov_b64 exec, -1" : "+v"(r1) : "v"(b), "s"(m1), "s"(m2));
+#define LDSW asm volatile("ds_write_b8 %0, %1\n ds_write_b8_d16_hi %0, %1 offset:1" : : "v"(la), "v"(r2) : "memory");
+#define MBCNT asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0\n v_mbcnt_hi_u32_b32 %0, %2, %0" : "+v"(r3) : "s"((uint32_t)m1), "s"((uint32_t)(m1 >> 32)));
+#define CMPS asm volatile("v_cmp_lt_u32_e64 %1, %0, %2\n s_nop 1\n v_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(r4), "=&s"(sm) : "v"(b));
+        if (T == 30) { M32(e, a) EXECSW V8 V8 V8 asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r0) : "v"(e[0]), "v"(e[15])); V8 }
+        if (T == 40) { EXECSW V8 V8 V8 V8 }
+        if (T == 31) { M32(e, a) LDSW V8 V8 V8 asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r0) : "v"(e[0]), "v"(e[15])); V8 }
+        if (T == 41) { LDSW V8 V8 V8 V8 }
+        if (T == 32) { M32(e, a) CMPS V8 V8 V8 asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r0) : "v"(e[0]), "v"(e[15])); V8 }
+        if (T == 42) { CMPS V8 V8 V8 V8 }
+        if (T == 33) { M32(e, a) MBCNT MBCNT V8 V8 V8 asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r0) : "v"(e[0]), "v"(e[15])); V8 }
+        if (T == 43) { MBCNT MBCNT V8 V8 V8 V8 }
+        if (T == 34) { M32(e, a) asm volatile("s_cmp_lg_u64 %0, 0\n s_cbranch_scc0 1f\n 1:" : : "s"(m1) : "scc"); V8 V8 V8 asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r0) : "v"(e[0]), "v"(e[15])); V8 }
         if (T == 12) { M4(d1, a) M4(d2, a) M4(d3, a) M4(d1, a) M4(d2, a) M4(d3, a) V8 V8 USE4(d1) USE4(d2) USE4(d3) V8 V8 }   // six 4x4x4
     }
     const uint64_t t1 = __builtin_readcyclecounter();
@@ -92,6 +110,15 @@ int main() {
     run<5>("3 x 4x4x4 i8 + 32 (+3)", 35);
     run<12>("6 x 4x4x4 i8 + 32 (+3)", 35);
     run<6>("3 x 16x16x64 i8 + 32 (+3)", 35);
+    run<40>("exec switches (2 v_add3 under them) + 32", 34);
+    run<30>("32x32x16 i8, exec switches + 32 (+1 read)", 35);
+    run<41>("2 LDS byte stores + 32", 32);
+    run<31>("32x32x16 i8, 2 LDS byte stores + 32 (+1)", 33);
+    run<42>("v_cmp -> sgpr -> v_cndmask + 32", 34);
+    run<32>("32x32x16 i8, v_cmp/v_cndmask + 32 (+1)", 35);
+    run<43>("4 v_mbcnt + 32", 36);
+    run<33>("32x32x16 i8, 4 v_mbcnt + 32 (+1)", 37);
+    run<34>("32x32x16 i8, scalar branch + 32 (+1)", 33);
     run<20>("1 x 32x32x16 i8 + 32, read 8 later", 33);
     run<21>("1 x 32x32x16 i8 + 32, read 16 later", 33);
     run<24>("1 x 32x32x16 i8 + 32, 4 reads 24 later", 36);
