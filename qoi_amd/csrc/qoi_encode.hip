@@ -24,6 +24,16 @@
 
 namespace qoimi {
 
+#ifdef QOIMI_ENC_PHASES
+// Diagnostic build (-DQOIMI_ENC_PHASES, tools/dev/enc_phases.py): where a wavefront of enc_sets spends its life - s_memtime
+// ticks per phase of a set, summed over all wavefronts.  [0] entry state, [1] the groups inside the image, [2] groups of the general
+// form, [3] look-back, [4] copy-out, [5] sets, [6] the part of [1] in front of the first group's first step.
+__device__ unsigned long long g_enc_phase[8];
+#define PHASE_MARK(k) do { const unsigned long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_enc_phase[k], t_now - t_mark); t_mark = t_now; } while (0)
+#else
+#define PHASE_MARK(k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------
 // pixel load: CH = 4 -> one dword; CH = 3 -> three bytes, alpha forced to 255
 // (the reference leaves alpha at its 255 start value for 3-channel input, qoi.h:399-413)
@@ -891,6 +901,10 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     const bool last_set = hi == n;
     const uint32_t ngroups = (hi - lo + kGroupPx - 1u) / kGroupPx;
     const size_t sg = (size_t)img * p.sets_per_image + set;    // global index of the set
+#ifdef QOIMI_ENC_PHASES
+    unsigned long long t_mark = __builtin_readcyclecounter();
+    if (lane == 0) atomicAdd(&g_enc_phase[5], 1ull);
+#endif
 
     // ---- loads: what the entry state needs first, then the first group of pixels ------------------------------
     SetIn in;
@@ -940,6 +954,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     if (PROBE == 0) L.mask[lane] = 0;
     uint32_t ccp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(63u + (uint32_t)((int)lo - last_edge)));
     __builtin_amdgcn_wave_barrier();
+    PHASE_MARK(0);
 
     const uint32_t sbase = lds_addr(L.stage);
     uint32_t vbase = sbase;                                    // LDS address of the next staged byte (same in every lane)
@@ -1006,6 +1021,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
             }
         }
     }
+    PHASE_MARK(1);
     // ---- general form, group by group (no loads in flight across groups: one set per image, and one group more) -----------
 #pragma unroll 1
     for (; g < ngroups; ++g) {
@@ -1022,6 +1038,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     }
     uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
     const uint32_t set_bytes = spilled + spos;
+    PHASE_MARK(2);
 
     if (!p.lookback) {
         // ---- order-free mode: park the set's bytes in its scratch slot, E4 (enc_offsets + enc_compact) places them ----
@@ -1067,6 +1084,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         }
     }
 
+    PHASE_MARK(3);
     // ---- copy the set's bytes out ----------------------------------------------------------
     uint8_t* __restrict__ out = p.out + (size_t)img * p.out_stride;
     if (set == 0 && lane < (uint32_t)kHeaderBytes) {        // 14-byte header (qoi.h:384-388)
@@ -1089,6 +1107,10 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         if (lane < (uint32_t)kTrailerBytes) out[end + lane] = (lane == 7u) ? 1 : 0;
         if (lane == 0) p.out_len[img] = (int)(end + kTrailerBytes);
     }
+#ifdef QOIMI_ENC_PHASES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PHASE_MARK(4);
 }
 
 // ENTRY 0: entry state from the per-slab summaries + scans (E1/E2).  ENTRY 1: each set finds it itself
@@ -1336,3 +1358,12 @@ int run_lds_order_selftest(hipStream_t st) {
 }
 
 }  // namespace qoimi
+
+#ifdef QOIMI_ENC_PHASES
+extern "C" int qoimi_debug_enc_phases(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(qoimi::g_enc_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(qoimi::g_enc_phase), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

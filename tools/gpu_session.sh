@@ -13,6 +13,7 @@ echo "== bench"; timeout 900 python bench.py > "$OUT/bench.log" 2>&1; echo "rc=$
 echo "== rocprofv3 kernel trace + stats"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o trace -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu --no-others --no-single --no-configs) > "$OUT/prof.log" 2>&1
 echo "rc=$?" >> "$OUT/prof.log"
+[ "${SKIP_PMC:-0}" = 1 ] && { echo "== done (PMC passes skipped)"; exit 0; }
 echo "== PMC: HBM traffic of the bench kernels (separate passes)"
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OLDPWD/$OUT/pmc_$set" -o pmc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu --no-others --no-single --no-configs) > "$OUT/pmc_$set.log" 2>&1
