@@ -14,7 +14,7 @@ ps = npx * 4
 ss = (api.encode_bound(w, h, 4) + 255) // 256 * 256
 px = torch.empty(F * ps, dtype=torch.uint8, device='cuda'); st = torch.empty(F * ss, dtype=torch.uint8, device='cuda'); lens = torch.zeros(F, dtype=torch.int32, device='cuda')
 s = torch.cuda.current_stream().cuda_stream
-c.synth_frames(synth.KIND_ID['photo'], synth.DEFAULT_SEED, 0, F, w, h, px.data_ptr(), ps, s)
+c.synth_frames(synth.KIND_ID[os.environ.get("KIND", "photo")], synth.DEFAULT_SEED, 0, F, w, h, px.data_ptr(), ps, s)
 desc = api.QoiDesc(w, h, 4, 0)
 for _ in range(2):
     c.encode_batch(px.data_ptr(), ps, desc, F, st.data_ptr(), ss, lens.data_ptr(), s); c.encode_status(s)
