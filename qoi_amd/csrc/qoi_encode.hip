@@ -584,10 +584,10 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const Ma
         ccp = clz64_plus64(Ec);
         // ---- colour-table probe/update (qoi.h:430-436) for edge pixels ---------------------
         // 4 * QOI_COLOR_HASH (qoi.h:322); CLS 1: the same modulo 256 (only bits 2..7 are looked at)
-        const uint32_t hsh = CLS == 1 ? (uint32_t)S.d[3] : __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);
+        const uint32_t hsh = CLS != 0 ? (uint32_t)S.d[3] : __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);
         uint32_t seen = ~px;
         uint32_t od = 0u, ol = 0u;
-        if (CLS == 1) { od = range_word_diff(S); ol = range_word_luma(S); }
+        if (CLS != 0) { od = range_word_diff(S); ol = range_word_luma(S); }
         if (PROBE == 1) {
             seen = GEN ? probe_swap((hsh & 0xFCu) | C.tbase, px, Ec) : probe_swap_all((hsh & 0xFCu) | C.tbase, px);
         } else {
@@ -609,7 +609,7 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const Ma
         // ---- chunk of an edge pixel (qoi.h:432-474): INDEX, else RGBA if alpha moved, else DIFF, LUMA, RGB ----
         u64 m_ad;                                          // lanes whose alpha differs from the previous pixel's
         uint32_t we;
-        if (CLS == 1) { we = literal_word_mat(S, od, ol); m_ad = S.alpha_moved; }
+        if (CLS != 0) { we = literal_word_mat(S, od, ol); m_ad = S.alpha_moved; }
         else we = literal_word<HALF>(K, px, prev, m_ad);
         // QOI_OP_INDEX (qoi.h:432-434) where the slot held the pixel; the edge lanes take their chunk word, the others keep
         // their run byte (one v_cndmask under exec = edges instead of two)
@@ -617,7 +617,7 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const Ma
         const u64 lng = __ballot(word_is_long(w));
         if (__builtin_expect(lng != 0ull, 0)) {
             // rare in natural images: some lane carries QOI_OP_RGB / QOI_OP_RGBA (qoi.h:461-474): tag r g b (a)
-            const u64 five = uniform64(lng & m_ad);          // (SGPR pairs for the exec switches below, whatever the compiler made of them)
+            const u64 five = lng & m_ad;
             const u64 two = __ballot(word_is_two(w)) & ~lng;
             const u64 b0 = (any & ~(two | lng)) | five;            // odd lengths: 1-byte chunks and RGBA
             const uint32_t off = vbase + count_below(b0) + 2u * count_below(two) + 4u * count_below(lng);
@@ -631,7 +631,7 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const Ma
     }
     // (this step's forms are consumed: the matrix pipe works on the next step's while the offsets below and the run lengths of
     // the next step are worked out)
-    if (CLS == 1 && has_next && next_E != 0ull) mat_classify(S, M, next_px, next_pv);
+    if (CLS != 0 && has_next && next_E != 0ull) mat_classify(S, M, next_px, next_pv);
     // ---- common case: chunk lengths 1 and 2 only.  offset = #chunks below + #LUMA chunks below ----
     {
         const u64 two = __ballot(word_is_two(w)) & any;
@@ -640,22 +640,6 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const Ma
         vbase += (uint32_t)__builtin_popcountll(any) + (uint32_t)__builtin_popcountll(two);
     }
 }
-
-// ---- deferred placement (CLS 2) ---------------------------------------------------------------------------------------
-// A set that is through waits for its place in the stream: for the byte counts of the sets of its image that run beside it -
-// 18 % of a wavefront's life (phase stamps).  In this form the wavefront does not wait: the set's bytes stay
-// where they are staged, the wavefront encodes its NEXT set into the other half of the staging buffer, and the set is placed when
-// that one is through - its predecessors have had a whole set's time to publish by then.  Two halves of 3 KB: two slabs per set,
-// and a step checks whether its 320 bytes still fit (a group's 2560 would not).
-struct SpillCtx { uint32_t sbase; uint32_t* stage; uint8_t* slot; uint32_t* spilled; };
-template <int PROBE>
-__device__ __forceinline__ uint32_t spill_stage_at(uint32_t* stage, uint8_t* __restrict__ slot, uint32_t& spilled, uint32_t spos, bool all, uint32_t lane);
-constexpr uint32_t kHalfBytes = kStageBytes / 2u;                 // 3168: a multiple of 16
-constexpr uint32_t kHalfSpill = kHalfBytes - 320u - 16u;          // more staged bytes than this in front of a step: spill first
-static_assert(kHalfBytes % 16u == 0u, "the second half of the staging buffer keeps the alignment of the first");
-struct Pending {                     // the set whose bytes wait in half `buf` (all wave-uniform)
-    uint32_t valid, img, set, set_bytes, spilled, spos, buf, last_set;
-};
 
 // lanes 0..r-1 (r <= 0: none, r >= 64: all)
 __device__ __forceinline__ u64 lanes_upto(int r) { return r >= 64 ? ~0ull : (r <= 0 ? 0ull : (1ull << r) - 1ull); }
@@ -667,19 +651,15 @@ __device__ __forceinline__ u64 lanes_upto(int r) { return r >= 64 ? ~0ull : (r <
 template <int PROBE, bool GEN, int CLS, class LDS>
 __device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, const MatConst& M, uint32_t lane,
                                               const uint32_t (&px)[kGroupSteps], const uint32_t (&pv)[kGroupSteps],
-                                              uint32_t nx_px, uint32_t nx_pv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase, const SpillCtx& sp) {
+                                              uint32_t nx_px, uint32_t nx_pv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase) {
     if (GEN) E &= lanes_upto(rem);                         // (the group before this one does not know where the image ends)
     PairClass K = {0u, 0u, 0u, 0u, 0u};
     // CLS 1: the forms of the step at hand (only looked at under the condition they were asked for under: no value for the
     // other case).  The group's first step asks for its own, every step then for the next one's.
     StepClass S;
-    if (CLS == 1 && E != 0ull) mat_classify(S, M, px[0], pv[0]);
+    if (CLS != 0 && E != 0ull) mat_classify(S, M, px[0], pv[0]);
 #pragma unroll
     for (int t = 0; t < kGroupSteps; ++t) {
-        if (CLS == 2) {                                        // (half a staging buffer: room for this step's bytes?)
-            const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sp.sbase;
-            if (spos > kHalfSpill) vbase = sp.sbase + spill_stage_at<PROBE>(sp.stage, sp.slot, *sp.spilled, spos, false, lane);
-        }
         const u64 Ec = E;
         u64 V = ~0ull, lastbit = 0ull;
         if (GEN) {
@@ -692,7 +672,7 @@ __device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, const 
         else E = __ballot(nx_px != nx_pv);
         if (GEN) E &= lanes_upto(rem - (t + 1) * 64);
         const u64 nb63 = E << 63;
-        if (CLS != 1 && (t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);   // this step and the next one
+        if (CLS == 0 && (t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);   // this step and the next one
         if (GEN && V == 0ull) continue;
         constexpr int kLast = kGroupSteps - 1;
         const bool has_next = t < kLast;
@@ -751,7 +731,7 @@ __device__ __forceinline__ void process_group_roll(LDS& L, const LaneConst& C, c
         if (t + 1 < kGroupSteps) E = __ballot(px[t + 1] != pv[t + 1]);
         else E = MORE ? __ballot(px[0] != pv[0]) : __ballot(end_px != end_pv);
         const u64 nb63 = E << 63;
-        if (CLS != 1 && (t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);
+        if (CLS == 0 && (t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);
         const bool has_next = MORE || t + 1 < kGroupSteps;
         constexpr int kMask = kGroupSteps - 1;
         const int tn = (t + 1) & kMask;
@@ -896,86 +876,24 @@ __device__ __forceinline__ void copy_stage_out(const uint32_t* stage, uint8_t* _
 
 // Moves the staged bytes [0, spos) to the set's scratch slot behind the `spilled` bytes already there (a multiple of 16).
 // all = false: whole 16-byte pieces only, the remainder moves to the front of the staging buffer.  Returns the bytes left staged.
-// (stage: the staging buffer in use - the whole of L.stage, or the half of it a set of the deferred form writes to)
-template <int PROBE>
-__device__ __forceinline__ uint32_t spill_stage_at(uint32_t* stage, uint8_t* __restrict__ slot, uint32_t& spilled, uint32_t spos, bool all, uint32_t lane) {
+template <int PROBE, class LDS>
+__device__ __forceinline__ uint32_t spill_stage(LDS& L, uint8_t* __restrict__ slot, uint32_t& spilled, uint32_t spos, bool all, uint32_t lane) {
     const uint32_t n16 = all ? (spos + 15u) >> 4 : spos >> 4;
     uint4* __restrict__ dst = reinterpret_cast<uint4*>(slot + spilled);
-    const uint4* src = reinterpret_cast<const uint4*>(stage);
+    const uint4* src = reinterpret_cast<const uint4*>(L.stage);
     __builtin_amdgcn_wave_barrier();
     for (uint32_t j = lane; j < n16; j += 64u) dst[j] = src[j];
     spilled += n16 << 4;
     if (all) return 0u;
-    const uint32_t keep = lane < 4u ? stage[(n16 << 2) + lane] : 0u;     // the incomplete piece (LDS ops of a wavefront run in order)
+    const uint32_t keep = lane < 4u ? L.stage[(n16 << 2) + lane] : 0u;     // the incomplete piece (LDS ops of a wavefront run in order)
     __builtin_amdgcn_wave_barrier();
-    if (lane < 4u) stage[lane] = keep;
+    if (lane < 4u) L.stage[lane] = keep;
     __builtin_amdgcn_wave_barrier();
     return spos & 15u;
 }
-template <int PROBE, class LDS>
-__device__ __forceinline__ uint32_t spill_stage(LDS& L, uint8_t* __restrict__ slot, uint32_t& spilled, uint32_t spos, bool all, uint32_t lane) {
-    return spill_stage_at<PROBE>(L.stage, slot, spilled, spos, all, lane);
-}
-
-// Places the set `d` (deferred form): its offset by look-back over the earlier sets of its image (they have had a set's time to
-// publish: one poll, asked for early - `early_rec` - or now), then the inclusive record, then the bytes from the half of the staging
-// buffer they wait in (and from the scratch slot what was spilled).  The same steps as at the end of encode_set.
-template <int CH, int ENTRY, class LDS>
-__device__ __forceinline__ void place_pending(const EncParams& p, const Pending& d, uint32_t lane, LDS& L, u64 early_rec, bool early) {
-    constexpr u64 kRecIncl = 2ull << 62;
-    const size_t sg = (size_t)d.img * p.sets_per_image + d.set;
-    const u64* const rec_base = p.status + (sg - d.set);
-    uint32_t excl = 0;
-    if (d.set != 0u) {
-        uint32_t look = d.set - 1u;
-        uint32_t spins = 0;
-        for (;;) {
-            const bool inwin = lane <= look;
-            u64 v;
-            if (early) { v = early_rec; early = false; }
-            else v = inwin ? granule_load(&rec_base[look - lane]) : kRecIncl;
-            const uint32_t flag = (uint32_t)(v >> 62);
-            const u64 notready = __ballot(flag == 0u);
-            const u64 incl = __ballot(flag == 2u);
-            const int stop = incl ? __builtin_ctzll(incl) : 64;
-            const u64 need = stop >= 64 ? ~0ull : ((1ull << stop) - 1ull);
-            if (notready & need) {
-                if (ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[d.img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-                if (++spins > (1u << 22)) { if (lane == 0) atomicOr(p.err, 1u); break; }
-                __builtin_amdgcn_s_sleep(2);
-                continue;
-            }
-            excl += wave_sum32_upto((uint32_t)v, lane, stop);
-            if (incl) break;
-            look -= 64u;
-        }
-        if (lane == 0) granule_store(&p.status[sg], kRecIncl | (u64)(excl + d.set_bytes));
-    }
-    uint8_t* __restrict__ out = p.out + (size_t)d.img * p.out_stride;
-    if (d.set == 0u && lane < (uint32_t)kHeaderBytes) {      // 14-byte header (qoi.h:384-388)
-        const uint32_t w = p.width, h = p.height;
-        const u64 hdr_lo = 0x66696F71ull | ((u64)__builtin_bswap32(w) << 32);
-        const u64 hdr_hi = (u64)__builtin_bswap32(h) | ((u64)p.channels << 32) | ((u64)p.colorspace << 40);
-        out[lane] = (uint8_t)((lane < 8u ? hdr_lo : hdr_hi) >> (8u * (lane & 7u)));
-    }
-    const u64 pos = (u64)kHeaderBytes + (u64)excl;
-    if (d.spilled) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        copy_global_out(p.scratch + sg * p.set_stride, out + pos, d.spilled, lane);
-    }
-    if (d.spos) {
-        __builtin_amdgcn_wave_barrier();
-        copy_stage_out(L.stage + d.buf * (kHalfBytes / 4u), out + pos + d.spilled, d.spos, lane);
-    }
-    if (d.last_set) {                                        // trailer (qoi.h:339,480-482) + *out_len
-        const u64 end = pos + d.set_bytes;
-        if (lane < (uint32_t)kTrailerBytes) out[end + lane] = (lane == 7u) ? 1 : 0;
-        if (lane == 0) p.out_len[d.img] = (int)(end + kTrailerBytes);
-    }
-}
 
 template <int CH, int PROBE, int ENTRY, int CLS, class LDS>
-__device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, LDS& L, Pending& pend) {
+__device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, LDS& L) {
     const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
     const uint32_t n = p.npx;
     const uint32_t lo = set * p.set_px;                        // first pixel of the set (a slab boundary)
@@ -1021,7 +939,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     C.tbase = lds_addr(L.table);                               // 256-byte aligned
     asm volatile("" : "+v"(C.tbase));                          // keep in a VGPR
     MatConst M = {0l};
-    if (CLS == 1) mat_const_init(M, lane);
+    if (CLS != 0) mat_const_init(M, lane);
     int last_edge;
     if (ENTRY == 1) {
         if (!warm_entry_state<CH, PROBE>(pix, lo, lane, L, C.tbase, in, last_edge)) {
@@ -1038,15 +956,10 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     __builtin_amdgcn_wave_barrier();
     PHASE_MARK(0);
 
-    // (deferred form: the half of the staging buffer the set before this one of this wavefront does not wait in)
-    const bool defer = CLS == 2 && p.lookback;
-    const uint32_t buf = (defer && pend.valid) ? (pend.buf ^ 1u) : 0u;
-    uint32_t* const stage = L.stage + buf * (kHalfBytes / 4u);
-    const uint32_t sbase = lds_addr(stage);
+    const uint32_t sbase = lds_addr(L.stage);
     uint32_t vbase = sbase;                                    // LDS address of the next staged byte (same in every lane)
     uint32_t spilled = 0;                                      // bytes of the set already moved to its scratch slot
     uint8_t* __restrict__ slot = p.scratch + sg * p.set_stride;
-    const SpillCtx sp = {sbase, stage, slot, &spilled};
 
     // Look-back, first poll: the records of the 64 sets before this one are asked for when the set's LAST group begins - the sets
     // before it started earlier and have mostly published by then - so that the answer travels while that group is encoded
@@ -1056,16 +969,11 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     u64 early_rec = kRecIncl;
     bool early = false;
     auto ask_early = [&]() {
-        if (defer) {                                           // (the set that waits: its window, not this set's)
-            if (pend.valid && pend.set != 0u) {
-                const u64* const rb = p.status + (size_t)pend.img * p.sets_per_image;
-                early_rec = lane < pend.set ? granule_load(&rb[pend.set - 1u - lane]) : kRecIncl; early = true;
-            }
-        } else if (p.lookback && set != 0u) { early_rec = lane < set ? granule_load(&rec_base[set - 1u - lane]) : kRecIncl; early = true; }
+        if (p.lookback && set != 0u) { early_rec = lane < set ? granule_load(&rec_base[set - 1u - lane]) : kRecIncl; early = true; }
     };
 
     uint32_t g = 0;
-    if (CLS == 1 && nint) {
+    if (CLS != 0 && nint) {
         // ---- rolling ring (process_group_roll): a* holds the eight steps at hand, each refilled for the next group as it is used up ----
         u64 E = __ballot(ax[0] != av[0]);
         StepClass S;
@@ -1086,7 +994,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
             ++g;
         }
     }
-    if (CLS != 1 && nint) {
+    if (CLS == 0 && nint) {
         u64 E = __ballot(ax[0] != av[0]);
         // ---- two groups per turn: while one is encoded the loads of the next are in flight ----------------------------
         // (the pair loaded when no group follows inside the loop: the two pixels around the end of the set, or around the
@@ -1096,19 +1004,19 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
             {   // group g sits in a*; fetch g+1 into b*
                 const uint32_t base = lo + g * kGroupPx;
                 const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-                if (CLS != 2 && spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+                if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, bx, bv);
                 else { bx[0] = load_px<CH>(pix, base + kGroupPx); bv[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
-                process_group<PROBE, false, CLS>(L, C, M, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase, sp);
+                process_group<PROBE, false, CLS>(L, C, M, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
                 if (++g >= nint) break;
             }
             {   // group g sits in b*; fetch g+1 into a*
                 const uint32_t base = lo + g * kGroupPx;
                 const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-                if (CLS != 2 && spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+                if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, ax, av);
                 else { ax[0] = load_px<CH>(pix, base + kGroupPx); av[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
-                process_group<PROBE, false, CLS>(L, C, M, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase, sp);
+                process_group<PROBE, false, CLS>(L, C, M, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
                 if (++g >= nint) break;
             }
         }
@@ -1119,14 +1027,14 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     for (; g < ngroups; ++g) {
         const uint32_t base = lo + g * kGroupPx;
         const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-        if (CLS != 2 && spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+        if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
         uint32_t nxp, nxv;
 #pragma unroll
         for (int t = 0; t < kGroupSteps; ++t) load_pair_guarded<CH>(pix, base + t * 64u + lane, n, ax[t], av[t]);
         load_pair_guarded<CH>(pix, base + kGroupPx + lane, n, nxp, nxv);
         if (g + 1u == ngroups) ask_early();
         u64 E = __ballot(ax[0] != av[0]);
-        process_group<PROBE, true, CLS>(L, C, M, lane, ax, av, nxp, nxv, (int)(n - base), E, ccp, vbase, sp);
+        process_group<PROBE, true, CLS>(L, C, M, lane, ax, av, nxp, nxv, (int)(n - base), E, ccp, vbase);
     }
     uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
     const uint32_t set_bytes = spilled + spos;
@@ -1134,16 +1042,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 
     if (!p.lookback) {
         // ---- order-free mode: park the set's bytes in its scratch slot, E4 (enc_offsets + enc_compact) places them ----
-        (void)spill_stage_at<PROBE>(stage, slot, spilled, spos, true, lane);
+        (void)spill_stage<PROBE>(L, slot, spilled, spos, true, lane);
         if (lane == 0) p.set_size[sg] = set_bytes;
-        return;
-    }
-    if (defer) {
-        // ---- deferred form: publish this set's byte count, place the set that waits, leave this one waiting in its half ----
-        if (lane == 0) granule_store(&p.status[sg], (set == 0u ? kRecIncl : kRecAgg) | set_bytes);
-        if (pend.valid) place_pending<CH, ENTRY>(p, pend, lane, L, early_rec, early);
-        pend.valid = 1u; pend.img = img; pend.set = set; pend.set_bytes = set_bytes; pend.spilled = spilled; pend.spos = spos;
-        pend.buf = buf; pend.last_set = last_set ? 1u : 0u;
         return;
     }
 
@@ -1223,7 +1123,6 @@ __global__ __launch_bounds__(256, PROBE == 1 ? (CLS == 1 ? QOIMI_ENC_WAVES_PER_S
     __shared__ EncLdsFor<PROBE, CLS> s_lds[4];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
-    Pending pend = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};            // (deferred form: the set of this wavefront that waits for its place)
 #pragma unroll 1
     for (uint32_t unit = blockIdx.x; unit < p.n_units; unit += gridDim.x) {
         const uint32_t img = unit % p.n_images;
@@ -1239,10 +1138,9 @@ __global__ __launch_bounds__(256, PROBE == 1 ? (CLS == 1 ? QOIMI_ENC_WAVES_PER_S
             if (lane == 0) t = atomicAdd(&p.ticket[img], 1u);
             set = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         }
-        if (set < p.sets_per_image) encode_set<CH, PROBE, ENTRY, CLS>(p, img, set, lane, s_lds[wave], pend);
+        if (set < p.sets_per_image) encode_set<CH, PROBE, ENTRY, CLS>(p, img, set, lane, s_lds[wave]);
         __builtin_amdgcn_wave_barrier();
     }
-    if (CLS == 2 && pend.valid) place_pending<CH, ENTRY>(p, pend, lane, s_lds[wave], 0ull, false);      // the wavefront's last set
 }
 
 // ---------------------------------------------------------------------------------
@@ -1395,10 +1293,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     if (phases & kEncSlabs) {
     if (warm) {
         p.only_flagged = 0;
-        // (deferred form: as many workgroups as the GPU holds at once - a wavefront takes unit after unit, each set placed while
-        // the next one is encoded)
-        const uint32_t resident = 256u * 6u;
-        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, CLS>), dim3(CLS == 2 && p.n_units > resident ? resident : p.n_units), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, CLS>), dim3(p.n_units), dim3(256), 0, st, p);
         tm->mark(kT_enc_slabs, st);
         p.only_flagged = 1;
     } else {
@@ -1433,14 +1328,12 @@ void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phas
     // (the matrix-pipe classes exist for the exchange probe only: the order-independent probe is the fall-back path)
     if (p.channels == 3) {
         if (!p.probe_xchg) launch_encode_t<3, 0, 0>(p, st, tm, phases);
-        else if (p.cls_mat == 2) launch_encode_t<3, 1, 2>(p, st, tm, phases);
         else if (p.cls_mat) launch_encode_t<3, 1, 1>(p, st, tm, phases);
         else launch_encode_t<3, 1, 0>(p, st, tm, phases);
         return;
     }
     if (!p.probe_xchg) { launch_encode_t<4, 0, 0>(p, st, tm, phases); return; }
-    if (p.cls_mat == 2) launch_encode_t<4, 1, 2>(p, st, tm, phases);
-    else if (p.cls_mat) launch_encode_t<4, 1, 1>(p, st, tm, phases);
+    if (p.cls_mat) launch_encode_t<4, 1, 1>(p, st, tm, phases);
     else launch_encode_t<4, 1, 0>(p, st, tm, phases);
 }
 

@@ -161,7 +161,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_DEBUG_DUMP")) c->enc_debug_dump = e;
     if (const char* e = getenv("QOIMI_ENC_WARM")) c->enc_warm = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
-    if (const char* e = getenv("QOIMI_ENC_CLS")) { const int v = atoi(e); if (v >= 0 && v <= 2) c->enc_cls = v; }
+    if (const char* e = getenv("QOIMI_ENC_CLS")) { const int v = atoi(e); if (v >= 0 && v <= 1) c->enc_cls = v; }
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
     if (const char* e = getenv("QOIMI_P3_PLAIN")) c->dec_p3_plain = atoi(e);
@@ -295,7 +295,6 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         const size_t total_slabs = (size_t)n_images * p.spi;
         uint32_t r = total_slabs >= 3u * 65536u ? 3u : (total_slabs >= 16384u ? 2u : 1u);
         if (r == 3u && c->enc_cls == 1 && c->xchg_ordered) r = 4u;     // (the matrix-pipe form stages 7.6 KB per wavefront: four slabs fit)
-        if (r == 3u && c->enc_cls == 2 && c->xchg_ordered) r = 2u;     // (the deferred form stages in halves of 3 KB: two slabs)
         if (c->enc_set_slabs > 0) r = (uint32_t)c->enc_set_slabs;
         if (r > kEncMaxSetSlabs) r = kEncMaxSetSlabs;
         p.set_slabs = r;

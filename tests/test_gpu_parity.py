@@ -273,9 +273,6 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_CLS": "1"},                               # literal classes of a step from the matrix pipe (one v_mfma_i32_32x32x16_i8 per step)
     {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_WARM": "0"},        # ... with the entry states from the summary passes
     {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
-    {"QOIMI_ENC_CLS": "2"},                               # deferred placement: a set is placed while its wavefront encodes the next one
-    {"QOIMI_ENC_CLS": "2", "QOIMI_ENC_SET_SLABS": "3"},   # ... with sets that outgrow their half of the staging buffer
-    {"QOIMI_ENC_CLS": "2", "QOIMI_ENC_WARM": "0"},
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
@@ -457,7 +454,7 @@ def test_flat_frames_byte_identical(api, oracle, env):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_CLS": "1"}, {"QOIMI_ENC_CLS": "2"}])
+@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_CLS": "1"}])
 def test_random_sweep_of_contents_and_shapes(api, oracle, env):
     """A seeded sweep over every synthetic content kind at shapes from a few pixels to several 64-slab groups, 3 and 4 channels:
     encode byte-identical to the reference, decode of that stream bit-identical to the pixels.  (The fixed shapes of the other
@@ -562,7 +559,7 @@ def _mixed_frame(rng, w, h, ch, seed):
 
 
 @pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_SET_SLABS": "3"}, {"QOIMI_ENC_SET_SLABS": "8"}, {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
-                                 {"QOIMI_ENC_CLS": "1"}, {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_SET_SLABS": "3"}, {"QOIMI_ENC_CLS": "2"}])
+                                 {"QOIMI_ENC_CLS": "1"}, {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_SET_SLABS": "3"}])
 def test_mixed_content_partial_spills(api, oracle, env):
     """Sets whose bytes only partly fit the LDS staging buffer (tools/dev/sweep_enc.py is the long form of this test)."""
     import torch
