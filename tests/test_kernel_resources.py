@@ -1,0 +1,55 @@
+"""The occupancy the kernels were measured at, held without a GPU: registers, scratch and LDS of every gfx950 kernel in the built
+library are read from the code object's metadata (tools/kernel_resources.py) and compared with the budgets DESIGN.md states
+(wavefronts per SIMD by registers, workgroups per CU by LDS: 160 KB per CU, 512 registers per SIMD lane).  A change that makes the
+compiler spill, or that takes a kernel over its register / LDS step, fails here before it costs a GPU run."""
+import os
+
+import pytest
+
+from tools import kernel_resources as KR
+
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qoi_amd", "lib", "libqoi_mi355x.so")
+LDS_PER_CU = 160 * 1024
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(LIB):
+        pytest.skip("library not built (python -c 'import __graft_entry__ as g; g.build()')")
+    ks = KR.kernels(LIB)
+    assert len(ks) >= 40, sorted(ks)
+    return ks
+
+
+def _one(ks, needle):
+    hits = [k for k in ks if needle in k]
+    assert len(hits) == 1, (needle, hits)
+    return ks[hits[0]]
+
+
+def test_no_kernel_spills_except_the_experimental_encoder_form(kernels):
+    for name, k in kernels.items():
+        if "enc_setsILi" in name and name.split("enc_setsILi")[1].split("E")[3] == "Li1":      # matrix-pipe form (QOIMI_ENC_CLS=1)
+            assert k["scratch"] <= 32, (name, k)
+        else:
+            assert k["scratch"] == 0 and k["vgpr_spills"] == 0, (name, k)
+
+
+@pytest.mark.parametrize("ch", [3, 4])
+@pytest.mark.parametrize("entry", [0, 1])
+def test_encoder_hot_kernel_keeps_six_wavefronts_per_simd(kernels, ch, entry):
+    k = _one(kernels, f"enc_setsILi{ch}ELi1ELi{entry}ELi0E")           # exchange probe, vector-pipe classes: the default
+    assert k["vgpr"] <= 80 and k["agpr"] == 0, k                       # 512 / 6 = 85 -> 80 at the allocation granule
+    assert 6 * k["lds"] <= LDS_PER_CU, k                               # six workgroups of four wavefronts per CU
+    m = _one(kernels, f"enc_setsILi{ch}ELi1ELi{entry}ELi1E")           # matrix-pipe classes: five wavefronts per SIMD
+    assert m["vgpr"] <= 96 and 5 * m["lds"] <= LDS_PER_CU, m
+
+
+def test_decoder_passes_keep_their_workgroups_per_cu(kernels):
+    tr = _one(kernels, "dec_transcodeILi0E")
+    assert tr["vgpr"] <= 80 and 4 * tr["lds"] <= LDS_PER_CU, tr        # four workgroups of four wavefronts
+    p3 = _one(kernels, "dec_summarize_recILb0E")
+    assert 8 * p3["lds"] <= LDS_PER_CU and p3["vgpr"] <= 128, p3       # eight wavefronts (one per workgroup) per CU
+    for och in (3, 4):
+        p4 = _one(kernels, f"dec_segments_recILi{och}E")
+        assert 6 * p4["lds"] <= LDS_PER_CU and p4["vgpr"] <= 128, p4   # six per CU
