@@ -1293,7 +1293,8 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     if (phases & kEncSlabs) {
     if (warm) {
         p.only_flagged = 0;
-        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, CLS>), dim3(p.n_units), dim3(256), 0, st, p);
+        // (p.persist: test knob - at most that many workgroups, each taking unit after unit in the kernel's grid-stride loop)
+        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, CLS>), dim3(p.persist && p.n_units > p.persist ? p.persist : p.n_units), dim3(256), 0, st, p);
         tm->mark(kT_enc_slabs, st);
         p.only_flagged = 1;
     } else {

@@ -270,6 +270,7 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_DEC_L2M": "2"},                               # the per-image level of the state chain as eight workgroups per image (calls of a few large images take it)
     {"QOIMI_DEC_L2M": "2", "QOIMI_SEG_BYTES": "128"},     # ... with many groups per image, several rounds (uiflat)
     {"QOIMI_DEC_L2M": "0"},                               # ... never
+    {"QOIMI_ENC_PERSIST": "3"},                           # three workgroups walk all units (grid-stride loop of enc_sets)
     {"QOIMI_ENC_CLS": "1"},                               # literal classes of a step from the matrix pipe (one v_mfma_i32_32x32x16_i8 per step)
     {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_WARM": "0"},        # ... with the entry states from the summary passes
     {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
