@@ -1125,7 +1125,11 @@ __global__ __launch_bounds__(256, PROBE == 1 ? (CLS == 1 ? QOIMI_ENC_WAVES_PER_S
     if (p.only_flagged && *p.any_generic == 0u) return;
 #pragma unroll 1
     for (uint32_t unit = blockIdx.x; unit < p.n_units; unit += gridDim.x) {
-        const uint32_t img = unit % p.n_images;
+        // p.spread (look-back + ticket mode only; prepared in round 3, NOT yet measured or run on a GPU): the four wavefronts of a
+        // workgroup serve four consecutive IMAGES instead of taking four consecutive tickets of one image at the same instant - those
+        // four run in lock step and each waits in its look-back for the others (what the 18 % are made of).
+        // Every image still receives sets_per_image tickets' worth of wavefronts (4 n_units / n_images of them).
+        const uint32_t img = (p.spread && p.use_ticket && p.lookback) ? (unit * 4u + wave) % p.n_images : unit % p.n_images;
         if (p.only_flagged && p.need_generic[img] == 0u) continue;
         if (ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;   // image already sent to the generic path
         uint32_t set = (unit / p.n_images) * 4u + wave;    // order-free mode: any order will do

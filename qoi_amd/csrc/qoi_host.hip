@@ -97,6 +97,7 @@ struct qoimi_ctx {
     long long enc_calls_at_check = 0, enc_recheck_every = 256, enc_suspect_calls = 0;   // env QOIMI_ENC_RECHECK_EVERY
     bool recheck_pending = false;       // a repeated self-test is in flight on own_stream, result in host_word[8]
     int enc_ticket = 1, enc_set_slabs = 0, enc_warm = 1;   // tuning / test knobs (env QOIMI_ENC_*)
+    int enc_spread = 0;                 // env QOIMI_ENC_SPREAD
     int enc_persist = 0;                // env QOIMI_ENC_PERSIST: workgroups of the first encode pass (0: one per unit)
     int enc_cls = 0;                    // env QOIMI_ENC_CLS: 0 the literal classes of a step from the vector pipe (paired 16-bit halves), 1 from the matrix
                                         // pipe (one v_mfma_i32_32x32x16_i8 per step, five wavefronts per SIMD; measured: no faster - DESIGN.md section 3)
@@ -162,6 +163,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_DEBUG_DUMP")) c->enc_debug_dump = e;
     if (const char* e = getenv("QOIMI_ENC_WARM")) c->enc_warm = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
+    if (const char* e = getenv("QOIMI_ENC_SPREAD")) c->enc_spread = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_PERSIST")) { const int v = atoi(e); if (v >= 0) c->enc_persist = v; }
     if (const char* e = getenv("QOIMI_ENC_CLS")) { const int v = atoi(e); if (v >= 0 && v <= 1) c->enc_cls = v; }
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
@@ -293,6 +295,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.warm = c->enc_warm ? 1 : 0;
     p.cls_mat = (uint8_t)c->enc_cls;
     p.persist = (uint32_t)c->enc_persist;
+    p.spread = (uint32_t)c->enc_spread;
     {   // slabs per set: a wavefront carries the colour table and its staged bytes from slab to slab, so the entry-state replay
         // and the look-back are paid once per set - as long as the sets still fill the 256 CUs x 20 wavefronts several times
         const size_t total_slabs = (size_t)n_images * p.spi;
