@@ -116,13 +116,16 @@ int qoimi_encode_batch(qoimi_ctx *ctx, const void *d_pixels, size_t pixel_stride
  * every 256 encode calls of the context (env QOIMI_ENC_RECHECK_EVERY) on the context's private stream; that repeat is looked at
  * by the NEXT encode call.  Failure latency, stated plainly: if a repeat ever failed, up to 2 x 256 earlier calls of the
  * context would already have returned streams made with the suspect probe.  The context then switches to the order-independent
- * probe for good (the call that notices is encoded with it and does not fail), qoimi_last_error() says so, and this counter
- * returns how many calls lie between the last passed check and the failed one - re-verify or re-encode those.  0 = never.
+ * probe for good; the call that notices is encoded with it and returns QOIMI_OK (its own stream is sound), qoimi_last_error()
+ * says what happened, the next qoimi_encode_status() returns QOIMI_E_INTERNAL ONCE, and this counter returns how many calls were
+ * made since the launch of the last check that passed (the calls before the failed repeat was launched and the ones made while
+ * it ran) - re-verify or re-encode those.  0 = never.
  * QOIMI_ENC_PROBE=0 in the environment selects the order-independent probe from the start (about 1.5 x the encode time). */
 long long qoimi_encode_suspect_calls(qoimi_ctx *ctx);
 
 /* Synchronise `stream` and return QOIMI_E_INTERNAL if the last qoimi_encode_batch on this
- * context tripped its device-side liveness bound (never expected); QOIMI_OK otherwise. */
+ * context tripped its device-side liveness bound (never expected), or - once - after a repeat of
+ * the LDS-order self-test failed (see qoimi_encode_suspect_calls); QOIMI_OK otherwise. */
 int qoimi_encode_status(qoimi_ctx *ctx, void *stream);
 
 /* Decode n_images streams that live in device memory.

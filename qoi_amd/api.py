@@ -97,6 +97,8 @@ def load_library() -> ctypes.CDLL:
     lib.qoimi_get_profile.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), ci]
     lib.qoimi_kernel_name.restype = ctypes.c_char_p
     lib.qoimi_kernel_name.argtypes = [ci]
+    lib.qoimi_encode_suspect_calls.restype = ctypes.c_longlong
+    lib.qoimi_encode_suspect_calls.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -219,6 +221,10 @@ class Context:
 
     def encode_status(self, stream: int = 0) -> None:
         self._check(self._lib.qoimi_encode_status(self._h, stream), "qoimi_encode_status")
+
+    def encode_suspect_calls(self) -> int:
+        """Encode calls of this context made with the exchange probe since the last passed LDS-order check when a repeat failed (0: never)."""
+        return int(self._lib.qoimi_encode_suspect_calls(self._h))
 
     def decode_batch(self, d_streams: int, stream_stride: int, sizes: Sequence[int], descs: Sequence[QoiDesc],
                      channels: int, d_pixels: int, pixel_stride: int, stream: int = 0) -> None:

@@ -27,7 +27,7 @@ namespace qoimi {
 #ifdef QOIMI_ENC_PHASES
 // Diagnostic build (-DQOIMI_ENC_PHASES, tools/dev/enc_phases.py): where a wavefront of enc_sets spends its life - s_memtime
 // ticks per phase of a set, summed over all wavefronts.  [0] entry state, [1] the groups inside the image, [2] groups of the general
-// form, [3] look-back, [4] copy-out, [5] sets, [6] the part of [1] in front of the first group's first step.
+// form, [3] look-back, [4] copy-out, [5] sets, [6] sets whose first poll (asked for a group ahead) did not suffice, [7] re-polls.
 __device__ unsigned long long g_enc_phase[8];
 #define PHASE_MARK(k) do { const unsigned long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_enc_phase[k], t_now - t_mark); t_mark = t_now; } while (0)
 #else
@@ -1070,8 +1070,9 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 const int stop = incl ? __builtin_ctzll(incl) : 64;       // nearest inclusive record
                 const u64 need = stop >= 64 ? ~0ull : ((1ull << stop) - 1ull);
                 if (notready & need) {                                    // a record we must add is not published yet
-                    // (first pass: a predecessor that gave the image up never publishes - the image is encoded again anyway)
-                    if (ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+                    // (first pass: a predecessor that gave the image up never publishes - the image is encoded again anyway.  Looked at
+                    // every 8th poll only: the flag is one more round trip through the fabric in front of every re-poll)
+                    if (ENTRY == 1 && (spins & 7u) == 7u && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
                     if (++spins > (1u << 22)) { if (lane == 0) atomicOr(p.err, 1u); break; }
                     __builtin_amdgcn_s_sleep(2);
                     continue;
@@ -1081,6 +1082,9 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 look -= 64u;                                              // (no inclusive record among 64: look >= 64 here)
             }
             if (lane == 0) granule_store(&st[sg], kRecIncl | (u64)(excl + set_bytes));
+#ifdef QOIMI_ENC_PHASES
+            if (lane == 0) { atomicAdd(&g_enc_phase[7], (unsigned long long)spins); if (spins) atomicAdd(&g_enc_phase[6], 1ull); }
+#endif
         }
     }
 
@@ -1094,10 +1098,16 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         out[lane] = (uint8_t)((lane < 8u ? hdr_lo : hdr_hi) >> (8u * (lane & 7u)));
     }
     const u64 pos = (u64)kHeaderBytes + (u64)excl;
+#ifdef QOIMI_EXP_NOCOPY   // timing experiment only (no stream bytes leave the wavefront)
+    if (p.n_units == 0xFFFFFFFFu)
+#endif
     if (spilled) {                                          // the part that went through the scratch slot: by this wavefront, from this CU
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         copy_global_out(slot, out + pos, spilled, lane);
     }
+#ifdef QOIMI_EXP_NOCOPY
+    if (p.n_units == 0xFFFFFFFFu)
+#endif
     if (spos) {
         __builtin_amdgcn_wave_barrier();
         copy_stage_out(L.stage, out + pos + spilled, spos, lane);
@@ -1125,9 +1135,9 @@ __global__ __launch_bounds__(256, PROBE == 1 ? (CLS == 1 ? QOIMI_ENC_WAVES_PER_S
     if (p.only_flagged && *p.any_generic == 0u) return;
 #pragma unroll 1
     for (uint32_t unit = blockIdx.x; unit < p.n_units; unit += gridDim.x) {
-        // p.spread (look-back + ticket mode only; prepared in round 3, NOT yet measured or run on a GPU): the four wavefronts of a
-        // workgroup serve four consecutive IMAGES instead of taking four consecutive tickets of one image at the same instant - those
-        // four run in lock step and each waits in its look-back for the others (what the 18 % are made of).
+        // p.spread (look-back + ticket mode; the default): the four wavefronts of a workgroup serve four consecutive IMAGES instead of
+        // taking four consecutive tickets of one image at the same instant.  An image's consecutive tickets then go to wavefronts that
+        // started at different times (1024 x 4K photographs: 12.45 -> 12.23 ms, profiles/r04_s1_enc_knobs.txt).
         // Every image still receives sets_per_image tickets' worth of wavefronts (4 n_units / n_images of them).
         const uint32_t img = (p.spread && p.use_ticket && p.lookback) ? (unit * 4u + wave) % p.n_images : unit % p.n_images;
         if (p.only_flagged && p.need_generic[img] == 0u) continue;

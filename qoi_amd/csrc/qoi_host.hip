@@ -94,10 +94,14 @@ struct qoimi_ctx {
     uint32_t* last_enc_err = nullptr;   // device flag of the most recent encode launch
     bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
     long long enc_calls = 0;            // encode calls so far: the self-test is repeated every enc_recheck_every of them
-    long long enc_calls_at_check = 0, enc_recheck_every = 256, enc_suspect_calls = 0;   // env QOIMI_ENC_RECHECK_EVERY
+    long long enc_calls_at_check = 0;   // ... as of the launch of the repeat in flight (or of the last one)
+    long long enc_calls_last_passed = 0;   // ... as of the launch of the last repeat that PASSED (0: the test at creation)
+    long long enc_recheck_every = 256, enc_suspect_calls = 0;   // env QOIMI_ENC_RECHECK_EVERY
     bool recheck_pending = false;       // a repeated self-test is in flight on own_stream, result in host_word[8]
+    bool recheck_failed_unreported = false;   // a repeat failed: the next qoimi_encode_status reports it (once)
+    bool test_force_recheck_fail = false;     // env QOIMI_TEST_FORCE_RECHECK_FAIL (tests): every repeat counts as failed
     int enc_ticket = 1, enc_set_slabs = 0, enc_warm = 1;   // tuning / test knobs (env QOIMI_ENC_*)
-    int enc_spread = 0;                 // env QOIMI_ENC_SPREAD
+    int enc_spread = 1;                 // env QOIMI_ENC_SPREAD: the wavefronts of a workgroup take their tickets from consecutive images (0: all four from one image)
     int enc_persist = 0;                // env QOIMI_ENC_PERSIST: workgroups of the first encode pass (0: one per unit)
     int enc_cls = 0;                    // env QOIMI_ENC_CLS: 0 the literal classes of a step from the vector pipe (paired 16-bit halves), 1 from the matrix
                                         // pipe (one v_mfma_i32_32x32x16_i8 per step, five wavefronts per SIMD; measured: no faster - DESIGN.md section 3)
@@ -158,6 +162,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     }
     if (const char* e = getenv("QOIMI_ENC_PROBE")) { if (atoi(e) == 0) c->xchg_ordered = false; }
     if (const char* e = getenv("QOIMI_ENC_RECHECK_EVERY")) { long v = atol(e); if (v >= 1) c->enc_recheck_every = v; }
+    if (const char* e = getenv("QOIMI_TEST_FORCE_RECHECK_FAIL")) c->test_force_recheck_fail = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_TICKET")) c->enc_ticket = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_SET_SLABS")) c->enc_set_slabs = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_DEBUG_DUMP")) c->enc_debug_dump = e;
@@ -275,12 +280,18 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     // lives on.  The repeat runs on the context's private stream; its result is looked at by the next call.
     if (c->recheck_pending && hipStreamQuery(c->own_stream) == hipSuccess) {
         c->recheck_pending = false;
-        if (c->host_word[8] != 0u) {
-            // Never observed.  The context switches to the order-free probe for good and THIS call is encoded with it (it does not
-            // fail); what cannot be undone is reported: qoimi_encode_suspect_calls() = calls since the last check that passed.
+        if (c->host_word[8] != 0u || c->test_force_recheck_fail) {
+            // Never observed.  The context switches to the order-free probe for good and THIS call is encoded with it (its own
+            // stream is sound, the call does not fail); what cannot be undone is reported: every call since the launch of the last
+            // repeat that PASSED is suspect - the ones before the failed repeat was launched and the ones made while it ran
+            // (enc_calls still excludes the call at hand) - and the next qoimi_encode_status returns QOIMI_E_INTERNAL once.
             c->xchg_ordered = false;
-            c->enc_suspect_calls += c->enc_calls - c->enc_calls_at_check;
-            t_error = "the LDS exchange-order self-test failed on repetition: streams encoded since the last passed check are suspect (qoimi_encode_suspect_calls); this context now uses the order-free probe";
+            c->enc_suspect_calls += c->enc_calls - c->enc_calls_last_passed;
+            c->enc_calls_last_passed = c->enc_calls;
+            c->recheck_failed_unreported = true;
+            (void)fail(QOIMI_E_INTERNAL, "the LDS exchange-order self-test failed on repetition: streams encoded since the last passed check are suspect (qoimi_encode_suspect_calls); this context now uses the order-free probe");
+        } else {
+            c->enc_calls_last_passed = c->enc_calls_at_check;
         }
     }
     ++c->enc_calls;
@@ -365,6 +376,11 @@ extern "C" int qoimi_encode_status(qoimi_ctx* c, void* stream) {
     if (!c) return fail(QOIMI_E_ARG, "ctx is NULL");
     DeviceGuard guard(c->device);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (c->recheck_failed_unreported) {
+        c->recheck_failed_unreported = false;
+        return fail(QOIMI_E_INTERNAL, "the LDS exchange-order self-test failed on repetition: " + std::to_string(c->enc_suspect_calls) +
+                    " earlier encode calls of this context are suspect (qoimi_encode_suspect_calls); the context now uses the order-free probe");
+    }
     if (!c->last_enc_err) return QOIMI_OK;
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, c->last_enc_err, sizeof err, hipMemcpyDeviceToHost));
@@ -632,7 +648,7 @@ class Prefaulter {
     void* ptr[kThreads] = {nullptr, nullptr};
     size_t len[kThreads] = {0, 0};
     unsigned long long ticket[kThreads] = {0, 0}, done[kThreads] = {0, 0};
-    bool started = false, quit = false;
+    bool started = false, quit = false, no_helpers = false;
     void loop(int i) {
         unsigned long long seen = 0;
         for (;;) {
@@ -652,8 +668,19 @@ public:
     // populate [p, p + n) in the background; wait() returns when it is done
     void start(void* p, size_t n) {
         if (!started) {
-            try { for (int i = 0; i < kThreads; ++i) th[i] = std::thread(&Prefaulter::loop, this, i); started = true; }
-            catch (...) { prefault_pages(p, n); return; }       // no threads to be had: populate here
+            if (no_helpers) { prefault_pages(p, n); return; }
+            int made = 0;
+            try { for (; made < kThreads; ++made) th[made] = std::thread(&Prefaulter::loop, this, made); started = true; }
+            catch (...) {
+                // no threads to be had: the ones that did start are told to quit and joined, the state stays "no helpers" for good
+                // (a second attempt would assign to a joinable std::thread), and this call populates here
+                { std::lock_guard<std::mutex> lk(mu); quit = true; }
+                cv_work.notify_all();
+                for (int i = 0; i < made; ++i) if (th[i].joinable()) th[i].join();
+                no_helpers = true;
+                prefault_pages(p, n);
+                return;
+            }
         }
         const size_t part = ((n / kThreads) + 4095u) & ~(size_t)4095u;
         std::lock_guard<std::mutex> lk(mu);

@@ -274,6 +274,9 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_CLS": "1"},                               # literal classes of a step from the matrix pipe (one v_mfma_i32_32x32x16_i8 per step)
     {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_WARM": "0"},        # ... with the entry states from the summary passes
     {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
+    {"QOIMI_ENC_SPREAD": "1"},                            # the wavefronts of a workgroup take their tickets from consecutive images
+    {"QOIMI_ENC_SPREAD": "1", "QOIMI_ENC_SET_SLABS": "2"},
+    {"QOIMI_ENC_SPREAD": "1", "QOIMI_ENC_PERSIST": "3"},  # ... in the grid-stride loop
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
@@ -501,7 +504,7 @@ def test_random_sweep_of_contents_and_shapes(api, oracle, env):
 
 
 @pytest.mark.parametrize("slabs", [1, 2, 3, 4, 5, 8])
-@pytest.mark.parametrize("lookback", ["1", "0"])
+@pytest.mark.parametrize("lookback", ["1", "0", "spread"])
 def test_set_sizes_and_placements(api, oracle, slabs, lookback):
     """A wavefront encodes a SET of R consecutive slabs (R = 1..8; the library picks it from the batch size, here it is forced) and
     places its bytes by look-back (bytes beyond the staging buffer spill through the set's scratch slot) or order-free.  Shapes
@@ -509,9 +512,10 @@ def test_set_sizes_and_placements(api, oracle, slabs, lookback):
     import torch
     from gpu_util import DeviceBatch
     from qoi_amd import synth
-    old = {k: os.environ.get(k) for k in ("QOIMI_ENC_SET_SLABS", "QOIMI_ENC_LOOKBACK")}
+    old = {k: os.environ.get(k) for k in ("QOIMI_ENC_SET_SLABS", "QOIMI_ENC_LOOKBACK", "QOIMI_ENC_SPREAD")}
     os.environ["QOIMI_ENC_SET_SLABS"] = str(slabs)
-    os.environ["QOIMI_ENC_LOOKBACK"] = lookback
+    os.environ["QOIMI_ENC_LOOKBACK"] = "1" if lookback == "spread" else lookback
+    os.environ["QOIMI_ENC_SPREAD"] = "1" if lookback == "spread" else "0"
     try:
         c = api.Context(0)
         for (w, h) in ((1400, 900), (517, 313), (64, 9), (1024, 16)):
@@ -726,3 +730,46 @@ def test_encode_batch_many_small_images(api, ctx, oracle, shape):
         want = oracle.encode(frames[i], w, h, 4)
         assert int(lens[i]) == len(want), (shape, i)
         assert b.stream_bytes(i, len(want)) == want, (shape, i)
+
+
+def test_failed_lds_order_recheck_is_counted_and_reported_once(api, oracle):
+    """The repeat of the LDS exchange-order self-test (qoi_host.hip, include/qoi_mi355x.h): forced to fail by the test hook with a
+    repeat after every call.  The call that notices is encoded with the order-independent probe and succeeds, the calls made with
+    the suspect probe since the last passed check are counted (all of them - the one made before the repeat was launched too),
+    and the next qoimi_encode_status reports the event exactly once."""
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    env = {"QOIMI_ENC_RECHECK_EVERY": "1", "QOIMI_TEST_FORCE_RECHECK_FAIL": "1"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = api.Context(0)
+        w, h = 640, 360
+        b = DeviceBatch(c, w, h, 4, 2)
+        frames = [synth.frame_rgba(k, w, h, 11 + i) for i, k in enumerate(("photo", "uiflat"))]
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        want = [oracle.encode(f, w, h, 4) for f in frames]
+        lens = b.encode()                                   # call 1: launches the first repeat
+        assert c.encode_suspect_calls() == 0
+        assert [b.stream_bytes(i, lens[i]) for i in range(2)] == want
+        import torch
+        torch.cuda.synchronize()
+        # call 2 notices the (forced) failure: it still succeeds, byte-identical, now with the order-independent probe
+        c.encode_batch(b.pixels.data_ptr(), b.pixel_stride, b.desc, b.n, b.streams.data_ptr(), b.stream_stride, b.lens.data_ptr(), b.stream)
+        assert c.encode_suspect_calls() == 1                # call 1 was made with the suspect probe
+        with pytest.raises(api.QoiError, match="self-test failed"):
+            c.encode_status(b.stream)
+        c.encode_status(b.stream)                           # reported once
+        lens = b.lens.cpu().numpy()
+        assert [b.stream_bytes(i, lens[i]) for i in range(2)] == want
+        lens = b.encode()                                   # call 3: no further repeats, nothing more to report
+        assert c.encode_suspect_calls() == 1
+        assert [b.stream_bytes(i, lens[i]) for i in range(2)] == want
+        c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

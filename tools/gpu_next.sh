@@ -9,7 +9,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out/${1:-next}; mkdir -p $OUT; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 SEL="encode or sweep or selectable or mixed or flat_frames or set_sizes or one_context or three_channel or 4k_frame or batch_1080p or many_small"
 QOIMI_ENC_SPREAD=1 timeout 250 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "$SEL" > $OUT/pytest_spread.log 2>&1; echo "rc=$?" >> $OUT/pytest_spread.log; tail -3 $OUT/pytest_spread.log
-for e in "" "QOIMI_ENC_SPREAD=1" "QOIMI_ENC_PERSIST=1536" "QOIMI_ENC_PERSIST=1280" "QOIMI_ENC_PERSIST=1024" "QOIMI_ENC_SPREAD=1 QOIMI_ENC_PERSIST=1536"; do
+for e in "" "QOIMI_ENC_SPREAD=1" "QOIMI_ENC_PERSIST=1536" "QOIMI_ENC_PERSIST=1280" "QOIMI_ENC_PERSIST=1024" "QOIMI_ENC_SPREAD=1 QOIMI_ENC_PERSIST=1536" "QOIMI_ENC_TICKET=0" "QOIMI_ENC_SPREAD=1 QOIMI_ENC_SET_SLABS=2" "QOIMI_ENC_SPREAD=1 QOIMI_ENC_SET_SLABS=4" "QOIMI_ENC_SET_SLABS=2"; do
   for f in 512 1024; do env $e python tools/dev/enc_time.py - $f 2>&1 | grep -v amdgpu.ids | sed "s/^/[$e] $f frames: /"; done
 done | tee $OUT/enc_time.txt
 if [ -f build/exp_phases/libqoi_mi355x.so ]; then
