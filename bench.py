@@ -64,20 +64,23 @@ def _latest_traffic_file() -> str:
 TRAFFIC_FILE = _latest_traffic_file()
 
 
-def measured_traffic(kernel_prefix: str, grid_threads: int, scale: float = 1.0):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
-    (tools/gpu_session.sh: separate FETCH_SIZE / WRITE_SIZE runs; the counters cannot be collected from inside
-    the process).  Returned only when the profiled launch had the same grid, i.e. the same workload; FETCH_SIZE
-    is doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibration in the file)."""
+def measured_traffic(kernel_prefix: str, scale: float = 1.0):
+    """HBM bytes per launch of the dominant kernel, EXTRAPOLATED from the latest committed rocprofv3 PMC passes of this
+    command (tools/gpu_session.sh: separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-cpu ...`; the counters cannot
+    be collected from inside the process): the per-launch figure of the kernel instantiation named in the file, scaled
+    by the frames per launch.  It is a figure of that session's build (the file names its commit where the session
+    recorded one), not of the run at hand - the source string says so.  FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md prescribes for gfx950 (calibration in the file)."""
     try:
         doc = json.load(open(TRAFFIC_FILE))
     except OSError:
         return None, None
     for name, k in doc["kernels"].items():
-        if name.startswith(kernel_prefix) and grid_threads in (k.get("grid"), -1) and "FETCH_SIZE_KB" in k and "WRITE_SIZE_KB" in k:
+        if name.startswith(kernel_prefix) and "FETCH_SIZE_KB" in k and "WRITE_SIZE_KB" in k:
             nbytes = (k["FETCH_SIZE_KB"] * doc["read_correction"] + k["WRITE_SIZE_KB"]) * 1024.0 * scale
             note = "" if scale == 1.0 else f", x {scale:g}: the PMC passes ran {doc.get('frames', '?')} frames per launch"
-            return nbytes, f"profiles/{os.path.basename(TRAFFIC_FILE)}: {name} (2 x FETCH_SIZE + WRITE_SIZE{note})"
+            return nbytes, (f"profiles/{os.path.basename(TRAFFIC_FILE)} (an earlier session's PMC passes, build {doc.get('commit', 'not recorded')}; "
+                            f"not collected in this run): {name} (2 x FETCH_SIZE + WRITE_SIZE{note})")
     return None, None
 
 
@@ -311,11 +314,33 @@ def main() -> None:
     sizes = [int(x) for x in lens[:F].cpu().numpy()]
     descs = [desc] * F
 
+    # Strong scaling with more frames per rank than fit at once: every pass codes DIFFERENT frames - the resident buffer is refilled
+    # with the pass's frame ids (synthetic frames are made on the device) and the stream lengths are read back after the encode,
+    # as a real pipeline would.  Both happen inside the timed region and count against `value`; the refill's device time is
+    # measured with events on the stream and reported beside it (`synth_ms_per_step`, `value_excluding_synth`).
+    regen = strong and passes > 1
+    synth_events = []
+    bytes_coded = [0.0]                # stream bytes of the passes run so far (regen: lengths differ from pass to pass)
+
     def step():
-        for _ in range(passes):        # strong scaling: the rank's share in passes over the resident frames
-            ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+        nonlocal sizes
+        for ps in range(passes):       # strong scaling: the rank's share in passes over the resident frames
+            n_now = F
+            if regen:
+                lo = first_frame + ps * F
+                n_now = min(F, mine.stop - lo)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ctx.synth_frames(synth.KIND_ID[args.kind], synth.DEFAULT_SEED, lo, n_now, w, h, pixels.data_ptr(), pstride, stream)
+                e1.record()
+                synth_events.append((e0, e1))
+            ctx.encode_batch(pixels.data_ptr(), pstride, desc, n_now, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+            if regen:
+                ctx.encode_status(stream)
+                sizes = [int(x) for x in lens[:n_now].cpu().numpy()]
+                bytes_coded[0] += float(sum(sizes))
             if not args.encode_only:
-                ctx.decode_batch(streams.data_ptr(), sstride, sizes, descs, 4, decoded.data_ptr(), pstride, stream)
+                ctx.decode_batch(streams.data_ptr(), sstride, sizes[:n_now], descs[:n_now], 4, decoded.data_ptr(), pstride, stream)
 
     def barrier():
         qdist.barrier()
@@ -324,23 +349,26 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     ctx.set_profiling(True)
+    synth_events.clear(); bytes_coded[0] = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    synth_ms = sum(a.elapsed_time(b) for a, b in synth_events)
+    n_last = (mine.stop - (first_frame + (passes - 1) * F)) if regen else F        # frames of the pass that ran last (resident now)
     prof = ctx.get_profile(stream)
     ctx.set_profiling(False)
     ctx.encode_status(stream)
     launches = args.steps * passes
 
     # bit-exact round trip (qoibench.c:408-417) on the whole batch, and four of its streams against the reference codec
-    ok = args.encode_only or equal_batches(torch, decoded, pixels, F, pstride, npx * 4)
+    ok = args.encode_only or equal_batches(torch, decoded, pixels, n_last, pstride, npx * 4)
     dstats = ctx.decode_stats()
     refcheck = None
     if rank == 0 and not args.encode_only:
-        refcheck = check_against_reference(torch, pixels, pstride, streams, sstride, sizes, w, h, sorted({0, 1, F // 2, F - 1}))
+        refcheck = check_against_reference(torch, pixels, pstride, streams, sstride, sizes, w, h, sorted({0, min(1, n_last - 1), n_last // 2, n_last - 1}))
         ok = ok and refcheck["streams_byte_identical"] and refcheck["reference_decoder_round_trips"]
 
     def timed(fn, reps):
@@ -488,9 +516,13 @@ def main() -> None:
                                               "unit": "GB/s", "frac": round(n3 * 4 / dte / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": n3 * 4, "ms_per_launch": round(dte * 1e3, 3)}}
 
     # RCCL: counters only (max elapsed; summed pixels / stream bytes / verified ranks)
-    my_frames = range(first_frame, first_frame + (len(mine) if strong else F))       # synthetic frame ids this rank coded
-    elapsed, (total_px, total_stream_bytes, n_ok, frames_coded, frame_id_sum) = qdist.reduce_counters(
-        elapsed, [float(F * npx * launches), float(sum(sizes)) * launches, float(ok), float(len(my_frames)), float(sum(my_frames))], cdev)
+    # synthetic frame ids this rank coded in a step: its whole share when every pass refills the buffer, else the resident frames
+    # (passes > 1 always refills; with one pass the resident frames ARE the share)
+    my_frames = range(first_frame, first_frame + (len(mine) if strong else F))
+    px_coded = float(len(my_frames) * npx * args.steps) if regen else float(F * npx * launches)
+    st_coded = bytes_coded[0] if regen else float(sum(sizes)) * launches
+    elapsed, (total_px, total_stream_bytes, n_ok, frames_coded, frame_id_sum, synth_ms_max) = qdist.reduce_counters(
+        elapsed, [px_coded, st_coded, float(ok), float(len(my_frames)), float(sum(my_frames)), float(synth_ms)], cdev)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -503,7 +535,8 @@ def main() -> None:
         slabs_calls = prof["enc_slabs"][1]
         slabs_ms = sum(prof[k][0] for k in ("enc_slabs", "enc_slabs_generic", "enc_slab_summary", "enc_scan_groups", "enc_scan_images") if k in prof)
         per_launch_ms = slabs_ms / max(1, slabs_calls)
-        alg_bytes = F * npx * 4                           # 4 B read per pixel
+        frames_per_launch = len(my_frames) / passes if regen else F
+        alg_bytes = frames_per_launch * npx * 4           # 4 B read per pixel
         stream_bytes = total_stream_bytes / max(1, launches) / world          # per launch of this rank
         gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         achieved = gbs(alg_bytes, per_launch_ms)
@@ -522,7 +555,7 @@ def main() -> None:
                 f_prof = float(json.load(open(TRAFFIC_FILE)).get("frames", F))
             except (OSError, ValueError):
                 f_prof = float(F)
-            traffic, traffic_src = measured_traffic("qoimi::enc_sets<4, 1, 1", -1, F / f_prof)   # (any CLS instantiation: the committed passes name one)
+            traffic, traffic_src = measured_traffic("qoimi::enc_sets<4, 1, 1", frames_per_launch / f_prof)
         roof = lambda kernel, nbytes, ms, **kw: dict({"bound": "hbm", "kernel": kernel, "achieved": round(gbs(nbytes, ms), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                       "frac": round(gbs(nbytes, ms) / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 4)}, **kw)
         out = {
@@ -535,15 +568,16 @@ def main() -> None:
                                     f"BASELINE configs[4] strong scaling: {args.total_frames} x {w}x{h} RGBA frames in total, {args.total_frames // world} per GPU per step "
                                     f"in {passes} pass(es) over {F} resident frames") +
                                    f", encode + decode, content={args.kind}, HBM-resident, bit-exact round trip verified",
-                       "frames_per_gpu": F * passes, "frames_resident": F, "width": w, "height": h, "content": args.kind,
+                       "frames_per_gpu": len(my_frames), "frames_resident": F, "passes_per_step": passes, "width": w, "height": h, "content": args.kind,
                        "stream_bytes_per_px": round(total_stream_bytes / total_px, 4), "parallelism": f"frames sharded x{world}"},
             "verified_bit_exact": n_ok == world, "reference_check": refcheck,
+            "distinct_frames_per_step": "every pass refills the resident buffer with its own frame ids (refill and stream-length read-back inside the timed region)" if regen
+                                        else "the resident frames (one pass per step)",
             "counter_backend": args.counter_backend, "frames_coded_all_ranks": int(frames_coded), "frame_id_sum_all_ranks": int(frame_id_sum),
             "encode_mpps_kernels": round(F * npx * launches / (enc_ms * 1e3), 1) if enc_ms else None,
             "decode_mpps_kernels": round(F * npx * launches / (dec_ms * 1e3), 1) if dec_ms else None,
             "decode_rounds": dstats["rounds"], "decode_redo_segments": dstats["redo_segments"], "decode_sync_fallback_segments": dstats.get("sync_fallback_segments"),
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
-            "encoder_classes": "matrix pipe (one v_mfma_i32_32x32x16_i8 per step; experimental)" if os.environ.get("QOIMI_ENC_CLS") == "1" else "vector pipe (paired 16-bit halves)",
             "roofline": roof("enc_sets (+ entry-state passes)", alg_bytes, per_launch_ms, traffic=traffic, traffic_source=traffic_src,
                              note="the kernel of the north star's 4K-encode roofline target; the kernel with the largest share of the step is in roofline_dominant"),
         }
@@ -569,6 +603,17 @@ def main() -> None:
             # the whole step against SURVEY.md 8d's bytes for encode + decode (pixels read, stream written and read back, pixels written)
             out["roofline_step"] = roof("whole step: qoimi_encode_batch + qoimi_decode_batch (wall clock)", 2 * alg_bytes + 2 * stream_bytes, ms_step / max(1, passes),
                                         note="SURVEY.md 8d: 4 B read per pixel + stream bytes written (encode), stream bytes read + 4 B written per pixel (decode)")
+        if regen:
+            sm = synth_ms_max / world                         # mean over the ranks (they refill the same number of frames)
+            out["synth_ms_per_step"] = round(sm / args.steps, 3)
+            out["value_excluding_synth"] = round(total_px / max(1e-9, elapsed - sm * 1e-3) / 1e6, 1)
+        # device memory: what the context's arenas hold now (they only grow) and what the process has taken from the device
+        ws = ctx.workspace_bytes()
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        out["device_memory"] = {"encode_workspace_bytes": ws["encode"], "decode_workspace_bytes": ws["decode"], "dropin_staging_bytes": ws["staging"],
+                                "bench_buffers_bytes": int(pixels.numel() + streams.numel() + decoded.numel()),
+                                "peak_device_bytes": int(total_b - free_b), "device_total_bytes": int(total_b),
+                                "note": "peak_device_bytes = device total - free at the end of the run (all processes on the device; the library's arenas and torch's caching allocator only grow)"}
         out["scaling_note"] = ("single GPU" if world == 1 else f"{world} ranks") + "; no multi-GPU scaling curve has been measured for this repository (gpurun exposes one GPU) - the driver computes efficiency from its own per-N runs"
         if single:
             out["single_frame"] = single

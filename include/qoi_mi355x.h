@@ -148,6 +148,10 @@ int qoimi_synth_frames(qoimi_ctx *ctx, int kind, unsigned seed, unsigned first_f
                        int n_frames, unsigned width, unsigned height,
                        void *d_pixels, size_t pixel_stride, void *stream);
 
+/* Device memory the context's growable arenas hold at the moment (bytes): [0] encode workspace, [1] decode workspace,
+ * [2] staging buffers of the host-pointer entry points (qoi_encode / qoi_decode of the calling thread's context). */
+void qoimi_workspace_bytes(qoimi_ctx *ctx, size_t out[3]);
+
 /* Counters of the last decode on this context: [0] speculation rounds, [1] segments
  * re-decoded after a failed check, [2] total segments, [3] segments whose entry position
  * needed the full five-phase parse (look-back synchronisation did not settle). */

@@ -24,7 +24,8 @@ QOI_SRGB = 0
 QOI_LINEAR = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqoi_mi355x.so")
+# (QOIMI_LIB: another build of the library - the experimental builds of tools/dev/build_exp.sh under build/; tests and tools only)
+LIB_PATH = os.path.abspath(os.environ["QOIMI_LIB"]) if os.environ.get("QOIMI_LIB") else os.path.join(_HERE, "lib", "libqoi_mi355x.so")
 
 EXPORTS = (
     # Part 1 — drop-in symbols (qoi.h:252,265,278,289)
@@ -33,7 +34,7 @@ EXPORTS = (
     "qoimi_ctx_create", "qoimi_ctx_destroy", "qoimi_last_error", "qoimi_encode_bound",
     "qoimi_encode_batch", "qoimi_encode_status", "qoimi_decode_batch", "qoimi_synth_frames",
     "qoimi_decode_stats", "qoimi_version", "qoimi_set_profiling", "qoimi_get_profile", "qoimi_kernel_name",
-    "qoimi_encode_suspect_calls",
+    "qoimi_encode_suspect_calls", "qoimi_workspace_bytes",
 )
 
 
@@ -97,6 +98,8 @@ def load_library() -> ctypes.CDLL:
     lib.qoimi_get_profile.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), ci]
     lib.qoimi_kernel_name.restype = ctypes.c_char_p
     lib.qoimi_kernel_name.argtypes = [ci]
+    lib.qoimi_workspace_bytes.restype = None
+    lib.qoimi_workspace_bytes.argtypes = [vp, ctypes.POINTER(sz)]
     lib.qoimi_encode_suspect_calls.restype = ctypes.c_longlong
     lib.qoimi_encode_suspect_calls.argtypes = [vp]
     _lib = lib
@@ -252,6 +255,12 @@ class Context:
         calls = (ctypes.c_longlong * 64)()
         n = min(64, self._lib.qoimi_get_profile(self._h, stream, ms, calls, 64))
         return {self._lib.qoimi_kernel_name(i).decode(): (ms[i], calls[i]) for i in range(1, n)}
+
+    def workspace_bytes(self) -> dict:
+        """Device bytes the context's arenas hold: encode workspace, decode workspace, staging of the host-pointer entry points."""
+        out = (ctypes.c_size_t * 3)()
+        self._lib.qoimi_workspace_bytes(self._h, out)
+        return {"encode": int(out[0]), "decode": int(out[1]), "staging": int(out[2])}
 
     def decode_stats(self) -> dict:
         out = (ctypes.c_longlong * 4)()

@@ -210,7 +210,8 @@ __global__ __launch_bounds__(64) void enc_scan_images(EncParams p) {
 //   * chunk words keep byte 0 in bits 0..7 and byte 1 in bits 16..23 (ds_write_b8 /
 //     ds_write_b8_d16_hi take them from there); two-byte words are the negative ones, 0x40000000 marks a long chunk;
 //   * the DIFF / LUMA classification of an edge pixel is worked out for two consecutive steps at once in the 16-bit
-//     halves of the registers (classify_pair);
+//     halves of the registers (classify_pair; byte/integer work only - a matrix-pipe form of it was measured in round 3 and
+//     removed: 19 % fewer vector instructions, no faster, EXPERIMENTS.md);
 //   * work that a step does not need is skipped by wave-uniform branches (no edges: no
 //     hash/probe/deltas; no 4/5-byte chunk: no third offset count).
 // Chunk bytes go to a per-wave LDS staging buffer; when the set is done its byte offset in the
@@ -227,7 +228,6 @@ constexpr uint32_t kGroupPx = 64u * kGroupSteps;
 #define QOIMI_ENC_WAVES_PER_SIMD 6
 #endif
 constexpr uint32_t kStageBytes = QOIMI_ENC_STAGE_BYTES; // staging buffer of a wavefront (6 workgroups of 4 per CU: 4 x 6656 x 6 = 156 KB of LDS)
-constexpr uint32_t kStageBytesBig = 7616;              // ... of the matrix-pipe form (CLS 1, five wavefronts per SIMD): 5 x 4 x 7936 = 155 KB
 
 template <int PROBE, uint32_t STAGE>
 struct EncLds {
@@ -238,7 +238,7 @@ struct EncLds {
     u64 mask[PROBE == 0 ? 64 : 1];     // PROBE 0 only
 };
 
-template <int PROBE, int CLS> using EncLdsFor = EncLds<PROBE, CLS == 1 ? kStageBytesBig : kStageBytes>;
+template <int PROBE> using EncLdsFor = EncLds<PROBE, kStageBytes>;
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -439,105 +439,6 @@ __device__ __forceinline__ uint32_t literal_word(const PairClass& K, uint32_t px
     return we;
 }
 
-// ---- the literal classes of one step from the MATRIX pipe (CLS 1; selectable, NOT the default: measured no faster) ----------
-// Every quantity the classification of qoi.h:438-474 needs is an integer-linear form of the eight bytes (previous pixel, pixel)
-// a lane holds, taken modulo 256: the wrapped channel deltas plus their range-test bias, the 4 x QOI_COLOR_HASH slot offset
-// (qoi.h:322), and - where the range tests hold - the QOI_OP_DIFF byte 0x40 | (vr+2) << 4 | (vg+2) << 2 | (vb+2) =
-// 16 vr + 4 vg + vb + 106 and the QOI_OP_LUMA bytes 0x80 | (vg+32) = vg + 160 and (vg_r+8) << 4 | (vg_b+8) = 16 vr - 17 vg + vb + 136.
-// The kernel is bound by its VECTOR instruction count while the matrix pipe of the SIMD idles, so these byte dot products go
-// there: v_mfma_i32_32x32x16_i8 takes eight bytes per lane as its B operand - exactly the (previous pixel, pixel) register pair
-// of the step - and hands every lane sixteen rows of a 32 x 16 coefficient matrix times those bytes.  Output lane l holds rows
-// 8 q + 4 (l / 32) + r (q, r = 0..3) of column l % 32, and the K range of lane half l / 32 is that half's own eight bytes: with
-// the coefficient matrix block-diagonal (row i non-zero only in the K range of half (i / 4) % 2) a lane's sixteen results are
-// sixteen linear forms of ITS OWN eight bytes (ten are used).  No contraction across pixels takes place - the matrix pipe serves
-// as a byte dot-product unit with constant coefficients.  The instruction reads the bytes as SIGNED: every form is only used modulo
-// 256 (its low byte, or bits 2..7 of it), where signed and unsigned readings agree (256 c = 0 mod 256).  The constant terms of
-// the forms ride on the alpha byte of the previous pixel, which no form needs: it is overwritten with 0xFF (= -1) before the pair
-// goes to the matrix pipe (the alpha comparison of qoi.h:468 is made first).
-// What a matrix instruction costs a vector-bound wavefront was measured first (tools/ubench/mfma_mix.hip):
-// ONE such instruction per step whose results are read 16+ vector instructions later costs ~1.3 issue slots; three shorter ones
-// back to back with their results read eight instructions later - the first form of this experiment - cost 9-14 (a matrix
-// instruction that finds the pipe busy, or a read that finds its result not ready, holds the SIMD's vector issue port).  So the
-// step asks for the NEXT step's forms when it has consumed its own (software pipeline of depth one, a single set of result
-// registers), and 10 vector instructions per step remain of "deltas, tests, words, hash" (21 in the vector-pipe form): 40.1
-// vector instructions per 64 pixels instead of 49.4 (SQ counters, profiles/r03_s7_sq_counters_encode_cls.txt).  The kernel is
-// no faster for it (1024 4K photographs: 12.80 ms against 12.48): with fewer vector instructions the wavefronts spend a larger
-// share of their time in s_waitcnt, and five wavefronts per SIMD (16 result registers) hide less of it than six.
-typedef int v16i32 __attribute__((ext_vector_type(16)));
-struct MatConst { long a; };   // this lane's piece of the coefficient matrix (A operand)
-struct StepClass {
-    v16i32 d;                  // rows 0..3: vr + 2, vg + 2, vb + 2 (QOI_OP_DIFF iff all three < 4 mod 256, qoi.h:446-453), 4 * hash;
-                               // 4, 5: vg_r + 8, vg_b + 8 (qoi.h:455-459); 8..11: LUMA byte 0, LUMA byte 1, DIFF byte, vg + 32
-    u64 alpha_moved;           // lanes whose alpha differs from the previous pixel's (qoi.h:468), taken before the alpha byte is overwritten
-};
-__device__ __forceinline__ uint32_t coef4(int c0, int c1, int c2, int c3) {
-    return (uint32_t)(c0 & 0xFF) | ((uint32_t)(c1 & 0xFF) << 8) | ((uint32_t)(c2 & 0xFF) << 16) | ((uint32_t)(c3 & 0xFF) << 24);
-}
-// a row over (previous pixel r g b, the constant -1, pixel r g b a) with constant term `bias`
-__device__ __forceinline__ long coef_row(int pr, int pg, int pb, int bias, int r, int g, int b, int a) {
-    return (long)(((u64)coef4(r, g, b, a) << 32) | (u64)coef4(pr, pg, pb, -bias));
-}
-__device__ __forceinline__ void mat_const_init(MatConst& M, uint32_t lane) {
-    // A operand of lane l: row l % 32 of the matrix, K range l / 32.  Non-zero only where (row / 4) % 2 == l / 32 (block diagonal);
-    // such a row is form number 4 (row / 8) + row % 4 of the lanes that read it.
-    const uint32_t row = lane & 31u, half = lane >> 5;
-    const bool on = ((row >> 2) & 1u) == half;
-    const uint32_t f = 4u * (row >> 3) + (row & 3u);
-    long c = 0l;
-    switch (f) {
-    case 0:  c = coef_row(-1, 0, 0, 2, 1, 0, 0, 0); break;            // vr + 2
-    case 1:  c = coef_row(0, -1, 0, 2, 0, 1, 0, 0); break;            // vg + 2
-    case 2:  c = coef_row(0, 0, -1, 2, 0, 0, 1, 0); break;            // vb + 2
-    case 3:  c = coef_row(0, 0, 0, 0, 12, 20, 28, 44); break;         // 4 * (3 r + 5 g + 7 b + 11 a)
-    case 4:  c = coef_row(-1, 1, 0, 8, 1, -1, 0, 0); break;           // vr - vg + 8
-    case 5:  c = coef_row(0, 1, -1, 8, 0, -1, 1, 0); break;           // vb - vg + 8
-    case 8:  c = coef_row(0, -1, 0, 160 - 256, 0, 1, 0, 0); break;    // vg + 160                (mod 256)
-    case 9:  c = coef_row(-16, 17, -1, 136 - 256, 16, -17, 1, 0); break;   // 16 vr - 17 vg + vb + 136   (mod 256)
-    case 10: c = coef_row(-16, -4, -1, 106, 16, 4, 1, 0); break;      // 16 vr + 4 vg + vb + 106
-    case 11: c = coef_row(0, -1, 0, 32, 0, 1, 0, 0); break;           // vg + 32
-    default: break;
-    }
-    M.a = on ? c : 0l;
-    asm volatile("" : "+v"(M.a));     // materialised once, not re-derived per step
-}
-// Asks the matrix pipe for the forms of (prev, px).
-__device__ __forceinline__ void mat_classify(StepClass& S, const MatConst& M, uint32_t px, uint32_t prev) {
-    asm("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3" : "=s"(S.alpha_moved) : "v"(px), "v"(prev));
-    // r, g, b as they are, 0xFF on top.  (Through the builtin, not inline assembly: the compiler has to see which instruction
-    // writes the register the matrix instruction reads - it keeps the distance the hardware asks for between the two; an
-    // assembly block in front of it made the matrix pipe read the register as it was BEFORE the write.)
-    const uint32_t pm = __builtin_amdgcn_perm(prev, prev, 0x0D020100u);
-    const long b = (long)(((u64)px << 32) | (u64)pm);                     // the register pair as loaded
-#ifdef QOIMI_EXP_NOMFMA   // timing experiment only (wrong bytes): the step without its matrix instruction
-    S.d = (v16i32)((int)(px ^ pm ^ (uint32_t)M.a));
-#else
-    S.d = __builtin_amdgcn_mfma_i32_32x32x16_i8(M.a, b, (v16i32)(0), 0, 0, 0);
-#endif
-}
-// The literal chunk word from those forms (the same word literal_word<HALF> makes from the packed halves): the tests read the
-// low bytes through SDWA selects.
-__device__ __forceinline__ uint32_t range_word_diff(const StepClass& S) { return (uint32_t)S.d[0] | (uint32_t)S.d[1] | (uint32_t)S.d[2]; }     // DIFF iff low byte < 4
-__device__ __forceinline__ uint32_t range_word_luma(const StepClass& S) {                                                                      // LUMA iff low byte < 16
-    return __builtin_amdgcn_ubfe((uint32_t)S.d[11], 2u, 6u) | (uint32_t)S.d[4] | (uint32_t)S.d[5];                                             // (vg + 32 < 64, the others < 16)
-}
-__device__ __forceinline__ uint32_t literal_word_mat(const StepClass& S, uint32_t od, uint32_t ol) {
-    uint32_t we;
-    u64 s_luma;
-    asm("v_cmp_gt_u32_sdwa %1, %2, %4 src0_sel:DWORD src1_sel:BYTE_0\n\t"
-        "v_cmp_gt_u32_sdwa vcc, %3, %5 src0_sel:DWORD src1_sel:BYTE_0\n\t"
-        "v_perm_b32 %0, %7, %6, %8\n\t"
-        "s_nop 0\n\t"
-        "v_cndmask_b32 %0, 2.0, %0, %1\n\t"
-        "v_cndmask_b32_sdwa %0, %0, %9, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-        "v_cndmask_b32 %0, %0, 2.0, %10"
-        : "=&v"(we), "=&s"(s_luma)
-        : "s"(16u), "s"(4u), "v"(ol), "v"(od), "v"((uint32_t)S.d[8]), "v"((uint32_t)S.d[9]), "s"(0x0D040C00u), "v"((uint32_t)S.d[10]), "s"(S.alpha_moved),
-          // (the six rows that carry nothing stay allocated up to here: handed out as temporaries right behind the instruction
-          // that writes them, they make the wavefront wait for it at once)
-          "v"(S.d[6]), "v"(S.d[7]), "v"(S.d[12]), "v"(S.d[13]), "v"(S.d[14]), "v"(S.d[15]) : "vcc");
-    return we;
-}
-
 // per-lane constants of the step
 struct LaneConst {
     uint32_t below_lo, below_hi;   // masks of the lanes below this one
@@ -550,12 +451,8 @@ struct LaneConst {
 // pixel after lane 63 is an edge.  GEN only: V valid lanes, lastbit the lane of the image's last pixel.
 // ccp (scalar) = 63 + (first pixel of the step - last edge before the step): stands in for clz(edges below the lane).
 // vbase (same value in every lane): LDS address of the next staged byte.
-// CLS 0: the literal classes come from classify_pair (K, vector pipe); CLS 1: from the matrix pipe (S holds this step's forms
-// on entry; once they are consumed the step asks for the forms of the NEXT step - next_px / next_pv, edges next_E - into the same
-// registers; compiled for five wavefronts per SIMD instead of six, with a larger staging buffer).
-template <int PROBE, bool GEN, int HALF, int CLS, class LDS>
-__device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const MatConst& M, uint32_t lane, uint32_t px, uint32_t prev, const PairClass& K,
-                                            StepClass& S, bool has_next, u64 next_E, uint32_t next_px, uint32_t next_pv,
+template <int PROBE, bool GEN, int HALF, class LDS>
+__device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, uint32_t lane, uint32_t px, uint32_t prev, const PairClass& K,
                                             u64 Ec, u64 nb63, u64 V, u64 lastbit, uint32_t& ccp, uint32_t& vbase) {
         const u64 En = (Ec >> 1) | nb63 | lastbit;             // lanes whose successor is an edge (or that end the image)
     const u64 NE = GEN ? (~Ec & V) : ~Ec;                  // repeat pixels
@@ -583,11 +480,8 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const Ma
     if (Ec) {
         ccp = clz64_plus64(Ec);
         // ---- colour-table probe/update (qoi.h:430-436) for edge pixels ---------------------
-        // 4 * QOI_COLOR_HASH (qoi.h:322); CLS 1: the same modulo 256 (only bits 2..7 are looked at)
-        const uint32_t hsh = CLS != 0 ? (uint32_t)S.d[3] : __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);
+        const uint32_t hsh = __builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false);      // 4 * QOI_COLOR_HASH (qoi.h:322)
         uint32_t seen = ~px;
-        uint32_t od = 0u, ol = 0u;
-        if (CLS != 0) { od = range_word_diff(S); ol = range_word_luma(S); }
         if (PROBE == 1) {
             seen = GEN ? probe_swap((hsh & 0xFCu) | C.tbase, px, Ec) : probe_swap_all((hsh & 0xFCu) | C.tbase, px);
         } else {
@@ -608,9 +502,7 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const Ma
         }
         // ---- chunk of an edge pixel (qoi.h:432-474): INDEX, else RGBA if alpha moved, else DIFF, LUMA, RGB ----
         u64 m_ad;                                          // lanes whose alpha differs from the previous pixel's
-        uint32_t we;
-        if (CLS != 0) { we = literal_word_mat(S, od, ol); m_ad = S.alpha_moved; }
-        else we = literal_word<HALF>(K, px, prev, m_ad);
+        const uint32_t we = literal_word<HALF>(K, px, prev, m_ad);
         // QOI_OP_INDEX (qoi.h:432-434) where the slot held the pixel; the edge lanes take their chunk word, the others keep
         // their run byte (one v_cndmask under exec = edges instead of two)
         select_edge_word(w, we, (hsh >> 2) & 63u, seen, px, Ec);
@@ -629,9 +521,6 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, const Ma
             any = 0ull;                                            // nothing left for the tail below
         }
     }
-    // (this step's forms are consumed: the matrix pipe works on the next step's while the offsets below and the run lengths of
-    // the next step are worked out)
-    if (CLS != 0 && has_next && next_E != 0ull) mat_classify(S, M, next_px, next_pv);
     // ---- common case: chunk lengths 1 and 2 only.  offset = #chunks below + #LUMA chunks below ----
     {
         const u64 two = __ballot(word_is_two(w)) & any;
@@ -648,16 +537,12 @@ __device__ __forceinline__ u64 lanes_upto(int r) { return r >= 64 ? ~0ull : (r <
 // E: edges of the group's first step on entry, of the first step AFTER the group on exit (from nx_px / nx_pv: the first
 // step of the next group, or the two pixels around the end of the set).  GEN: rem = pixels of the image left at the
 // group's first pixel.
-template <int PROBE, bool GEN, int CLS, class LDS>
-__device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, const MatConst& M, uint32_t lane,
+template <int PROBE, bool GEN, class LDS>
+__device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, uint32_t lane,
                                               const uint32_t (&px)[kGroupSteps], const uint32_t (&pv)[kGroupSteps],
                                               uint32_t nx_px, uint32_t nx_pv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase) {
     if (GEN) E &= lanes_upto(rem);                         // (the group before this one does not know where the image ends)
     PairClass K = {0u, 0u, 0u, 0u, 0u};
-    // CLS 1: the forms of the step at hand (only looked at under the condition they were asked for under: no value for the
-    // other case).  The group's first step asks for its own, every step then for the next one's.
-    StepClass S;
-    if (CLS != 0 && E != 0ull) mat_classify(S, M, px[0], pv[0]);
 #pragma unroll
     for (int t = 0; t < kGroupSteps; ++t) {
         const u64 Ec = E;
@@ -672,13 +557,10 @@ __device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, const 
         else E = __ballot(nx_px != nx_pv);
         if (GEN) E &= lanes_upto(rem - (t + 1) * 64);
         const u64 nb63 = E << 63;
-        if (CLS == 0 && (t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);   // this step and the next one
+        if ((t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);   // this step and the next one
         if (GEN && V == 0ull) continue;
-        constexpr int kLast = kGroupSteps - 1;
-        const bool has_next = t < kLast;
-        const int tn = t < kLast ? t + 1 : t;                  // (the last step asks for nothing: the next group's first step does that itself)
-        if (t & 1) encode_step<PROBE, GEN, 1, CLS>(L, C, M, lane, px[t], pv[t], K, S, has_next, E, px[tn], pv[tn], Ec, nb63, V, lastbit, ccp, vbase);
-        else encode_step<PROBE, GEN, 0, CLS>(L, C, M, lane, px[t], pv[t], K, S, has_next, E, px[tn], pv[tn], Ec, nb63, V, lastbit, ccp, vbase);
+        if (t & 1) encode_step<PROBE, GEN, 1>(L, C, lane, px[t], pv[t], K, Ec, nb63, V, lastbit, ccp, vbase);
+        else encode_step<PROBE, GEN, 0>(L, C, lane, px[t], pv[t], K, Ec, nb63, V, lastbit, ccp, vbase);
     }
 }
 
@@ -708,39 +590,6 @@ __device__ __forceinline__ void load_group(const uint8_t* __restrict__ pix, uint
 #pragma unroll
     for (int t = 0; t < kGroupSteps; ++t) load_pair_at<CH>(q, t * 64, px[t], pv[t]);
 }
-// ---- the same with a ROLLING register ring (CLS 1) ---------------------------------------------------------------------
-// The two-group form above keeps 32 registers of pixels: the group at hand and the whole next one, asked for when the group
-// begins.  The matrix-pipe form needs 16 registers for its results; with the two-group ring the compiler paid for them with
-// scratch spills around the loop whose reloads - each one a wait for EVERY load in flight, ~500 quad-cycles of s_waitcnt per
-// reload - cost far more than the matrix pipe saves.  Here a step's two registers are refilled with the
-// same step of the NEXT group as soon as the step is through: every load is still asked for eight steps ahead of its use, in
-// 16 registers instead of 32, and the last step of a group can ask the matrix pipe for the next group's first step like any
-// other.  (The vector-pipe form gains nothing from the ring: 71 registers instead of 78, 6.45 against 6.38 ms per 512 frames,
-// and a seventh wavefront per SIMD with the registers it frees - 5.3 KB of staging, two slabs per set - 6.68.)
-// q: this lane's pixel of the group's first step.  MORE: another interior group follows (its pixels are asked for here); else
-// end_px / end_pv are the two pixels around the end of the group (only "is the next pixel an edge" is taken from them).
-template <int CH, int PROBE, int CLS, bool MORE, class LDS>
-__device__ __forceinline__ void process_group_roll(LDS& L, const LaneConst& C, const MatConst& M, uint32_t lane,
-                                                   uint32_t (&px)[kGroupSteps], uint32_t (&pv)[kGroupSteps], const uint8_t* __restrict__ q,
-                                                   uint32_t end_px, uint32_t end_pv, StepClass& S, u64& E, uint32_t& ccp, uint32_t& vbase) {
-    PairClass K = {0u, 0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int t = 0; t < kGroupSteps; ++t) {
-        const u64 Ec = E;
-        // edges of the next step (its lane 0 tells lane 63 whether its run ends here); px[0] / pv[0] already hold the next group's
-        if (t + 1 < kGroupSteps) E = __ballot(px[t + 1] != pv[t + 1]);
-        else E = MORE ? __ballot(px[0] != pv[0]) : __ballot(end_px != end_pv);
-        const u64 nb63 = E << 63;
-        if (CLS == 0 && (t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);
-        const bool has_next = MORE || t + 1 < kGroupSteps;
-        constexpr int kMask = kGroupSteps - 1;
-        const int tn = (t + 1) & kMask;
-        if (t & 1) encode_step<PROBE, false, 1, CLS>(L, C, M, lane, px[t], pv[t], K, S, has_next, E, px[tn], pv[tn], Ec, nb63, ~0ull, 0ull, ccp, vbase);
-        else encode_step<PROBE, false, 0, CLS>(L, C, M, lane, px[t], pv[t], K, S, has_next, E, px[tn], pv[tn], Ec, nb63, ~0ull, 0ull, ccp, vbase);
-        if (MORE) load_pair_at<CH>(q, (kGroupSteps + t) * 64, px[t], pv[t]);      // this step's registers: the same step of the next group
-    }
-}
-
 // pixel i and the one before it, any i: lanes beyond the image's last pixel get 0, the pixel before the image's first one is
 // the start value of qoi.h:396-399
 template <int CH>
@@ -892,7 +741,7 @@ __device__ __forceinline__ uint32_t spill_stage(LDS& L, uint8_t* __restrict__ sl
     return spos & 15u;
 }
 
-template <int CH, int PROBE, int ENTRY, int CLS, class LDS>
+template <int CH, int PROBE, int ENTRY, class LDS>
 __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, LDS& L) {
     const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
     const uint32_t n = p.npx;
@@ -907,6 +756,10 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 #endif
 
     // ---- loads: what the entry state needs first, then the first group of pixels ------------------------------
+    // The vector issue of a SIMD goes to the highest priority, then to the OLDEST wavefront (MI355X_MICROARCH.md): a set that has
+    // just started loses every arbitration and its first loads go out late.  Raised priority up to the end of the entry state - a few
+    // dozen instructions - costs the older wavefronts next to nothing (1024 x 4K photographs: 12.56 -> 12.40 ms, profiles/r04_s3_*).
+    __builtin_amdgcn_s_setprio(2);
     SetIn in;
     if (ENTRY == 1) {
         if (lo != 0u) {                                        // (a set begins on a slab boundary: lo >= 1024, all of these lie inside the image)
@@ -938,8 +791,6 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     C.lane_run = lane + 128u;
     C.tbase = lds_addr(L.table);                               // 256-byte aligned
     asm volatile("" : "+v"(C.tbase));                          // keep in a VGPR
-    MatConst M = {0l};
-    if (CLS != 0) mat_const_init(M, lane);
     int last_edge;
     if (ENTRY == 1) {
         if (!warm_entry_state<CH, PROBE>(pix, lo, lane, L, C.tbase, in, last_edge)) {
@@ -954,6 +805,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     if (PROBE == 0) L.mask[lane] = 0;
     uint32_t ccp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(63u + (uint32_t)((int)lo - last_edge)));
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_setprio(0);
     PHASE_MARK(0);
 
     const uint32_t sbase = lds_addr(L.stage);
@@ -973,28 +825,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     };
 
     uint32_t g = 0;
-    if (CLS != 0 && nint) {
-        // ---- rolling ring (process_group_roll): a* holds the eight steps at hand, each refilled for the next group as it is used up ----
-        u64 E = __ballot(ax[0] != av[0]);
-        StepClass S;
-        if (E != 0ull) mat_classify(S, M, ax[0], av[0]);       // the set's first step; every step then asks for the one after it
-#pragma unroll 1
-        for (; g + 1u < nint; ++g) {
-            const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-            if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
-            process_group_roll<CH, PROBE, CLS, true>(L, C, M, lane, ax, av, pix + (size_t)(lo + g * kGroupPx + lane) * (size_t)CH, 0u, 0u, S, E, ccp, vbase);
-        }
-        {   // the last group inside the image: nothing to refill, the two pixels around its end stand in for the next step
-            const uint32_t base = lo + g * kGroupPx;
-            const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-            if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
-            const uint32_t ex = load_px<CH>(pix, base + kGroupPx), ev = load_px<CH>(pix, base + kGroupPx - 1u);
-            if (!last_set) ask_early();
-            process_group_roll<CH, PROBE, CLS, false>(L, C, M, lane, ax, av, pix, ex, ev, S, E, ccp, vbase);
-            ++g;
-        }
-    }
-    if (CLS == 0 && nint) {
+    if (nint) {
         u64 E = __ballot(ax[0] != av[0]);
         // ---- two groups per turn: while one is encoded the loads of the next are in flight ----------------------------
         // (the pair loaded when no group follows inside the loop: the two pixels around the end of the set, or around the
@@ -1007,7 +838,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, bx, bv);
                 else { bx[0] = load_px<CH>(pix, base + kGroupPx); bv[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
-                process_group<PROBE, false, CLS>(L, C, M, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
+                process_group<PROBE, false>(L, C, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
                 if (++g >= nint) break;
             }
             {   // group g sits in b*; fetch g+1 into a*
@@ -1016,7 +847,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, ax, av);
                 else { ax[0] = load_px<CH>(pix, base + kGroupPx); av[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
-                process_group<PROBE, false, CLS>(L, C, M, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
+                process_group<PROBE, false>(L, C, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
                 if (++g >= nint) break;
             }
         }
@@ -1034,7 +865,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         load_pair_guarded<CH>(pix, base + kGroupPx + lane, n, nxp, nxv);
         if (g + 1u == ngroups) ask_early();
         u64 E = __ballot(ax[0] != av[0]);
-        process_group<PROBE, true, CLS>(L, C, M, lane, ax, av, nxp, nxv, (int)(n - base), E, ccp, vbase);
+        process_group<PROBE, true>(L, C, lane, ax, av, nxp, nxv, (int)(n - base), E, ccp, vbase);
     }
     uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
     const uint32_t set_bytes = spilled + spos;
@@ -1098,16 +929,10 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         out[lane] = (uint8_t)((lane < 8u ? hdr_lo : hdr_hi) >> (8u * (lane & 7u)));
     }
     const u64 pos = (u64)kHeaderBytes + (u64)excl;
-#ifdef QOIMI_EXP_NOCOPY   // timing experiment only (no stream bytes leave the wavefront)
-    if (p.n_units == 0xFFFFFFFFu)
-#endif
     if (spilled) {                                          // the part that went through the scratch slot: by this wavefront, from this CU
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         copy_global_out(slot, out + pos, spilled, lane);
     }
-#ifdef QOIMI_EXP_NOCOPY
-    if (p.n_units == 0xFFFFFFFFu)
-#endif
     if (spos) {
         __builtin_amdgcn_wave_barrier();
         copy_stage_out(L.stage, out + pos + spilled, spos, lane);
@@ -1128,9 +953,9 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 // the ENTRY 0 passes with only_flagged set: small grid-stride grids that return at once when nothing was
 // flagged.  A workgroup serves unit u = (image u % n_images, four consecutive sets u / n_images) so that the
 // sets in flight spread over all images.
-template <int CH, int PROBE, int ENTRY, int CLS>
-__global__ __launch_bounds__(256, PROBE == 1 ? (CLS == 1 ? QOIMI_ENC_WAVES_PER_SIMD - 1 : QOIMI_ENC_WAVES_PER_SIMD) : 4) void enc_sets(EncParams p) {
-    __shared__ EncLdsFor<PROBE, CLS> s_lds[4];
+template <int CH, int PROBE, int ENTRY>
+__global__ __launch_bounds__(256, PROBE == 1 ? QOIMI_ENC_WAVES_PER_SIMD : 4) void enc_sets(EncParams p) {
+    __shared__ EncLdsFor<PROBE> s_lds[4];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
 #pragma unroll 1
@@ -1152,7 +977,7 @@ __global__ __launch_bounds__(256, PROBE == 1 ? (CLS == 1 ? QOIMI_ENC_WAVES_PER_S
             if (lane == 0) t = atomicAdd(&p.ticket[img], 1u);
             set = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         }
-        if (set < p.sets_per_image) encode_set<CH, PROBE, ENTRY, CLS>(p, img, set, lane, s_lds[wave]);
+        if (set < p.sets_per_image) encode_set<CH, PROBE, ENTRY>(p, img, set, lane, s_lds[wave]);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1295,7 +1120,7 @@ __global__ __launch_bounds__(64 * WAVES) void lds_order_selftest(uint32_t* out) 
 // ---------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------
-template <int CH, int PROBE, int CLS>
+template <int CH, int PROBE>
 static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int phases) {
     const uint32_t total_slabs = p.n_images * p.spi;
     const uint32_t slab_blocks = (total_slabs + 3u) / 4u;
@@ -1308,7 +1133,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     if (warm) {
         p.only_flagged = 0;
         // (p.persist: test knob - at most that many workgroups, each taking unit after unit in the kernel's grid-stride loop)
-        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, CLS>), dim3(p.persist && p.n_units > p.persist ? p.persist : p.n_units), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1>), dim3(p.persist && p.n_units > p.persist ? p.persist : p.n_units), dim3(256), 0, st, p);
         tm->mark(kT_enc_slabs, st);
         p.only_flagged = 1;
     } else {
@@ -1326,7 +1151,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     // (256 flat 4K frames: 9.0 ms with look-back, 7.5 order-free).  The placement passes then serve the flagged images only.
     const bool first_lookback = p.lookback != 0;
     if (warm) p.lookback = 0;
-    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0, CLS>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
     tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
     p.only_flagged = (warm && first_lookback) ? 1 : 0;
     }
@@ -1340,16 +1165,13 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
 }
 
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phases) {
-    // (the matrix-pipe classes exist for the exchange probe only: the order-independent probe is the fall-back path)
     if (p.channels == 3) {
-        if (!p.probe_xchg) launch_encode_t<3, 0, 0>(p, st, tm, phases);
-        else if (p.cls_mat) launch_encode_t<3, 1, 1>(p, st, tm, phases);
-        else launch_encode_t<3, 1, 0>(p, st, tm, phases);
+        if (!p.probe_xchg) launch_encode_t<3, 0>(p, st, tm, phases);
+        else launch_encode_t<3, 1>(p, st, tm, phases);
         return;
     }
-    if (!p.probe_xchg) { launch_encode_t<4, 0, 0>(p, st, tm, phases); return; }
-    if (p.cls_mat) launch_encode_t<4, 1, 1>(p, st, tm, phases);
-    else launch_encode_t<4, 1, 0>(p, st, tm, phases);
+    if (!p.probe_xchg) launch_encode_t<4, 0>(p, st, tm, phases);
+    else launch_encode_t<4, 1>(p, st, tm, phases);
 }
 
 // returns the number of mismatching patterns of the LDS exchange-order self-test (0 = ordered)

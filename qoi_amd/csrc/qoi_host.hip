@@ -103,8 +103,6 @@ struct qoimi_ctx {
     int enc_ticket = 1, enc_set_slabs = 0, enc_warm = 1;   // tuning / test knobs (env QOIMI_ENC_*)
     int enc_spread = 1;                 // env QOIMI_ENC_SPREAD: the wavefronts of a workgroup take their tickets from consecutive images (0: all four from one image)
     int enc_persist = 0;                // env QOIMI_ENC_PERSIST: workgroups of the first encode pass (0: one per unit)
-    int enc_cls = 0;                    // env QOIMI_ENC_CLS: 0 the literal classes of a step from the vector pipe (paired 16-bit halves), 1 from the matrix
-                                        // pipe (one v_mfma_i32_32x32x16_i8 per step, five wavefronts per SIMD; measured: no faster - DESIGN.md section 3)
     int enc_lookback = -1;              // 1: sets place their bytes themselves (decoupled look-back); 0: order-free (scratch slots + enc_offsets + enc_compact); -1: by the number of sets per image
     std::string enc_debug_dump;         // env QOIMI_ENC_DEBUG_DUMP: file that receives the entry-state arrays of every encode call
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
@@ -170,7 +168,6 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_SPREAD")) c->enc_spread = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_PERSIST")) { const int v = atoi(e); if (v >= 0) c->enc_persist = v; }
-    if (const char* e = getenv("QOIMI_ENC_CLS")) { const int v = atoi(e); if (v >= 0 && v <= 1) c->enc_cls = v; }
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
     if (const char* e = getenv("QOIMI_P3_PLAIN")) c->dec_p3_plain = atoi(e);
@@ -250,6 +247,12 @@ extern "C" const char* qoimi_kernel_name(int i) {
 
 extern "C" long long qoimi_encode_suspect_calls(qoimi_ctx* c) { return c ? c->enc_suspect_calls : 0; }
 
+// device memory the context holds: [0] encode workspace, [1] decode workspace, [2] staging of the host-pointer entry points
+extern "C" void qoimi_workspace_bytes(qoimi_ctx* c, size_t out[3]) {
+    out[0] = c ? c->enc_ws.cap : 0; out[1] = c ? c->dec_ws.cap : 0;
+    out[2] = c ? c->io_a.cap + c->io_b.cap + c->io_c.cap : 0;
+}
+
 extern "C" void qoimi_decode_stats(qoimi_ctx* c, long long out[4]) {
     for (int i = 0; i < 4; ++i) out[i] = c ? c->dec_stats[i] : 0;
 }
@@ -304,14 +307,12 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.probe_xchg = c->xchg_ordered ? 1 : 0;
     p.use_ticket = c->enc_ticket ? 1 : 0;
     p.warm = c->enc_warm ? 1 : 0;
-    p.cls_mat = (uint8_t)c->enc_cls;
     p.persist = (uint32_t)c->enc_persist;
     p.spread = (uint32_t)c->enc_spread;
     {   // slabs per set: a wavefront carries the colour table and its staged bytes from slab to slab, so the entry-state replay
         // and the look-back are paid once per set - as long as the sets still fill the 256 CUs x 20 wavefronts several times
         const size_t total_slabs = (size_t)n_images * p.spi;
         uint32_t r = total_slabs >= 3u * 65536u ? 3u : (total_slabs >= 16384u ? 2u : 1u);
-        if (r == 3u && c->enc_cls == 1 && c->xchg_ordered) r = 4u;     // (the matrix-pipe form stages 7.6 KB per wavefront: four slabs fit)
         if (c->enc_set_slabs > 0) r = (uint32_t)c->enc_set_slabs;
         if (r > kEncMaxSetSlabs) r = kEncMaxSetSlabs;
         p.set_slabs = r;

@@ -52,7 +52,6 @@ struct EncParams {
                              // 0: order-free - sets park their bytes in scratch slots, enc_offsets + enc_compact place them
     uint8_t warm;            // 1: sets find their entry state themselves (look-back window), E1/E2 only for flagged images
     uint8_t only_flagged;    // set by the launcher: this pass handles images with need_generic[img] != 0 only
-    uint8_t cls_mat;         // 1: the literal classes of a step come from the matrix pipe (enc_sets CLS 1: one v_mfma_i32_32x32x16_i8 per step; exchange probe only)
     uint32_t n_units;        // set by the launcher: (image, four consecutive sets) work units
     uint32_t spread;         // 1 (default): the wavefronts of a workgroup serve consecutive images (env QOIMI_ENC_SPREAD=0: all four take tickets of one image)
     uint32_t persist;        // 0: one workgroup per unit; else the first pass runs at most this many workgroups (env QOIMI_ENC_PERSIST, a test knob)

@@ -271,12 +271,9 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_DEC_L2M": "2", "QOIMI_SEG_BYTES": "128"},     # ... with many groups per image, several rounds (uiflat)
     {"QOIMI_DEC_L2M": "0"},                               # ... never
     {"QOIMI_ENC_PERSIST": "3"},                           # three workgroups walk all units (grid-stride loop of enc_sets)
-    {"QOIMI_ENC_CLS": "1"},                               # literal classes of a step from the matrix pipe (one v_mfma_i32_32x32x16_i8 per step)
-    {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_WARM": "0"},        # ... with the entry states from the summary passes
-    {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
-    {"QOIMI_ENC_SPREAD": "1"},                            # the wavefronts of a workgroup take their tickets from consecutive images
-    {"QOIMI_ENC_SPREAD": "1", "QOIMI_ENC_SET_SLABS": "2"},
-    {"QOIMI_ENC_SPREAD": "1", "QOIMI_ENC_PERSIST": "3"},  # ... in the grid-stride loop
+    {"QOIMI_ENC_SPREAD": "0"},                            # the four wavefronts of a workgroup take their tickets from ONE image (the default: from consecutive images)
+    {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "2"},
+    {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_PERSIST": "3"},  # ... in the grid-stride loop
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
@@ -458,7 +455,7 @@ def test_flat_frames_byte_identical(api, oracle, env):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_CLS": "1"}])
+@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_SPREAD": "0"}])
 def test_random_sweep_of_contents_and_shapes(api, oracle, env):
     """A seeded sweep over every synthetic content kind at shapes from a few pixels to several 64-slab groups, 3 and 4 channels:
     encode byte-identical to the reference, decode of that stream bit-identical to the pixels.  (The fixed shapes of the other
@@ -504,7 +501,7 @@ def test_random_sweep_of_contents_and_shapes(api, oracle, env):
 
 
 @pytest.mark.parametrize("slabs", [1, 2, 3, 4, 5, 8])
-@pytest.mark.parametrize("lookback", ["1", "0", "spread"])
+@pytest.mark.parametrize("lookback", ["1", "0", "nospread"])
 def test_set_sizes_and_placements(api, oracle, slabs, lookback):
     """A wavefront encodes a SET of R consecutive slabs (R = 1..8; the library picks it from the batch size, here it is forced) and
     places its bytes by look-back (bytes beyond the staging buffer spill through the set's scratch slot) or order-free.  Shapes
@@ -514,8 +511,8 @@ def test_set_sizes_and_placements(api, oracle, slabs, lookback):
     from qoi_amd import synth
     old = {k: os.environ.get(k) for k in ("QOIMI_ENC_SET_SLABS", "QOIMI_ENC_LOOKBACK", "QOIMI_ENC_SPREAD")}
     os.environ["QOIMI_ENC_SET_SLABS"] = str(slabs)
-    os.environ["QOIMI_ENC_LOOKBACK"] = "1" if lookback == "spread" else lookback
-    os.environ["QOIMI_ENC_SPREAD"] = "1" if lookback == "spread" else "0"
+    os.environ["QOIMI_ENC_LOOKBACK"] = "1" if lookback == "nospread" else lookback
+    os.environ["QOIMI_ENC_SPREAD"] = "0" if lookback == "nospread" else "1"
     try:
         c = api.Context(0)
         for (w, h) in ((1400, 900), (517, 313), (64, 9), (1024, 16)):
@@ -564,7 +561,7 @@ def _mixed_frame(rng, w, h, ch, seed):
 
 
 @pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_SET_SLABS": "3"}, {"QOIMI_ENC_SET_SLABS": "8"}, {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
-                                 {"QOIMI_ENC_CLS": "1"}, {"QOIMI_ENC_CLS": "1", "QOIMI_ENC_SET_SLABS": "3"}])
+                                 {"QOIMI_ENC_SPREAD": "0"}, {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "3"}])
 def test_mixed_content_partial_spills(api, oracle, env):
     """Sets whose bytes only partly fit the LDS staging buffer (tools/dev/sweep_enc.py is the long form of this test)."""
     import torch

@@ -23,4 +23,4 @@ for _ in range(3):
 lib.qoimi_debug_enc_phases(buf, 0)
 v = list(buf); sets = v[5]; tot = sum(v[0:5])
 names = ['entry state', 'groups inside the image', 'general-form groups', 'look-back', 'copy-out']
-print(f"CLS={os.environ.get('QOIMI_ENC_CLS', '0')} R={os.environ.get('QOIMI_ENC_SET_SLABS', '-')} sets {sets}: ticks per set {tot / sets:.0f}; " + ', '.join(f"{n} {v[i] / sets:.0f} ({100.0 * v[i] / tot:.1f} %)" for i, n in enumerate(names)) + f"; sets that re-polled {100.0 * v[6] / max(sets, 1):.1f} %, re-polls per set {v[7] / max(sets, 1):.2f}")
+print(f"R={os.environ.get('QOIMI_ENC_SET_SLABS', '-')} sets {sets}: ticks per set {tot / sets:.0f}; " + ', '.join(f"{n} {v[i] / sets:.0f} ({100.0 * v[i] / tot:.1f} %)" for i, n in enumerate(names)) + f"; sets that re-polled {100.0 * v[6] / max(sets, 1):.1f} %, re-polls per set {v[7] / max(sets, 1):.2f}")

@@ -22,4 +22,4 @@ c.set_profiling(True)
 for _ in range(5):
     c.encode_batch(px.data_ptr(), ps, desc, F, st.data_ptr(), ss, lens.data_ptr(), s); c.encode_status(s)
 prof = c.get_profile(s)
-print(os.environ.get('QOIMI_ENC_CLS', '0'), os.environ.get('QOIMI_ENC_SET_SLABS', '-'), os.path.basename(os.path.dirname(api.LIB_PATH)), {k: round(v[0] / 5, 3) for k, v in prof.items() if v[1] and v[0] / 5 > 0.02}, 'bytes/px', round(float(lens.sum()) / (F * npx), 4))
+print(os.environ.get('QOIMI_ENC_SET_SLABS', '-'), os.path.basename(os.path.dirname(api.LIB_PATH)), {k: round(v[0] / 5, 3) for k, v in prof.items() if v[1] and v[0] / 5 > 0.02}, 'bytes/px', round(float(lens.sum()) / (F * npx), 4))
