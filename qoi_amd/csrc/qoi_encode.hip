@@ -19,6 +19,7 @@
 // Pass E3 (enc_sets) is the hot kernel: two coalesced dword loads per pixel (the pixel and the
 // one before it), an LDS-resident colour table per wavefront, 64-bit ballots / mbcnt for run
 // lengths and byte offsets.  Byte/integer work only - no MFMA.
+#include <stdlib.h>
 #include "qoi_dev.h"
 #include "qoi_kernels.h"
 
@@ -683,24 +684,28 @@ __device__ __forceinline__ bool warm_entry_state(const uint8_t* __restrict__ pix
 
 // n bytes from a 16-byte aligned source in global memory to dst (any alignment): head up to the first 16-byte boundary byte by
 // byte, aligned 16-byte stores (source re-aligned with v_alignbyte), tail byte by byte.  One wavefront.
+// The source is read with L1-bypassing (nt) loads: scratch slots of the pool are REUSED inside one launch, and this CU's vector L1
+// may still hold the lines of a slot as an earlier holder on this CU read them - a wavefront's own stores go through to the L2 and
+// do not refresh them (MI355X_MICROARCH.md, inter-workgroup visibility).  With a slot per set nothing was ever read twice.
 __device__ __forceinline__ void copy_global_out(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t n, uint32_t lane) {
     const uint32_t mis = (uint32_t)(uintptr_t)dst & 15u;
     const uint32_t head = min(n, (16u - mis) & 15u);                 // bytes before dst becomes 16-byte aligned
-    if (lane < head) dst[lane] = src[lane];
+    if (lane < head) dst[lane] = __builtin_nontemporal_load(&src[lane]);
     const uint32_t n16 = (n - head) >> 4;
     uint4* __restrict__ d16 = reinterpret_cast<uint4*>(dst + head);
     const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(src) + (head >> 2);
     const uint32_t sh = head & 3u;
     for (uint32_t j = lane; j < n16; j += 64u) {
         const uint32_t* q = s32 + 4u * j;
-        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+        const uint32_t w0 = __builtin_nontemporal_load(&q[0]), w1 = __builtin_nontemporal_load(&q[1]), w2 = __builtin_nontemporal_load(&q[2]),
+                       w3 = __builtin_nontemporal_load(&q[3]), w4 = __builtin_nontemporal_load(&q[4]);
         uint4 v;
         v.x = __builtin_amdgcn_alignbyte(w1, w0, sh); v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
         v.z = __builtin_amdgcn_alignbyte(w3, w2, sh); v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
         d16[j] = v;
     }
     const uint32_t done = head + (n16 << 4);
-    if (lane < n - done) dst[done + lane] = src[done + lane];
+    if (lane < n - done) dst[done + lane] = __builtin_nontemporal_load(&src[done + lane]);
 }
 // the same from the wavefront's LDS staging buffer
 __device__ __forceinline__ void copy_stage_out(const uint32_t* stage, uint8_t* __restrict__ dst, uint32_t n, uint32_t lane) {
@@ -739,6 +744,35 @@ __device__ __forceinline__ uint32_t spill_stage(LDS& L, uint8_t* __restrict__ sl
     if (lane < 4u) L.stage[lane] = keep;
     __builtin_amdgcn_wave_barrier();
     return spos & 15u;
+}
+
+// Scratch slots of the sets that spill (look-back mode).  A worst-case slot per set was 42.5 GB for the 1024-frame 4K shard and stayed
+// untouched on photographs; only the sets in flight ever hold spilled bytes.  A set takes a slot at its first spill (a bit of the
+// map, lane 0) and gives it back after its copy-out - by then its loads from the slot have all returned (their data went into the
+// stores).  All-zero = all free: the map is part of the header the launcher zeroes.
+__device__ __forceinline__ uint32_t pool_take(const EncParams& p, uint32_t seed, uint32_t lane) {
+    uint32_t id = p.pool_slots;                                // the emergency slot: only reached with every slot taken (never expected)
+    if (lane == 0) {
+        // One word of the map per 128-byte line (with the 128 words of 8192 slots in eight lines, every set of a noise batch queued at
+        // the same few lines for its slot: 36 us per set).  The first fetch-or is a guess; what it returns names the word's free bits.
+        const uint32_t words = p.pool_slots >> 6;
+        uint32_t w = seed % words, bit = (seed >> 16) & 63u;
+        for (uint32_t tries = 0; tries < 64u * words; ++tries) {
+            const u64 old = __hip_atomic_fetch_or((gu64*)&p.pool_map[(size_t)w * kEncPoolMapStride], 1ull << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((old >> bit) & 1ull) == 0ull) { id = w * 64u + bit; break; }
+            const u64 free_bits = ~(old | (1ull << bit));
+            if (free_bits == 0ull) { w = w + 1u < words ? w + 1u : 0u; continue; }         // (the bit set above was set before: nothing to undo)
+            const uint32_t r = (bit + 17u) & 63u;                                         // the next free bit from a place of our own
+            const u64 rot = (free_bits >> r) | (r ? free_bits << (64u - r) : 0ull);
+            bit = ((uint32_t)__builtin_ctzll(rot) + r) & 63u;
+        }
+        if (id == p.pool_slots) atomicOr(p.err, 2u);
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+}
+__device__ __forceinline__ void pool_give(const EncParams& p, uint32_t id, uint32_t lane) {
+    if (lane == 0 && id < p.pool_slots)
+        (void)__hip_atomic_fetch_and((gu64*)&p.pool_map[(size_t)(id >> 6) * kEncPoolMapStride], ~(1ull << (id & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int CH, int PROBE, int ENTRY, class LDS>
@@ -811,7 +845,14 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     const uint32_t sbase = lds_addr(L.stage);
     uint32_t vbase = sbase;                                    // LDS address of the next staged byte (same in every lane)
     uint32_t spilled = 0;                                      // bytes of the set already moved to its scratch slot
-    uint8_t* __restrict__ slot = p.scratch + sg * p.set_stride;
+    uint32_t slot_id = 0xFFFFFFFFu;                            // pool mode: the slot the set holds (none yet)
+    uint8_t* slot = p.pool ? nullptr : p.scratch + sg * p.set_stride;
+    auto need_slot = [&]() {
+        if (p.pool && slot_id == 0xFFFFFFFFu) {
+            slot_id = pool_take(p, (uint32_t)sg * 2654435761u, lane);
+            slot = p.scratch + (size_t)slot_id * p.set_stride;
+        }
+    };
 
     // Look-back, first poll: the records of the 64 sets before this one are asked for when the set's LAST group begins - the sets
     // before it started earlier and have mostly published by then - so that the answer travels while that group is encoded
@@ -835,7 +876,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
             {   // group g sits in a*; fetch g+1 into b*
                 const uint32_t base = lo + g * kGroupPx;
                 const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-                if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+                if (spos > LDS::kSpill) { need_slot(); vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane); }
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, bx, bv);
                 else { bx[0] = load_px<CH>(pix, base + kGroupPx); bv[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
                 process_group<PROBE, false>(L, C, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
@@ -844,7 +885,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
             {   // group g sits in b*; fetch g+1 into a*
                 const uint32_t base = lo + g * kGroupPx;
                 const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-                if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+                if (spos > LDS::kSpill) { need_slot(); vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane); }
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, ax, av);
                 else { ax[0] = load_px<CH>(pix, base + kGroupPx); av[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
                 process_group<PROBE, false>(L, C, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
@@ -858,7 +899,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     for (; g < ngroups; ++g) {
         const uint32_t base = lo + g * kGroupPx;
         const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
-        if (spos > LDS::kSpill) vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane);
+        if (spos > LDS::kSpill) { need_slot(); vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane); }
         uint32_t nxp, nxv;
 #pragma unroll
         for (int t = 0; t < kGroupSteps; ++t) load_pair_guarded<CH>(pix, base + t * 64u + lane, n, ax[t], av[t]);
@@ -903,7 +944,10 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 if (notready & need) {                                    // a record we must add is not published yet
                     // (first pass: a predecessor that gave the image up never publishes - the image is encoded again anyway.  Looked at
                     // every 8th poll only: the flag is one more round trip through the fabric in front of every re-poll)
-                    if (ENTRY == 1 && (spins & 7u) == 7u && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+                    if (ENTRY == 1 && (spins & 7u) == 7u && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        if (slot_id != 0xFFFFFFFFu) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pool_give(p, slot_id, lane); }
+                        return;
+                    }
                     if (++spins > (1u << 22)) { if (lane == 0) atomicOr(p.err, 1u); break; }
                     __builtin_amdgcn_s_sleep(2);
                     continue;
@@ -932,6 +976,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     if (spilled) {                                          // the part that went through the scratch slot: by this wavefront, from this CU
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         copy_global_out(slot, out + pos, spilled, lane);
+        if (slot_id != 0xFFFFFFFFu) pool_give(p, slot_id, lane);
     }
     if (spos) {
         __builtin_amdgcn_wave_barrier();
@@ -1127,7 +1172,13 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     const uint32_t quads_per_image = (p.sets_per_image + 3u) / 4u;
     p.n_units = quads_per_image * p.n_images;
     const bool warm = p.warm && PROBE == 1;
-    uint32_t small = 2048u;                                  // grid of the passes that usually have nothing to do
+    // grid of the passes that usually have nothing to do: they return at once then (a few microseconds for 2048 workgroups).  When
+    // there IS work - flat content - a grid-stride loop over few long-lived workgroups is the slow way to run enc_sets (a persistent
+    // grid costs it 20 %, profiles/r04_s1_enc_knobs.txt): large calls get 1/32 of the full grid (256 flat 4K frames: 8.5 -> 7.3 ms;
+    // 1/8: 7.0 ms, but its empty launches cost the photographs 0.7 %; 1/32: 0.2 %).  QOIMI_ENC_GEN_GRID_DIV sets the divisor.
+    static const uint32_t gen_div = [] { const char* e = getenv("QOIMI_ENC_GEN_GRID_DIV"); const int v = e ? atoi(e) : 32; return (uint32_t)(v >= 1 ? v : 32); }();
+    uint32_t small = 2048u;
+    { const uint32_t big = (p.n_units > slab_blocks ? p.n_units : slab_blocks) / gen_div; if (big > small) small = big; }
     tm->mark(kT_begin, st);
     if (phases & kEncSlabs) {
     if (warm) {
@@ -1146,14 +1197,23 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     tm->mark(kT_enc_scan_groups, st);
     hipLaunchKernelGGL(enc_scan_images, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_images, st);
-    // The images the first pass gave up on (flat content) are encoded again from their first set - ORDER-FREE whatever the first
-    // pass used: their sets are a few bytes each, a look-back per set costs more than the scan + move of the placement passes
-    // (256 flat 4K frames: 9.0 ms with look-back, 7.5 order-free).  The placement passes then serve the flagged images only.
+    // The images the first pass gave up on (flat content) are encoded again from their first set ...
     const bool first_lookback = p.lookback != 0;
-    if (warm) p.lookback = 0;
-    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0>), dim3(p.n_units < small ? p.n_units : small), dim3(256), 0, st, p);
+    EncParams g = p;
+    if (warm && first_lookback) {
+        // ... by look-back as well, with records / tickets of their own (the first pass left some behind for these images) and
+        // kEncGenSetSlabs slabs per set: flat content is a few bytes per slab, eight slabs per look-back instead of R.  (Round 3 parked
+        // these sets order-free in per-set scratch slots - the worst-case slots of EVERY set of the batch, 42.5 GB for 1024 4K frames.)
+        g.status = p.status_gen; g.ticket = p.ticket_gen;
+        g.set_slabs = kEncGenSetSlabs; g.set_px = kEncGenSetSlabs * kEncSlabPx;
+        g.sets_per_image = (p.spi + kEncGenSetSlabs - 1u) / kEncGenSetSlabs;
+        g.n_units = ((g.sets_per_image + 3u) / 4u) * p.n_images;
+    } else if (warm) {
+        g.lookback = 0; p.lookback = 0;                      // an order-free call: the flagged images are parked and placed with the others
+    }
+    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0>), dim3(g.n_units < small ? g.n_units : small), dim3(256), 0, st, g);
     tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
-    p.only_flagged = (warm && first_lookback) ? 1 : 0;
+    p.only_flagged = 0;
     }
     if (!p.lookback && (phases & kEncPlace)) {
         const uint32_t set_blocks = (p.n_images * p.sets_per_image + 3u) / 4u;

@@ -32,6 +32,10 @@ constexpr int kEncSteps = 16;                         // 64-pixel steps per slab
 constexpr uint32_t kEncSlabPx = 64u * kEncSteps;      // pixels per slab: the unit of the generic entry-state passes
 constexpr uint32_t kEncMaxSetSlabs = 8;               // a wavefront encodes a SET of 1..8 consecutive slabs
 constexpr uint32_t kEncSlabWorst = kEncSlabPx * 5u;   // most bytes a slab can produce (QOI_OP_RGBA everywhere)
+constexpr uint32_t kEncPoolSlots = 8192;              // look-back mode: scratch slots of the sets that spill, handed out by a bitmap (more than the 6144
+                                                      // wavefronts of enc_sets a chip holds at a time: a set keeps its slot from its first spill to its copy-out)
+constexpr uint32_t kEncPoolMapStride = 16;            // u64 words between two words of the pool's bitmap: one word per 128-byte line
+constexpr uint32_t kEncGenSetSlabs = 8;               // slabs per set of the generic pass when it places by look-back (flat content: few bytes per slab)
 
 struct EncParams {
     const uint8_t* pixels;   // image i at pixels + i*pixel_stride
@@ -65,7 +69,14 @@ struct EncParams {
     uint32_t* err;       // liveness-bound flag               -- zeroed before every launch
     uint32_t* need_generic;  // [n_images] image needs the E1/E2 path  -- zeroed before every launch
     uint32_t* any_generic;   // [1]                                    -- zeroed before every launch
-    uint8_t* scratch;    // [n_images*sets_per_image][set_stride]: parked sets (order-free mode) / spilled pieces (look-back mode)
+    uint8_t* scratch;    // order-free mode: [n_images*sets_per_image][set_stride] parked sets; look-back mode (pool = 1): [pool_slots + 1][set_stride],
+                         // the spilled pieces of the sets that hold a slot (the last slot is the emergency slot of an exhausted pool: err bit 1)
+    u64* pool_map;       // [pool_slots / 64 * kEncPoolMapStride] look-back mode: bit set = slot taken      -- zeroed before every launch
+    uint32_t pool_slots; // multiple of 64
+    uint8_t pool;        // 1: scratch slots come from the pool (look-back mode)
+    // the generic pass of a look-back call places by look-back too, with its own records / tickets and kEncGenSetSlabs slabs per set
+    u64* status_gen;     // [n_images * ceil(spi / kEncGenSetSlabs)]                                     -- zeroed before every launch
+    uint32_t* ticket_gen;    // [n_images]                                                             -- zeroed before every launch
     uint32_t* set_size;  // [n_images*sets_per_image]  order-free mode
     uint32_t* set_off;   // [n_images*sets_per_image]  order-free mode
     // output

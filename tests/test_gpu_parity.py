@@ -770,3 +770,43 @@ def test_failed_lds_order_recheck_is_counted_and_reported_once(api, oracle):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_spilling_sets_share_a_scratch_pool(api, oracle):
+    """Look-back placement: sets that outgrow their LDS staging buffer spill to a slot of a POOL (qoi_encode.hip pool_take) instead of a
+    worst-case slot per set.  21 600 noise sets - more than the pool's 8192 slots - so slots are handed out again and again inside
+    one launch (the bytes a set reads back must be its own, not what this CU's L1 kept of the slot's earlier holder), next to
+    photographs that never spill; and the workspace of a larger batch stays far below a slot per set."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    old = os.environ.get("QOIMI_ENC_SET_SLABS")
+    os.environ["QOIMI_ENC_SET_SLABS"] = "1"
+    try:
+        c = api.Context(0)
+        w, h, n = 1280, 720, 26
+        b = DeviceBatch(c, w, h, 4, n)
+        kinds = ["noise"] * 24 + ["photo", "uiflat"]
+        for i in range(n):
+            c.synth_frames(synth.KIND_ID[kinds[i]], synth.DEFAULT_SEED, 900 + i, 1, w, h, b.pixels.data_ptr() + i * b.pixel_stride, b.pixel_stride, b.stream)
+        for rep in range(2):
+            lens = b.encode()
+            for i in (0, 7, 13, 23, 24, 25):
+                assert b.stream_bytes(i, lens[i]) == oracle.encode(synth.frame_rgba(kinds[i], w, h, 900 + i), w, h, 4), (rep, i)
+        out = torch.zeros(n * b.pixel_stride, dtype=torch.uint8, device="cuda")
+        b.decode_into(out, lens)
+        assert torch.equal(out.view(n, -1)[:, :w * h * 4], b.pixels.view(n, -1)[:, :w * h * 4])
+        c.close()
+    finally:
+        if old is None:
+            os.environ.pop("QOIMI_ENC_SET_SLABS", None)
+        else:
+            os.environ["QOIMI_ENC_SET_SLABS"] = old
+    c = api.Context(0)
+    w, h, n = 1920, 1080, 128
+    b = DeviceBatch(c, w, h, 4, n)
+    c.synth_frames(synth.KIND_ID["photo"], synth.DEFAULT_SEED, 0, n, w, h, b.pixels.data_ptr(), b.pixel_stride, b.stream)
+    b.encode()
+    ws = c.workspace_bytes()["encode"]
+    assert ws < 700 << 20, ws            # generic-path tables 0.13 GB + pool 0.34 GB (a worst-case slot per set: 1.3 GB more)
+    c.close()
