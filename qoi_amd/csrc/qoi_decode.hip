@@ -1133,7 +1133,10 @@ struct PipeReader {
 #endif
 typedef PipeReader TransReader;
 constexpr uint32_t kTrThreads = 64u * QOIMI_TR_WAVES;
-struct LdsLutT { uint32_t tpl[260], info[260]; };   // record template; chunk-table word with QOI_OP_RGBA's length set to 0 (visited twice); entry 256: the null chunk of a lane that is through (no record, no bytes, no pixels)
+// per tag byte: record template and chunk-table word (QOI_OP_RGBA's length set to 0: visited twice) side by side - ONE 8-byte LDS read per
+// step (two 4-byte reads of two arrays: a third of the kernel's LDS cycles were bank conflicts of these reads, profiles/r04_s6_sq_counters_decode.txt);
+// entry 256: the null chunk of a lane that is through (no record, no bytes, no pixels)
+struct LdsLutT { uint2 e[260]; };
 
 // Parse + P2 + transcode: lane = segment.  Walks every chunk that starts in the segment, writes the chunk records of the
 // segment as 16-byte granules (row g of the wavefront's block, null-padded), counts the pixels and leaves the speculative
@@ -1160,12 +1163,11 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     if (MODE == 1 && !p.sync_all && *p.sync_fails == 0u) return;
     for (uint32_t b = threadIdx.x; b < 256u; b += kTrThreads) {
         uint32_t d, i; lut_entry(b, d, i);
-        s_lut.tpl[b] = rec_template(b);
         // the transcoder's own info word: bits 0..2 chunk length (0 for QOI_OP_RGBA: visited twice), bits 8..15 all ones for
         // QOI_OP_LUMA (ANDed onto the chunk bytes it leaves the second byte there, nothing for every other chunk), bits 30..31 class
-        s_lut.info[b] = (b == 0xFFu ? 0u : (i & 7u)) | ((i >> 28) & 1u ? 0x0000FF00u : 0u) | (i & 0xC0000000u);
+        s_lut.e[b] = make_uint2(rec_template(b), (b == 0xFFu ? 0u : (i & 7u)) | ((i >> 28) & 1u ? 0x0000FF00u : 0u) | (i & 0xC0000000u));
     }
-    if (threadIdx.x < 4u) { s_lut.tpl[256u + threadIdx.x] = 0u; s_lut.info[256u + threadIdx.x] = 0u; }
+    if (threadIdx.x < 4u) s_lut.e[256u + threadIdx.x] = make_uint2(0u, 0u);
     __syncthreads();
     const uint32_t q = blockIdx.x * kTrThreads + threadIdx.x;
     bool have = q < p.total_segs;
@@ -1176,7 +1178,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     if (!lanes_where(have)) return;
     const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
-    const uint32_t lut_base = lds_addr_of(&s_lut.tpl[0]);
+    const uint32_t lut_base = lds_addr_of(&s_lut.e[0]);
     TransReader R;
     uint32_t pos;
     bool failed = false;
@@ -1228,13 +1230,15 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     // SDWA shift: 20 vector instructions per chunk in the common path (23 with an absolute cursor, round 2).
     uint32_t rp = pos - R.aoff;
     const uint32_t end_rel = end - R.aoff;
-    uint32_t two = 2u;
-    asm volatile("" : "+v"(two));                                        // the shift count of byte0_times4 lives in a VGPR (SDWA takes no literal)
-    auto byte0_times4 = [&](uint32_t w) { uint32_t r; asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w)); return r; };
+    uint32_t three = 3u;
+    asm volatile("" : "+v"(three));                                      // the shift count of byte0_times8 lives in a VGPR (SDWA takes no literal)
+    auto byte0_times8 = [&](uint32_t w) { uint32_t r; asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(w)); return r; };
+    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const u32x2v lds_u32x2;
     uint32_t w32, b5hi, b5sh; R.peek4_rel(rp, w32, b5hi, b5sh);
     uint32_t tpl, info;                        // of the chunk under the cursor; the null entry once the lane is through
-    {   const uint32_t i4 = byte0_times4(w32);
-        const lds_u32* lq = (const lds_u32*)(lut_base + (active ? i4 : 1024u)); tpl = lq[0]; info = lq[260]; }
+    {   const uint32_t i8 = byte0_times8(w32);
+        const u32x2v te = *(lds_u32x2*)(lut_base + (active ? i8 : 2048u)); tpl = te.x; info = te.y; }
     uint32_t a_abs = 0u, a_last = 0u;            // a QOI_OP_RGBA occurred in the segment / the alpha of the last one (for dec_slot_tails)
     uint32_t pend = 0u;                          // 1: the stash record of the QOI_OP_RGBA chunk under the cursor is out
     bool any_pend = false;
@@ -1274,9 +1278,9 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                 const uint32_t nrp = rp + adv;
                 uint32_t nw32; R.peek4_rel(nrp, nw32, b5hi, b5sh);
                 active = active && nrp < end_rel;
-                const uint32_t i4 = byte0_times4(nw32);                  // (outside the select: a call in a ?: arm is a branch)
-                const lds_u32* lq = (const lds_u32*)(lut_base + (active ? i4 : 1024u));
-                const uint32_t ntpl = lq[0], ninfo = lq[260];
+                const uint32_t i8 = byte0_times8(nw32);                  // (outside the select: a call in a ?: arm is a branch)
+                const u32x2v te = *(lds_u32x2*)(lut_base + (active ? i8 : 2048u));
+                const uint32_t ntpl = te.x, ninfo = te.y;
                 rr[u] = rec;
                 rp = nrp; w32 = nw32; tpl = ntpl; info = ninfo;
             }
@@ -1360,11 +1364,15 @@ __global__ __launch_bounds__(64) void dec_slot_tails(DecParams p) {
     TailState t; tail_init(t);
     t.found = (have && S.n_gran != 0u) ? 0u : 1u;                         // nothing to scan: the identity transfer (h_rel = 1, hc = 0)
     const bool empty = have && S.n_gran == 0u;
-    // rows from the wavefront's last one down; a lane joins when the walk reaches ITS last row, and the walk goes on while any
-    // lane has not met its anchor
-    for (uint32_t g = wave_max_u32(S.n_gran); g-- > 0u && lanes_where(t.found == 0u) != 0;) {
-        const u32x4 v = S.granule(g);                                     // zeros for lanes that have no row g
-        if (g < S.n_gran) { tail_step(t, v.w, in.a_abs, in.ac); tail_step(t, v.z, in.a_abs, in.ac); tail_step(t, v.y, in.a_abs, in.ac); tail_step(t, v.x, in.a_abs, in.ac); }
+    // Every lane walks ITS OWN rows from its last one down, two rows per turn (both loads in flight together), while any lane has
+    // not met its anchor.  (Round 3 walked a common row index down from the wavefront's LARGEST row count: the lanes' counts differ
+    // by tens of rows, every one of them a dependent load - 0.63 ms per 1024 frames for three useful rows per lane.)
+    const uint32_t most = wave_max_u32(S.n_gran);
+    for (uint32_t i = 0; i < most && lanes_where(t.found == 0u) != 0; i += 2u) {
+        const uint32_t g0 = S.n_gran - 1u - i, g1 = S.n_gran - 2u - i;    // (wrap past row 0: far beyond n_gran, granule() returns zeros)
+        const u32x4 v0 = S.granule(g0), v1 = S.granule(g1);
+        if (i < S.n_gran) { tail_step(t, v0.w, in.a_abs, in.ac); tail_step(t, v0.z, in.a_abs, in.ac); tail_step(t, v0.y, in.a_abs, in.ac); tail_step(t, v0.x, in.a_abs, in.ac); }
+        if (i + 1u < S.n_gran) { tail_step(t, v1.w, in.a_abs, in.ac); tail_step(t, v1.z, in.a_abs, in.ac); tail_step(t, v1.y, in.a_abs, in.ac); tail_step(t, v1.x, in.a_abs, in.ac); }
     }
     if (empty) t.found = 0u;
     if (have) p.slot_rec[q] = tail_finish(t, in.a_abs, in.ac);
@@ -1644,13 +1652,15 @@ struct BurstWriter : LaneWriter<OCH, RING_, GROUP_> {
             // instruction, SQ_WAIT_INST_ANY 43 % of the wavefront cycles, profiles/r02).
             constexpr uint32_t kLpo = kG / 4u, kOwners = 64u / kLpo;                // lanes per owner, owners per instruction
             const uint32_t lane = (this->row >> 2) & 63u;
-            const uint32_t A = go ? boff + this->fpos * 4u : kNowhere;            // the group's byte offset in the descriptor
-            const uint32_t rb = this->fpos & kG;                                   // the group is the lower or the upper half of the ring
+            // the group's byte offset in the descriptor (below 2^31: kRange) with "the group is the upper half of the ring" on top:
+            // ONE cross-lane gather per owner instead of two
+            const uint32_t A = (go ? boff + this->fpos * 4u : kNowhere) | ((this->fpos & kG) ? 0x80000000u : 0u);
             const uint32_t piece = lane & (kLpo - 1u);
 #pragma unroll
             for (uint32_t j = 0; j < kLpo; ++j) {
                 const uint32_t owner = lane / kLpo + kOwners * j;
-                const uint32_t Ao = gather_lane(A, owner), rbo = gather_lane(rb, owner);
+                const uint32_t Ag = gather_lane(A, owner);
+                const uint32_t Ao = Ag & 0x7FFFFFFFu, rbo = (Ag >> 31) * kG;
                 const uint32_t raddr = this->row - lane * 4u + owner * 4u + ((rbo + 4u * piece) << 8);
                 u32x4 w;
                 w.x = *(const lds_u32*)(raddr); w.y = *(const lds_u32*)(raddr + 256u); w.z = *(const lds_u32*)(raddr + 512u); w.w = *(const lds_u32*)(raddr + 768u);
@@ -1674,13 +1684,13 @@ struct BurstWriter : LaneWriter<OCH, RING_, GROUP_> {
                 }
             }
             const uint32_t lane = (this->row >> 2) & 63u;
-            const uint32_t A = go ? boff + this->fpos * 3u : kNowhere;             // the group's byte offset in the descriptor
-            const uint32_t rb = this->fpos & kG;
+            const uint32_t A = (go ? boff + this->fpos * 3u : kNowhere) | ((this->fpos & kG) ? 0x80000000u : 0u);   // (as above)
             const uint32_t piece = lane & 3u;                                      // piece 3 does not exist: 48 bytes per group
 #pragma unroll
             for (uint32_t j = 0; j < 4u; ++j) {
                 const uint32_t owner = lane / 4u + 16u * j;
-                const uint32_t Ao = gather_lane(A, owner), rbo = gather_lane(rb, owner);
+                const uint32_t Ag = gather_lane(A, owner);
+                const uint32_t Ao = Ag & 0x7FFFFFFFu, rbo = (Ag >> 31) * kG;
                 const uint32_t raddr = this->row - lane * 4u + owner * 4u + ((rbo + 4u * piece) << 8);
                 u32x4 w;
                 w.x = *(const lds_u32*)(raddr); w.y = *(const lds_u32*)(raddr + 256u); w.z = *(const lds_u32*)(raddr + 512u); w.w = *(const lds_u32*)(raddr + 768u);
