@@ -50,7 +50,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def _latest_traffic_file() -> str:
-    """The most recent committed PMC traffic summary (profiles/rNN_sM_pmc_traffic.json, written by tools/gpu_session.sh)."""
+    """The most recent committed PMC traffic summary (profiles/rNN_sM_pmc_traffic.json, written by tools/measure/session.sh)."""
     import glob
     import re
     best, key = "", (-1, -1)
@@ -66,7 +66,7 @@ TRAFFIC_FILE = _latest_traffic_file()
 
 def measured_traffic(kernel_prefix: str, scale: float = 1.0):
     """HBM bytes per launch of the dominant kernel, EXTRAPOLATED from the latest committed rocprofv3 PMC passes of this
-    command (tools/gpu_session.sh: separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-cpu ...`; the counters cannot
+    command (tools/measure/session.sh: separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-cpu ...`; the counters cannot
     be collected from inside the process): the per-launch figure of the kernel instantiation named in the file, scaled
     by the frames per launch.  It is a figure of that session's build (the file names its commit where the session
     recorded one), not of the run at hand - the source string says so.  FETCH_SIZE is doubled as
@@ -364,7 +364,7 @@ def main() -> None:
     launches = args.steps * passes
 
     # bit-exact round trip (qoibench.c:408-417) on the whole batch, and four of its streams against the reference codec
-    ok = args.encode_only or equal_batches(torch, decoded, pixels, n_last, pstride, npx * 4)
+    ok = args.encode_only or equal_batches(torch, decoded[:n_last * pstride], pixels[:n_last * pstride], n_last, pstride, npx * 4)
     dstats = ctx.decode_stats()
     refcheck = None
     if rank == 0 and not args.encode_only:

@@ -24,7 +24,7 @@ QOI_SRGB = 0
 QOI_LINEAR = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (QOIMI_LIB: another build of the library - the experimental builds of tools/dev/build_exp.sh under build/; tests and tools only)
+# (QOIMI_LIB: another build of the library - the experimental builds of tools/measure/build_exp.sh under build/; tests and tools only)
 LIB_PATH = os.path.abspath(os.environ["QOIMI_LIB"]) if os.environ.get("QOIMI_LIB") else os.path.join(_HERE, "lib", "libqoi_mi355x.so")
 
 EXPORTS = (

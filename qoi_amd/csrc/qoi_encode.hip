@@ -26,7 +26,7 @@
 namespace qoimi {
 
 #ifdef QOIMI_ENC_PHASES
-// Diagnostic build (-DQOIMI_ENC_PHASES, tools/dev/enc_phases.py): where a wavefront of enc_sets spends its life - s_memtime
+// Diagnostic build (-DQOIMI_ENC_PHASES, tools/measure/enc_phases.py): where a wavefront of enc_sets spends its life - s_memtime
 // ticks per phase of a set, summed over all wavefronts.  [0] entry state, [1] the groups inside the image, [2] groups of the general
 // form, [3] look-back, [4] copy-out, [5] sets, [6] sets whose first poll (asked for a group ahead) did not suffice, [7] re-polls.
 __device__ unsigned long long g_enc_phase[8];
@@ -534,16 +534,53 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, uint32_t
 // lanes 0..r-1 (r <= 0: none, r >= 64: all)
 __device__ __forceinline__ u64 lanes_upto(int r) { return r >= 64 ? ~0ull : (r <= 0 ? 0ull : (1ull << r) - 1ull); }
 
+// The pair stays RAW in its two registers - (px, pv) for 4 channels, the two loaded dwords (hi, lo) for 3 - and is taken apart by
+// unpack_pair() where it is USED (process_group, warm_entry_state): written the other way round, the three instructions that take a
+// 3-channel pair apart stood right behind their load in the source, and whether the compiler sank them to the use or kept them
+// there - every load of a group followed by its own s_waitcnt vmcnt(0) - hung on unrelated code (round 4: the scratch pool's
+// branch in the group loop made a 3-channel batch 31 % slower; `s_waitcnt vmcnt` census of the kernel, EXPERIMENTS.md).
+template <int CH>
+__device__ __forceinline__ void load_pair_at(const uint8_t* __restrict__ q, int k, uint32_t& a, uint32_t& b) {
+    if constexpr (CH == 4) {
+        a = reinterpret_cast<const uint32_t*>(q)[k];
+        b = reinterpret_cast<const uint32_t*>(q)[k - 1];
+    } else {
+        struct __attribute__((packed, aligned(1))) U2 { uint32_t x, y; };
+        const U2 v = *reinterpret_cast<const U2*>(q + k * 3 - 3);
+        a = v.y; b = v.x;
+    }
+}
+template <int CH>
+__device__ __forceinline__ void unpack_pair(uint32_t a, uint32_t b, uint32_t& px, uint32_t& pv) {
+    if constexpr (CH == 4) { px = a; pv = b; }
+    else { pv = b | 0xFF000000u; px = __builtin_amdgcn_alignbit(a, b, 24) | 0xFF000000u; }
+}
+// the raw pair that unpacks to (px, pv) - for the two single pixels around the end of a set, which are loaded one by one
+template <int CH>
+__device__ __forceinline__ void pack_pair(uint32_t px, uint32_t pv, uint32_t& a, uint32_t& b) {
+    if constexpr (CH == 4) { a = px; b = pv; }
+    else { b = (pv & 0x00FFFFFFu) | (px << 24); a = px >> 8; }
+}
+
 // ---- a group of kGroupSteps steps whose pixels (px) and previous pixels (pv) sit in registers ----------
 // E: edges of the group's first step on entry, of the first step AFTER the group on exit (from nx_px / nx_pv: the first
 // step of the next group, or the two pixels around the end of the set).  GEN: rem = pixels of the image left at the
 // group's first pixel.
-template <int PROBE, bool GEN, class LDS>
+// RAW: 0 = px / pv hold pixels; 3 or 4 = they hold raw pairs of that many channels as load_group leaves them (taken apart here).
+template <int PROBE, bool GEN, int RAW, class LDS>
 __device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, uint32_t lane,
-                                              const uint32_t (&px)[kGroupSteps], const uint32_t (&pv)[kGroupSteps],
-                                              uint32_t nx_px, uint32_t nx_pv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase) {
+                                              const uint32_t (&rx)[kGroupSteps], const uint32_t (&rv)[kGroupSteps],
+                                              uint32_t nx_rx, uint32_t nx_rv, int rem, u64& E, uint32_t& ccp, uint32_t& vbase) {
+    // (a step's pair is taken apart one step ahead of its use - the edges of step t + 1 are wanted in step t - and not before:
+    // eight unpacked pairs beside the eight raw ones cost the generic 3-channel instantiation a register spill)
+    auto pair_at = [&](int t, uint32_t& px, uint32_t& pv) {
+        const uint32_t a = t < kGroupSteps ? rx[t < kGroupSteps ? t : 0] : nx_rx, b = t < kGroupSteps ? rv[t < kGroupSteps ? t : 0] : nx_rv;
+        if constexpr (RAW == 3) unpack_pair<3>(a, b, px, pv); else { px = a; pv = b; }
+    };
     if (GEN) E &= lanes_upto(rem);                         // (the group before this one does not know where the image ends)
     PairClass K = {0u, 0u, 0u, 0u, 0u};
+    uint32_t cpx, cpv, npx, npv;
+    pair_at(0, cpx, cpv);
 #pragma unroll
     for (int t = 0; t < kGroupSteps; ++t) {
         const u64 Ec = E;
@@ -554,36 +591,21 @@ __device__ __forceinline__ void process_group(LDS& L, const LaneConst& C, uint32
             lastbit = (r >= 1 && r <= 64) ? 1ull << (r - 1) : 0ull;
         }
         // edges of the next step (its lane 0 tells lane 63 whether its run ends here)
-        if (t + 1 < kGroupSteps) E = __ballot(px[t + 1] != pv[t + 1]);
-        else E = __ballot(nx_px != nx_pv);
+        pair_at(t + 1, npx, npv);
+        E = __ballot(npx != npv);
         if (GEN) E &= lanes_upto(rem - (t + 1) * 64);
         const u64 nb63 = E << 63;
-        if ((t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, px[t], pv[t], px[t + 1], pv[t + 1]);   // this step and the next one
-        if (GEN && V == 0ull) continue;
-        if (t & 1) encode_step<PROBE, GEN, 1>(L, C, lane, px[t], pv[t], K, Ec, nb63, V, lastbit, ccp, vbase);
-        else encode_step<PROBE, GEN, 0>(L, C, lane, px[t], pv[t], K, Ec, nb63, V, lastbit, ccp, vbase);
+        if ((t & 1) == 0 && (Ec | E) != 0ull) classify_pair(K, cpx, cpv, npx, npv);   // this step and the next one
+        if (!(GEN && V == 0ull)) {
+            if (t & 1) encode_step<PROBE, GEN, 1>(L, C, lane, cpx, cpv, K, Ec, nb63, V, lastbit, ccp, vbase);
+            else encode_step<PROBE, GEN, 0>(L, C, lane, cpx, cpv, K, Ec, nb63, V, lastbit, ccp, vbase);
+        }
+        cpx = npx; cpv = npv;
     }
 }
 
-// pixels base + 64 t + lane and the pixels before them, t = 0..kGroupSteps-1, of a group that lies inside the image and
-// does not hold its first pixel: no bounds checks, one 64-bit address, the 16 loads differ in their immediate offsets only
-// (previous pixel, pixel) k pixels from q in ONE load.  4 channels: the eight bytes from q + 4k - 4.  3 channels: the eight bytes
-// from q + 3k - 3 (no alignment at all: global loads take it) - the previous pixel is the low three, the pixel the next three,
-// alpha 255 (qoi.h:399-400,411-413: `a` keeps its start value); 3 vector instructions per step instead of six byte loads and
-// their merging (a 3-channel batch took 2.1 x the time of the same frames with four channels).  The load touches two bytes
-// behind the pixel: callers use it for pixels that are not the image's last one.
-template <int CH>
-__device__ __forceinline__ void load_pair_at(const uint8_t* __restrict__ q, int k, uint32_t& px, uint32_t& pv) {
-    if constexpr (CH == 4) {
-        px = reinterpret_cast<const uint32_t*>(q)[k];
-        pv = reinterpret_cast<const uint32_t*>(q)[k - 1];
-    } else {
-        struct __attribute__((packed, aligned(1))) U2 { uint32_t x, y; };
-        const U2 v = *reinterpret_cast<const U2*>(q + k * 3 - 3);
-        pv = v.x | 0xFF000000u;
-        px = __builtin_amdgcn_alignbit(v.y, v.x, 24) | 0xFF000000u;
-    }
-}
+// pixels base + 64 t + lane and the pixels before them, t = 0..kGroupSteps-1, of a group that lies inside the image and does not
+// hold its first pixel, as RAW pairs: no bounds checks, one 64-bit address, the loads differ in their immediate offsets only
 template <int CH>
 __device__ __forceinline__ void load_group(const uint8_t* __restrict__ pix, uint32_t base, uint32_t lane,
                                            uint32_t (&px)[kGroupSteps], uint32_t (&pv)[kGroupSteps]) {
@@ -633,8 +655,9 @@ __device__ __forceinline__ bool warm_entry_state(const uint8_t* __restrict__ pix
 #pragma unroll
     for (int k = kWarmBatch - 1; k >= 0; --k) {
         const int base = (int)lo - 64 * (k + 1);
-        const uint32_t px = in.warm[k];
-        const u64 E = __ballot(px != in.warm_prev[k]);
+        uint32_t px, pvw;
+        unpack_pair<CH>(in.warm[k], in.warm_prev[k], px, pvw);
+        const u64 E = __ballot(px != pvw);
         if (E) {
             last_edge = base + msb64(E);
             (void)probe_swap((__builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false) & 0xFCu) | tbase, px, E);
@@ -867,7 +890,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 
     uint32_t g = 0;
     if (nint) {
-        u64 E = __ballot(ax[0] != av[0]);
+        u64 E;
+        { uint32_t p0, v0; unpack_pair<CH>(ax[0], av[0], p0, v0); E = __ballot(p0 != v0); }
         // ---- two groups per turn: while one is encoded the loads of the next are in flight ----------------------------
         // (the pair loaded when no group follows inside the loop: the two pixels around the end of the set, or around the
         // start of the image's last group - every lane reads the same two, only "is the next pixel an edge" is taken from them)
@@ -878,8 +902,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
                 if (spos > LDS::kSpill) { need_slot(); vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane); }
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, bx, bv);
-                else { bx[0] = load_px<CH>(pix, base + kGroupPx); bv[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
-                process_group<PROBE, false>(L, C, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
+                else { pack_pair<CH>(load_px<CH>(pix, base + kGroupPx), load_px<CH>(pix, base + kGroupPx - 1u), bx[0], bv[0]); if (!last_set) ask_early(); }
+                process_group<PROBE, false, CH>(L, C, lane, ax, av, bx[0], bv[0], 0, E, ccp, vbase);
                 if (++g >= nint) break;
             }
             {   // group g sits in b*; fetch g+1 into a*
@@ -887,8 +911,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 const uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
                 if (spos > LDS::kSpill) { need_slot(); vbase = sbase + spill_stage<PROBE>(L, slot, spilled, spos, false, lane); }
                 if (g + 1u < nint) load_group<CH>(pix, base + kGroupPx, lane, ax, av);
-                else { ax[0] = load_px<CH>(pix, base + kGroupPx); av[0] = load_px<CH>(pix, base + kGroupPx - 1u); if (!last_set) ask_early(); }
-                process_group<PROBE, false>(L, C, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
+                else { pack_pair<CH>(load_px<CH>(pix, base + kGroupPx), load_px<CH>(pix, base + kGroupPx - 1u), ax[0], av[0]); if (!last_set) ask_early(); }
+                process_group<PROBE, false, CH>(L, C, lane, bx, bv, ax[0], av[0], 0, E, ccp, vbase);
                 if (++g >= nint) break;
             }
         }
@@ -906,7 +930,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         load_pair_guarded<CH>(pix, base + kGroupPx + lane, n, nxp, nxv);
         if (g + 1u == ngroups) ask_early();
         u64 E = __ballot(ax[0] != av[0]);
-        process_group<PROBE, true>(L, C, lane, ax, av, nxp, nxv, (int)(n - base), E, ccp, vbase);
+        process_group<PROBE, true, 0>(L, C, lane, ax, av, nxp, nxv, (int)(n - base), E, ccp, vbase);
     }
     uint32_t spos = (uint32_t)__builtin_amdgcn_readfirstlane((int)vbase) - sbase;
     const uint32_t set_bytes = spilled + spos;
@@ -999,7 +1023,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 // flagged.  A workgroup serves unit u = (image u % n_images, four consecutive sets u / n_images) so that the
 // sets in flight spread over all images.
 template <int CH, int PROBE, int ENTRY>
-__global__ __launch_bounds__(256, PROBE == 1 ? QOIMI_ENC_WAVES_PER_SIMD : 4) void enc_sets(EncParams p) {
+// (the generic 3-channel form - flat 3-channel images only - takes a register more than six wavefronts per SIMD leave it: five)
+__global__ __launch_bounds__(256, PROBE == 1 ? (CH == 3 && ENTRY == 0 ? QOIMI_ENC_WAVES_PER_SIMD - 1 : QOIMI_ENC_WAVES_PER_SIMD) : 4) void enc_sets(EncParams p) {
     __shared__ EncLdsFor<PROBE> s_lds[4];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;

@@ -563,7 +563,7 @@ def _mixed_frame(rng, w, h, ch, seed):
 @pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_SET_SLABS": "3"}, {"QOIMI_ENC_SET_SLABS": "8"}, {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
                                  {"QOIMI_ENC_SPREAD": "0"}, {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "3"}])
 def test_mixed_content_partial_spills(api, oracle, env):
-    """Sets whose bytes only partly fit the LDS staging buffer (tools/dev/sweep_enc.py is the long form of this test)."""
+    """Sets whose bytes only partly fit the LDS staging buffer ."""
     import torch
     from gpu_util import DeviceBatch
     old = {k: os.environ.get(k) for k in env}

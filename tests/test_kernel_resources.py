@@ -36,7 +36,10 @@ def test_no_kernel_spills(kernels):
 @pytest.mark.parametrize("entry", [0, 1])
 def test_encoder_hot_kernel_keeps_six_wavefronts_per_simd(kernels, ch, entry):
     k = _one(kernels, f"enc_setsILi{ch}ELi1ELi{entry}EE")              # exchange probe: the default
-    assert k["vgpr"] <= 80 and k["agpr"] == 0, k                       # 512 / 6 = 85 -> 80 at the allocation granule
+    if (ch, entry) == (3, 0):                                          # flat 3-channel images only: five wavefronts per SIMD
+        assert k["vgpr"] <= 96 and k["agpr"] == 0, k
+    else:
+        assert k["vgpr"] <= 80 and k["agpr"] == 0, k                   # 512 / 6 = 85 -> 80 at the allocation granule
     assert 6 * k["lds"] <= LDS_PER_CU, k                               # six workgroups of four wavefronts per CU
 
 
@@ -48,3 +51,22 @@ def test_decoder_passes_keep_their_workgroups_per_cu(kernels):
     for och in (3, 4):
         p4 = _one(kernels, f"dec_segments_recILi{och}E")
         assert 6 * p4["lds"] <= LDS_PER_CU and p4["vgpr"] <= 128, p4   # six per CU
+
+
+@pytest.mark.parametrize("ch", [3, 4])
+def test_encoder_keeps_its_pixel_prefetch(ch):
+    """enc_sets asks for a group's sixteen pixel pairs a group ahead and waits for them one by one as the steps reach them:
+    `s_waitcnt vmcnt(N)` with N counting down through the group.  Whether the compiler keeps that shape has hung on unrelated
+    code twice (round 3: a refill at the top of the loop; round 4: a branch with vector-memory operations in the group loop made
+    every 3-channel load wait for itself, -31 % on 3-channel batches, invisible to every parity test).  The disassembly of the
+    built library must show the staggered waits."""
+    import re
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(LIB) and os.path.exists(objdump)):
+        pytest.skip("needs the built library and llvm-objdump")
+    dis = KR.disassembly(LIB, objdump)
+    name = [k for k in dis if f"enc_setsILi{ch}ELi1ELi1EE" in k]
+    assert len(name) == 1, [k for k in dis if "enc_sets" in k]
+    waits = [int(m.group(1)) for l in dis[name[0]] for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m]
+    deep = [w for w in waits if w >= 3]
+    assert len(deep) >= 16, (len(waits), sorted(set(waits)))          # two groups of eight steps in the pipelined loop

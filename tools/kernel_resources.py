@@ -58,6 +58,31 @@ def kernels(path: str) -> dict:
     return out
 
 
+def disassembly(path: str, objdump: str = '/opt/rocm/lib/llvm/bin/llvm-objdump') -> dict:
+    """kernel symbol -> list of its instruction lines (llvm-objdump -d of the library's gfx950 code objects)"""
+    import os
+    import re
+    import subprocess
+    import tempfile
+    out = {}
+    blob = open(path, 'rb').read()
+    for elf in code_objects(blob):
+        with tempfile.NamedTemporaryFile(suffix='.co', delete=False) as f:
+            f.write(elf)
+        try:
+            text = subprocess.run([objdump, '-d', '--no-show-raw-insn', f.name], capture_output=True, text=True, check=True).stdout
+        finally:
+            os.unlink(f.name)
+        cur = None
+        for line in text.split('\n'):
+            m = re.match(r'^[0-9a-f]+ <([^>]+)>:', line)
+            if m:
+                cur = out.setdefault(m.group(1), [])
+            elif cur is not None and line.strip():
+                cur.append(line.strip())
+    return out
+
+
 if __name__ == '__main__':
     ks = kernels(sys.argv[1] if len(sys.argv) > 1 else 'qoi_amd/lib/libqoi_mi355x.so')
     for n in sorted(ks):

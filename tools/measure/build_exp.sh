@@ -1,6 +1,6 @@
 #!/bin/bash
 # Experimental build of the library with one source compiled with extra defines: build/exp_<name>/libqoi_mi355x.so
-# usage: tools/dev/build_exp.sh <name> <enc|dec|host> <flags...>      (the other objects come from qoi_amd/lib/obj: run make first)
+# usage: tools/measure/build_exp.sh <name> <enc|dec|host> <flags...>      (the other objects come from qoi_amd/lib/obj: run make first)
 set -e
 R="$(cd "$(dirname "$0")/../.." && pwd)"; name=$1; what=$2; shift 2
 case $what in enc) src=qoi_encode;; dec) src=qoi_decode;; host) src=qoi_host;; *) echo "enc|dec|host"; exit 2;; esac

@@ -1,7 +1,7 @@
 #!/bin/bash
 # effective shader clock under the encode / decode kernels: GRBM_GUI_ACTIVE (cycles the GPU was busy) per kernel against its duration
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out/${1:-clk}; mkdir -p $OUT; export TMPDIR=/tmp PYTHONUNBUFFERED=1
-(cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OLDPWD/$OUT/enc -o pmc -- python $OLDPWD/tools/dev/enc_time.py - 256) > $OUT/enc.log 2>&1; echo "enc rc=$?"
+(cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OLDPWD/$OUT/enc -o pmc -- python $OLDPWD/tools/measure/enc_time.py - 256) > $OUT/enc.log 2>&1; echo "enc rc=$?"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OLDPWD/$OUT/dec -o pmc -- python $OLDPWD/bench.py --frames 256 --steps 3 --warmup 1 --no-cpu --no-others --no-single --no-configs) > $OUT/dec.log 2>&1; echo "dec rc=$?"
 python - $OUT <<'PY'
 import csv, glob, sys, collections

@@ -1,4 +1,4 @@
-"""Where a wavefront of enc_sets spends its life: python tools/dev/enc_phases.py <lib built with -DQOIMI_ENC_PHASES> [frames]
+"""Where a wavefront of enc_sets spends its life: python tools/measure/enc_phases.py <lib built with -DQOIMI_ENC_PHASES> [frames]
 (build: see the comment at g_enc_phase in qoi_amd/csrc/qoi_encode.hip; the library is a diagnostic build, never the product)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,4 +1,4 @@
-"""Encode-only timing of one library build: python tools/dev/enc_time.py <libqoi_mi355x.so> [frames] - per-kernel ms of
+"""Encode-only timing of one library build: python tools/measure/enc_time.py <libqoi_mi355x.so> [frames] - per-kernel ms of
 qoimi_encode_batch on 4K photo frames (no checks: for builds whose bytes are wrong on purpose)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

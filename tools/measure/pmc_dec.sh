@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the decoder's kernels (bench.py, 256 x 4K photo frames), two passes: LDS side, issue side.  usage: bash tools/gpu_pmc_dec.sh outdir
+# SQ counters of the decoder's kernels (bench.py, 256 x 4K photo frames), two passes: LDS side, issue side.  usage: bash tools/measure/pmc_dec.sh outdir
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out/${1:-pmcdec}; mkdir -p $OUT; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \

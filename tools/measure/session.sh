@@ -39,8 +39,8 @@ for k in sorted(rows):
         if v:
             e[c + '_KB'] = round(sum(v) / len(v), 1); e['launches_averaged'] = len(v)
     kern[k] = e
-doc = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu --no-others --no-single --no-configs (two separate passes, tools/gpu_session.sh)",
-       "frames": 1024,
+doc = {"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu --no-others --no-single --no-configs (two separate passes, tools/measure/session.sh)",
+       "frames": 1024, "commit": (open('build/HEAD').read().strip() if __import__('os').path.exists('build/HEAD') else 'not recorded'),
        "note": "per-launch means over the batch launches (largest grid of each kernel); KB as rocprofv3 reports them. gfx950: FETCH_SIZE tallies 128-byte read requests at 64 bytes (MI355X_MICROARCH.md HBM section); calibration: enc_slab_summary is a pure streaming read of every pixel byte of the batch, its FETCH_SIZE comes out at ~0.5 x those bytes -> read bytes = 2 x FETCH_SIZE. WRITE_SIZE is taken as reported.",
        "read_correction": 2.0, "kernels": kern}
 json.dump(doc, open(out + '/pmc_traffic.json', 'w'), indent=1)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Diagnostic: N single-frame encode + decode calls (device-resident 4K photo frame) for a rocprofv3 --kernel-trace run.
-usage (GPU box): rocprofv3 --kernel-trace --output-format csv -d OUT -o t -- python tools/dev/single_trace.py [reps]"""
+usage (GPU box): rocprofv3 --kernel-trace --output-format csv -d OUT -o t -- python tools/measure/single_trace.py [reps]"""
 import os
 import sys
 import time
