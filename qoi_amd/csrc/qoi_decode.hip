@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     {   const uint32_t i8 = byte0_times8(w32);
         const u32x2v te = *(lds_u32x2*)(lut_base + (active ? i8 : 2048u)); tpl = te.x; info = te.y; }
     uint32_t a_abs = 0u, a_last = 0u;            // a QOI_OP_RGBA occurred in the segment / the alpha of the last one (for dec_slot_tails)
-    uint32_t pend = 0u;                          // 1: the stash record of the QOI_OP_RGBA chunk under the cursor is out
+    uint32_t pend = 0u;                          // 1 / 2: the first record of the QOI_OP_RGBA / QOI_OP_RGB chunk under the cursor is out
     bool any_pend = false;
     uint32_t ngran = 0u, npix = 0u;
     // granule row g of this wavefront's 64 segments: one contiguous KiB
@@ -1261,17 +1261,30 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                 add_byte0(rec, er); add_byte2_from0(rec, eb);
                 uint32_t cnt = (rec >> 24) & 63u;                        // pixels of the chunk (qoi.h:573-575); the stash marker is set right below
                 if (lanes_where(lut_hi(c_info)) != 0 || any_pend) {     // QOI_OP_RGB / QOI_OP_RGBA somewhere in the wavefront (rare in natural images)
+                    // These chunks leave a PAIR of records that begins on an even record index of the segment (u is a compile-time
+                    // constant here): QOI_OP_RGBA = (stash half, alpha half), QOI_OP_RGB = (the record, a null record); a chunk met on
+                    // an odd index leaves a null record first.  The chunk stays under the cursor until its second record is out.  So
+                    // P3 / P4 can take RGBA-dense content - noise, sprites with many alpha levels - a pair at a time, whatever mix of
+                    // the two ops the lanes hold (dec_summarize_rec, dec_segments_rec: "a block of pairs"); a null record is a no-op
+                    // anywhere but in front of a stream's first chunk, and index 0 is even.
                     const bool hi = lut_hi(c_info), lo = lut_lo(c_info);
-                    const bool rgba = hi && lo, second = rgba && pend != 0u, first = rgba && pend == 0u;
+                    const bool rgba = hi && lo;
                     const uint32_t rgb = (w32 >> 8) & 0x00FFFFFFu;
                     const uint32_t b5 = (b5hi >> (b5sh & 24u)) & 0xFFu;                      // chunk byte 4: the alpha of a QOI_OP_RGBA
-                    const uint32_t rec_hi = second ? rec_make(3u, 1u, b5) : (rec | rgb);      // rec still is the class-2 template here
-                    rec = hi ? rec_hi : rec;
-                    adv = second ? 5u : adv;
-                    cnt = first ? 0u : (second ? 1u : cnt);
-                    a_abs = second ? 1u : a_abs;
-                    a_last = second ? b5 : a_last;
-                    pend = first ? 1u : 0u;
+                    if ((u & 1u) == 0u) {                                                    // a pair begins (no lane has one pending here)
+                        rec = hi ? (rec | rgb) : rec;                                        // rec still is the class-2 template: stash marker / one pixel
+                        adv = hi ? 0u : adv;
+                        cnt = rgba ? 0u : cnt;
+                        pend = hi ? (lo ? 1u : 2u) : 0u;
+                    } else {
+                        const bool second_rgba = pend == 1u, second_rgb = pend == 2u, stall = hi && pend == 0u;
+                        rec = second_rgba ? rec_make(3u, 1u, b5) : ((second_rgb || stall) ? 0u : rec);
+                        adv = second_rgba ? 5u : (second_rgb ? 4u : (stall ? 0u : adv));
+                        cnt = second_rgba ? 1u : ((second_rgb || stall) ? 0u : cnt);
+                        a_abs = second_rgba ? 1u : a_abs;
+                        a_last = second_rgba ? b5 : a_last;
+                        pend = 0u;
+                    }
                     any_pend = lanes_where(pend != 0u) != 0;
                 }
                 npix += cnt;
@@ -1397,6 +1410,9 @@ __device__ __forceinline__ uint32_t and_or_b32(uint32_t a, uint32_t m, uint32_t 
     return r;
 }
 // code byte of the plain form (dec_summarize_rec): source 0..64, bit 7 = r,g,b absolute -> the general form's code
+// records of a PAIR (dec_transcode puts QOI_OP_RGB / QOI_OP_RGBA on even record indices): its first is class 2 or null, its second class 3 or null
+__device__ __forceinline__ bool pair_head(uint32_t r) { return (r >> 30) == 2u || r == 0u; }
+__device__ __forceinline__ bool pair_tail(uint32_t r) { return r >= 0xC0000000u || r == 0u; }
 __device__ __forceinline__ uint32_t plain_code_general(uint32_t c) { return (c & 0x80u) ? (c & 0x7Fu) + kSymCodeRgb : c; }
 template <bool REFINE>
 __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
@@ -1536,6 +1552,27 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
                 }
             };
             if (lanes_where((int32_t)any < 0) == 0) plain_block(std::false_type{}); else plain_block(std::true_type{});
+        } else if (!REFINE && lanes_where(!(pair_head(rc[0]) && pair_tail(rc[1]) && pair_head(rc[2]) && pair_tail(rc[3]) &&
+                                            pair_head(rc[4]) && pair_tail(rc[5]) && pair_head(rc[6]) && pair_tail(rc[7]))) == 0) {
+            // ---- a block of PAIRS in every lane: (stash half, alpha half) = QOI_OP_RGBA, (record, null) = QOI_OP_RGB, (null, null) -
+            // RGBA-dense content (noise, sprites with many alpha levels); the transcoder puts these chunks on even record indices
+            // for this.  Such a chunk names r,g,b - and with QOI_OP_RGBA the alpha - absolutely (qoi.h:547-557): nothing is read from
+            // the table, a pair is a dozen vector instructions instead of two passes through the rare body below.  Same function
+            // of the records as those: RGBA sets pc = r,g,b | a << 24, code = all absolute, alpha = a; RGB sets r,g,b and keeps alpha
+            // and its code; both name the slot QOI_COLOR_HASH; a null pair stores the running word where it already stands.
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u += 2u) {
+                const uint32_t rs = rc[u], ra = rc[u + 1u];
+                const bool real = rs != 0u, is_a = ra != 0u;
+                const uint32_t npc = (rs & 0x00FFFFFFu) | (is_a ? (ra << 24) : (pc & 0xFF000000u));
+                const uint32_t hb = ph < kSymCodeRgb ? ph + kSymCodeRgb : ph;
+                ph = is_a ? kSymCodeAbs : (real ? hb : ph);
+                alpha = is_a ? (ra & 0xFFu) : alpha;
+                pc = real ? npc : pc;
+                slot = (real ? __builtin_amdgcn_udot4(pc, 0x00070503u, 0u, false) + 11u * alpha : slot) & 63u;
+                *(lds_u32*)(tc_base + (slot << 8)) = pc;                   // index update after every chunk (qoi.h:577)
+                *(lds_u8*)symcode_addr(tm_lane, slot) = (uint8_t)ph;
+            }
         } else {
 #pragma unroll
             for (uint32_t u = 0; u < 8u; ++u) {
@@ -1802,6 +1839,27 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
             unsigned long long hm[8], lm[8];
 #pragma unroll
             for (uint32_t u = 0; u < 8u; ++u) { hm[u] = __ballot((int32_t)rc[u] < 0); lm[u] = __ballot((rc[u] & 0x3F000000u) > 0x02000000u); }
+            // A block of PAIRS in every lane - (stash half, alpha half) = QOI_OP_RGBA, (record, null) = QOI_OP_RGB, (null, null) - is
+            // RGBA-dense content (see the same test in dec_summarize_rec): the pair names r,g,b and perhaps alpha absolutely
+            // (qoi.h:547-557), one short step per pair instead of two passes through the rare body.  Looked for only where the
+            // block's first record is such a chunk in some lane, so photographs never pay for the question.
+            if (__builtin_expect(hm[0] != 0ull, 0) &&
+                lanes_where(!(pair_head(rc[0]) && pair_tail(rc[1]) && pair_head(rc[2]) && pair_tail(rc[3]) &&
+                              pair_head(rc[4]) && pair_tail(rc[5]) && pair_head(rc[6]) && pair_tail(rc[7]))) == 0) {
+#pragma unroll
+                for (uint32_t u = 0; u < 8u; u += 2u) {
+                    const uint32_t rs = rc[u], ra = rc[u + 1u];
+                    bool real = rs != 0u;
+                    if (CLIP) real = real && W.ppos < limit;              // at the pixel limit the decoder has stopped (qoi.h:540)
+                    const uint32_t npx = (rs & 0x00FFFFFFu) | (ra != 0u ? (ra << 24) : (px & 0xFF000000u));
+                    px = real ? npx : px;
+                    const uint32_t h = __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false);
+                    *(lds_u32*)(((h << 8) & 0x3F00u) | tab_base) = px;    // qoi.h:577
+                    W.put2n(px, real ? 1u : 0u);
+                }
+                ring[2u * d] = S.granule(2u * (blk + kDepth)); ring[2u * d + 1u] = S.granule(2u * (blk + kDepth) + 1u);
+                return;
+            }
 #pragma unroll
             for (uint32_t u = 0; u < 8u; ++u) {
                 if (kDrainEvery < 8u && u == 4u) W.drain_block();

@@ -536,15 +536,17 @@ QOIMI_HD uint32_t decode_segment_fast(const uint8_t* in, uint32_t pos, uint32_t 
 //                                    else happens (no pixel, the table is left exactly as it is)
 //                       3 ALPHA      second half of QOI_OP_RGBA: pixel = stashed r,g,b + payload byte 0 as alpha;
 //                                    one pixel, table updated                                       (qoi.h:552-557)
-// A record of 0 is the null record (padding of a segment's last granule, lanes that are through): relative, delta
+// QOI_OP_RGB and QOI_OP_RGBA leave PAIRS of records on even indices: (class 2, null) and (stash, alpha) - see dec_transcode.
+// A record of 0 is the null record (padding of a segment's last granule, pair padding, lanes that are through): relative, delta
 // 0, no pixels - it re-stores the running pixel where it already is (index[hash(px)] == px after every chunk).
 // The stash half must be a true no-op instead: as a stream's FIRST chunk the start pixel {0,0,0,255} is not in the
 // table yet and must not be put there.
 // =====================================================================================
 constexpr uint32_t kRecStash = 63u;
 // Records a segment of B stream bytes can hold, padded to whole granules of 4: one per byte at most (every chunk of one
-// byte) - plus ONE, because a QOI_OP_RGBA chunk that starts on the segment's last byte still leaves both of its records.
-QOIMI_HD uint32_t rec_region_dwords(uint32_t B) { return (B + 1u + 3u) & ~3u; }
+// byte; a QOI_OP_RGB / QOI_OP_RGBA with its pair padding leaves three at most for four / five bytes) - plus TWO, because such a
+// chunk that starts on the segment's last byte still leaves all of its records.
+QOIMI_HD uint32_t rec_region_dwords(uint32_t B) { return (B + 2u + 3u) & ~3u; }
 QOIMI_HD uint32_t rec_class(uint32_t r) { return r >> 30; }
 QOIMI_HD uint32_t rec_pixels(uint32_t r) { return (r >> 24) & 63u; }
 QOIMI_HD uint32_t rec_make(uint32_t cls, uint32_t npx, uint32_t payload) { return (cls << 30) | (npx << 24) | (payload & 0x00FFFFFFu); }
@@ -619,7 +621,11 @@ QOIMI_HD uint32_t transcode_segment(const uint8_t* in, uint32_t pos, uint32_t se
         const unsigned long long w = load8(in + pos);
         uint32_t two[2];
         const uint32_t k = rec_of_chunk(w, two);
-        recs[n++] = two[0]; if (k == 2u) recs[n++] = two[1];
+        // QOI_OP_RGB / QOI_OP_RGBA leave a PAIR of records that begins on an even index: (record, null) / (stash half, alpha half),
+        // behind a null record where the chunk is met on an odd index (dec_transcode does the same; see there)
+        const bool hi = ((uint32_t)w & 0xFEu) == 0xFEu;
+        if (hi && (n & 1u)) recs[n++] = 0u;
+        recs[n++] = two[0]; if (k == 2u) recs[n++] = two[1]; else if (hi) recs[n++] = 0u;
         uint32_t w32, b5; R.peek(pos, w32, b5);
         { const uint32_t info = lut.info[w32 & 0xFFu]; slotf_step_split(s, w32, b5, info, lut_hi(info)); }
         pos += len_of(w32 & 0xFFu);

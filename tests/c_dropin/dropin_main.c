@@ -4,8 +4,9 @@
  *
  *   dropin roundtrip W H C     encode + decode + memcmp (qoibench.c:408-417), then qoi_write + qoi_read + memcmp
  *                              (the call pattern of qoiconv.c:60,76); prints "ok <stream bytes> <crc32 of the stream>"
- *   dropin fuzz FILE           the body of qoifuzz.c:20-32: first four bytes = channels argument, the rest a stream;
- *                              prints "null" or "<w> <h> <channels> <colorspace> <crc32 of the pixels>"
+ *   dropin fuzz FILE...        the body of qoifuzz.c:20-32 per file: first four bytes = channels argument, the rest a stream;
+ *                              prints one line per file: "null" or "<w> <h> <channels> <colorspace> <crc32 of the pixels>"
+ *                              (many files per process: a process start costs a HIP initialisation, seconds on some boxes)
  *   dropin header              which header this binary was compiled against
  */
 #include <stdio.h>
@@ -92,7 +93,10 @@ static int fuzz(const char *file) {
 int main(int argc, char **argv) {
     if (argc >= 2 && strcmp(argv[1], "header") == 0) { printf("%s\n", QOI_HEADER_NAME); return 0; }
     if (argc >= 5 && strcmp(argv[1], "roundtrip") == 0) return roundtrip((unsigned)atoi(argv[2]), (unsigned)atoi(argv[3]), atoi(argv[4]));
-    if (argc >= 3 && strcmp(argv[1], "fuzz") == 0) return fuzz(argv[2]);
-    fprintf(stderr, "usage: dropin roundtrip W H C | fuzz FILE | header\n");
+    if (argc >= 3 && strcmp(argv[1], "fuzz") == 0) {
+        for (int i = 2; i < argc; ++i) { const int rc = fuzz(argv[i]); if (rc) return rc; }
+        return 0;
+    }
+    fprintf(stderr, "usage: dropin roundtrip W H C | fuzz FILE... | header\n");
     return 2;
 }

@@ -249,3 +249,38 @@ def dense_record_streams():
             h = (npx + w - 1) // w + 1              # a few pixels past the last chunk: filled with the last pixel (qoi.h:544)
             stream = b"qoif" + struct.pack(">II", w, h) + bytes([4, 0]) + bytes(body) + bytes([0, 0, 0, 0, 0, 0, 0, 1])
             yield f"dense_B{B}_lead{lead}", B, stream, w, h
+
+
+def pair_streams():
+    """Streams dense in QOI_OP_RGB / QOI_OP_RGBA, the chunks the transcoder lays out as PAIRS of records on even record
+    indices (dec_transcode): all of them such chunks (every block of every lane takes the pair path of P3 / P4), nearly all
+    (blocks fall back to the general steps at random, pairs are pushed to the next even index by one-byte chunks), half.
+    Yields (name, stream, width, height)."""
+    import struct
+    for seed, p_hi, p_rgba, n_chunks in ((1, 1.0, 1.0, 40000), (2, 1.0, 0.5, 40000), (3, 1.0, 0.0, 40000), (4, 0.97, 0.7, 40000),
+                                         (5, 0.5, 0.5, 60000), (6, 0.9, 0.2, 300000)):
+        rng = np.random.default_rng(seed)
+        body = bytearray()
+        npx = 0
+        kinds = rng.random(n_chunks)
+        sub = rng.random(n_chunks)
+        val = rng.integers(0, 256, size=(n_chunks, 4))
+        for i in range(n_chunks):
+            if kinds[i] < p_hi:
+                if sub[i] < p_rgba:
+                    body += bytes([0xFF, val[i, 0], val[i, 1], val[i, 2], val[i, 3]])
+                else:
+                    body += bytes([0xFE, val[i, 0], val[i, 1], val[i, 2]])
+                npx += 1
+            elif sub[i] < 0.3:
+                body.append(val[i, 0] & 0x3F); npx += 1                        # INDEX
+            elif sub[i] < 0.6:
+                body.append(0x40 | (val[i, 0] & 0x3F)); npx += 1                 # DIFF
+            elif sub[i] < 0.8:
+                body += bytes([0x80 | (val[i, 0] & 0x3F), val[i, 1]]); npx += 1  # LUMA
+            else:
+                r = val[i, 0] % 62
+                body.append(0xC0 | r); npx += r + 1                              # RUN
+        w = 97
+        h = (npx + w - 1) // w + 1
+        yield (f"pairs_seed{seed}", b"qoif" + struct.pack(">II", w, h) + bytes([4, 0]) + bytes(body) + bytes([0, 0, 0, 0, 0, 0, 0, 1]), w, h)

@@ -124,6 +124,29 @@ def test_decode_record_dense_segments(api, oracle):
             del os.environ["QOIMI_SEG_BYTES"]
 
 
+@pytest.mark.parametrize("seg", [None, "64", "128"])
+def test_decode_record_pairs(api, oracle, seg):
+    """QOI_OP_RGB / QOI_OP_RGBA become pairs of records on even record indices and P3 / P4 take blocks of pairs on a short path
+    (cases.pair_streams): all-pair streams, pairs displaced by one-byte chunks, mixtures - 3- and 4-channel output."""
+    import torch
+    if seg is not None:
+        os.environ["QOIMI_SEG_BYTES"] = seg
+    try:
+        c = api.Context(0)
+        for name, stream, w, h in cases.pair_streams():
+            s = torch.from_numpy(np.frombuffer(stream + b"\0" * 8, dtype=np.uint8).copy()).cuda()
+            for och in (4, 3):
+                want, _ = oracle.decode(stream, och)
+                out = torch.full((w * h * och + 8,), 0xAB, dtype=torch.uint8, device="cuda")
+                c.decode_batch(s.data_ptr(), s.numel(), [len(stream)], [api.QoiDesc(w, h, 4, 0)], och, out.data_ptr(), w * h * och)
+                assert np.array_equal(out[:w * h * och].cpu().numpy(), want), (name, och)
+                assert int(out[w * h * och]) == 0xAB, "wrote past the image"
+        c.close()
+    finally:
+        if seg is not None:
+            del os.environ["QOIMI_SEG_BYTES"]
+
+
 def test_round_trip_random_host_api(api, oracle):
     rng = np.random.default_rng(7)
     for it in range(40):
