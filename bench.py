@@ -206,8 +206,16 @@ def dropin_path(torch, api, ctx, pixels, w, h, dev) -> dict:
         return {"error": "qoi_encode failed"}
     stream_bytes = ctypes.string_at(p, n.value); free(p)
     sbuf = (ctypes.c_ubyte * len(stream_bytes)).from_buffer_copy(stream_bytes)
+    # qoibench's pattern (qoibench.c:446-449, 471-475): the result is free()d inside the timed region, so the next call's malloc
+    # gets the same pages back from glibc (a 31.6 MiB chunk is below the allocator's 32 MiB ceiling for its dynamic mmap
+    # threshold).  "results_kept": the caller keeps every result, each call's malloc is untouched address space whose pages the
+    # kernel zero-fills inside the call.
+    def enc_free():
+        q = enc(host_px.ctypes.data, ctypes.byref(desc), ctypes.byref(n)); free(q)
+    enc_free()
+    t_enc = best(enc_free)
     outs = []
-    t_enc = best(lambda: outs.append(enc(host_px.ctypes.data, ctypes.byref(desc), ctypes.byref(n))))
+    t_enc_kept = best(lambda: outs.append(enc(host_px.ctypes.data, ctypes.byref(desc), ctypes.byref(n))))
     for q in outs:
         free(q)
     d = api.QoiDesc()
@@ -215,8 +223,13 @@ def dropin_path(torch, api, ctx, pixels, w, h, dev) -> dict:
     ok = bool(q) and np.array_equal(np.frombuffer(ctypes.string_at(q, npx * 4), dtype=np.uint8), host_px)
     if q:
         free(q)
+
+    def dec_free():
+        q = dec(ctypes.addressof(sbuf), len(stream_bytes), ctypes.byref(d), 4); free(q)
+    dec_free()
+    t_dec = best(dec_free)
     outs = []
-    t_dec = best(lambda: outs.append(dec(ctypes.addressof(sbuf), len(stream_bytes), ctypes.byref(d), 4)))
+    t_dec_kept = best(lambda: outs.append(dec(ctypes.addressof(sbuf), len(stream_bytes), ctypes.byref(d), 4)))
     for q in outs:
         free(q)
     # the copies alone: pageable host <-> device, same sizes
@@ -229,8 +242,11 @@ def dropin_path(torch, api, ctx, pixels, w, h, dev) -> dict:
     sync(lambda: dpx.copy_(hpx)); sync(lambda: hst2.copy_(dst))
     c_enc = best(lambda: sync(lambda: (dpx.copy_(hpx), hst2.copy_(dst))))
     c_dec = best(lambda: sync(lambda: (dst.copy_(hst), hpx2.copy_(dpx))))
-    return {"workload": f"1 x {w}x{h} RGBA frame through qoi_encode / qoi_decode on host pointers (PCIe in and out inside the call)",
+    return {"workload": f"1 x {w}x{h} RGBA frame through qoi_encode / qoi_decode on host pointers (PCIe in and out inside the call), "
+                        "the result free()d inside the timed region as qoibench.c:446-449 does",
             "encode_ms": round(t_enc * 1e3, 3), "decode_ms": round(t_dec * 1e3, 3),
+            "results_kept_ms": {"encode": round(t_enc_kept * 1e3, 3), "decode": round(t_dec_kept * 1e3, 3),
+                                "note": "the caller keeps every result: each call's malloc is fresh address space, zero-filled by the kernel inside the call"},
             "encode_mpixels_per_s": round(npx / t_enc / 1e6, 1), "decode_mpixels_per_s": round(npx / t_dec / 1e6, 1),
             "copies_alone_ms": {"encode": round(c_enc * 1e3, 3), "decode": round(c_dec * 1e3, 3)},
             "frac_of_copies": {"encode": round(c_enc / t_enc, 3), "decode": round(c_dec / t_dec, 3)},

@@ -45,7 +45,9 @@ typedef struct {
 /* Replaces qoi.h:278 / implementation qoi.h:356-486.
  * Same contract: NULL on data/desc/out_len == NULL, width or height 0, channels not 3/4,
  * colorspace > 1 or height >= 400000000/width; otherwise a malloc()ed buffer (caller
- * free()s it) holding a stream BYTE-IDENTICAL to the reference encoder's, *out_len set. */
+ * free()s it) holding a stream BYTE-IDENTICAL to the reference encoder's, *out_len set.
+ * The buffer holds at least *out_len bytes; the reference's is always the worst-case size
+ * (qoi.h:374-379), which nothing in its contract lets a caller rely on. */
 void *qoi_encode(const void *data, const qoi_desc *desc, int *out_len);
 
 /* Replaces qoi.h:289 / implementation qoi.h:488-590.

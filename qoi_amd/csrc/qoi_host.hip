@@ -754,13 +754,18 @@ extern "C" void* qoi_encode(const void* data, const qoi_desc* desc, int* out_len
     const size_t bound = qoimi_encode_bound(desc);                        // qoi.h:374-376
     if (c->io_a.reserve(in_bytes + 16) || c->io_b.reserve(bound + 16) || c->io_c.reserve(256)) return NULL;
     void* result = NULL;
-    uint8_t* bytes = (uint8_t*)malloc(bound);                              // worst case, as qoi.h:379
-    if (!bytes) return NULL;
-    // The result's pages are populated by the thread's parked helpers WHILE the pixels go in and the kernels run: the stream's
-    // length is not known yet, so they take the length of this thread's previous stream (a third of the bound at first) - pages
-    // beyond that are touched by the copy as before (round 2 populated after the kernels: 0.35 ms of a 1.3 ms call).
+    // The reference allocates the worst case (qoi.h:379) and the caller learns only *out_len; here the buffer is sized by this
+    // thread's previous stream (+ 1/8; a third of the bound at first) and replaced by an exact one in the rare case the stream
+    // turns out longer.  A 4K frame's worst case is 39.6 MiB - above the 32 MiB ceiling of glibc's dynamic mmap threshold, so every
+    // call would map, populate and (in the caller's free) unmap it: 1.1 ms of a 2.0 ms call in qoibench's encode-free loop.  A buffer
+    // of the expected size comes back from the allocator's heap with its pages in place.
     const size_t guess = c->last_drop_len ? c->last_drop_len + c->last_drop_len / 8u : bound / 3u;
-    const size_t ahead = guess < bound ? guess : bound;
+    size_t ahead = guess < bound ? guess : bound;
+    if (ahead < (size_t)kHeaderBytes + kTrailerBytes) ahead = (size_t)kHeaderBytes + kTrailerBytes;
+    uint8_t* bytes = (uint8_t*)malloc(ahead);
+    if (!bytes) return NULL;
+    // The result's pages are populated by the thread's parked helpers WHILE the pixels go in and the kernels run (round 2
+    // populated after the kernels: 0.35 ms of a 1.3 ms call).
     const bool populate = ahead >= ((size_t)1 << 20);
     if (populate) t_ctx.pf.start(bytes, ahead);
     do {
@@ -777,6 +782,12 @@ extern "C" void* qoi_encode(const void* data, const qoi_desc* desc, int* out_len
             break;
         }
         if (populate) { t_ctx.pf.wait(); }
+        if ((size_t)len > ahead) {                                      // longer than expected: an exact buffer instead
+            free(bytes);
+            bytes = (uint8_t*)malloc((size_t)len);
+            if (!bytes) return NULL;
+            prefault_pages(bytes, (size_t)len);
+        }
         if (hipMemcpyAsync(bytes, c->io_b.base, (size_t)len, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) break;
         c->last_drop_len = (size_t)len;

@@ -166,6 +166,17 @@ def test_round_trip_random_host_api(api, oracle):
             assert np.array_equal(got, want), (it, chn)
 
 
+def test_host_encode_result_outgrows_the_expected_size(api, oracle):
+    """qoi_encode sizes its malloc by the calling thread's previous stream (qoi_host.hip): a flat frame, then noise (the stream is
+    two hundred times longer than expected: the exact-size path), then flat again - byte-identical every time."""
+    from qoi_amd import synth
+    w, h = 1920, 1080
+    for kind in ("constant", "noise", "constant", "photo", "noise"):
+        px = synth.frame_rgba(kind, w, h, 11).reshape(-1, 4)
+        s = api.qoi_encode(px, api.QoiDesc(w, h, 4, 0))
+        assert s == oracle.encode(px, w, h, 4), kind
+
+
 # ------------------------------------------------------------------ device batch API
 @pytest.mark.parametrize("kind", ["photo", "noise", "uiflat", "constant"])
 def test_4k_frame_device_path(api, ctx, oracle, kind):
