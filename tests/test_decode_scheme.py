@@ -122,3 +122,20 @@ def test_record_dense_segments(host_lib, port):
             assert np.array_equal(got, want), (name, fast, stats)
         n += 1
     assert n == 21
+
+
+def test_record_pairs(host_lib, port):
+    """QOI_OP_RGB / QOI_OP_RGBA leave pairs of records on even record indices (cases.pair_streams; transcode_segment pads with null
+    records as dec_transcode does): the record pipeline stays exact at every segment size, 3- and 4-channel output."""
+    n = 0
+    for name, stream, w, h in cases.pair_streams():
+        if len(stream) > 250000:
+            continue                                   # the long mixture is the GPU test's
+        for och in (4, 3):
+            want, _ = port.decode(stream, och)
+            for B in (64, 128, 4096):
+                got, stats = run(host_lib, stream, och, B, 64, "rec")
+                assert np.array_equal(got, want), (name, och, B, stats)
+                assert stats[3] == 0, ("slot transfer from the record tail differs from the forward walk", name, B)
+        n += 1
+    assert n == 5
