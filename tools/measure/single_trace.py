@@ -12,7 +12,7 @@ from qoi_amd import api, synth  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 mode = sys.argv[2] if len(sys.argv) > 2 else "both"
-w, h = 3840, 2160
+w, h = int(os.environ.get("W", 3840)), int(os.environ.get("H", 2160))
 npx = w * h
 ctx = api.Context(0)
 stream = torch.cuda.current_stream().cuda_stream
