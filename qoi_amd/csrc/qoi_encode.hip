@@ -751,15 +751,22 @@ __device__ __forceinline__ void copy_stage_out(const uint32_t* stage, uint8_t* _
     if (lane < n - done_b) dst[done_b + lane] = stage8[done_b + lane];
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxWriteThrough = 1 | 16;                       // cache policy bits of a buffer instruction on gfx950: sc0 | sc1
 // Moves the staged bytes [0, spos) to the set's scratch slot behind the `spilled` bytes already there (a multiple of 16).
 // all = false: whole 16-byte pieces only, the remainder moves to the front of the staging buffer.  Returns the bytes left staged.
+// The stores are WRITE-THROUGH (sc0 sc1): a pool slot is written by one holder after another, from different XCDs, and a plain store
+// leaves a dirty line in its XCD's L2 for as long as that L2 likes - an earlier holder's line written back after the next holder's
+// bytes have reached memory would put stale bytes under that holder's read-back (the L2s of the XCDs are not coherent with each
+// other, MI355X_MICROARCH.md).  Written through, a holder's bytes are in memory when its `s_waitcnt vmcnt(0)` in front of the
+// copy-out returns, i.e. before it gives the slot back; 16-byte sc1 stores cost what plain ones do.
 template <int PROBE, class LDS>
 __device__ __forceinline__ uint32_t spill_stage(LDS& L, uint8_t* __restrict__ slot, uint32_t& spilled, uint32_t spos, bool all, uint32_t lane) {
     const uint32_t n16 = all ? (spos + 15u) >> 4 : spos >> 4;
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(slot + spilled);
-    const uint4* src = reinterpret_cast<const uint4*>(L.stage);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slot, 0, 0x7FFFFFF0, 0x00020000);
+    const u32x4* src = reinterpret_cast<const u32x4*>(L.stage);
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = lane; j < n16; j += 64u) dst[j] = src[j];
+    for (uint32_t j = lane; j < n16; j += 64u) __builtin_amdgcn_raw_buffer_store_b128(src[j], rs, spilled + (j << 4), 0, kAuxWriteThrough);
     spilled += n16 << 4;
     if (all) return 0u;
     const uint32_t keep = lane < 4u ? L.stage[(n16 << 2) + lane] : 0u;     // the incomplete piece (LDS ops of a wavefront run in order)
