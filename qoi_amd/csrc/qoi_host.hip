@@ -759,15 +759,19 @@ extern "C" void* qoi_encode(const void* data, const qoi_desc* desc, int* out_len
     // turns out longer.  A 4K frame's worst case is 39.6 MiB - above the 32 MiB ceiling of glibc's dynamic mmap threshold, so every
     // call would map, populate and (in the caller's free) unmap it: 1.1 ms of a 2.0 ms call in qoibench's encode-free loop.  A buffer
     // of the expected size comes back from the allocator's heap with its pages in place.
-    const size_t guess = c->last_drop_len ? c->last_drop_len + c->last_drop_len / 8u : bound / 3u;
+    // QOIMI_ENCODE_WORST_CASE_BUFFER=1 restores the reference's allocation for callers that count on its capacity.
+    const char* const wc_env = getenv("QOIMI_ENCODE_WORST_CASE_BUFFER");
+    const bool worst_case = wc_env && atoi(wc_env) != 0;
+    const size_t guess = worst_case ? bound : (c->last_drop_len ? c->last_drop_len + c->last_drop_len / 8u : bound / 3u);
     size_t ahead = guess < bound ? guess : bound;
     if (ahead < (size_t)kHeaderBytes + kTrailerBytes) ahead = (size_t)kHeaderBytes + kTrailerBytes;
     uint8_t* bytes = (uint8_t*)malloc(ahead);
     if (!bytes) return NULL;
     // The result's pages are populated by the thread's parked helpers WHILE the pixels go in and the kernels run (round 2
     // populated after the kernels: 0.35 ms of a 1.3 ms call).
-    const bool populate = ahead >= ((size_t)1 << 20);
-    if (populate) t_ctx.pf.start(bytes, ahead);
+    const size_t expect = worst_case ? (c->last_drop_len ? c->last_drop_len + c->last_drop_len / 8u : bound / 3u) : ahead;   // pages the stream will touch
+    const bool populate = expect >= ((size_t)1 << 20);
+    if (populate) t_ctx.pf.start(bytes, expect < ahead ? expect : ahead);
     do {
         // pixels in (the copy engine reads pageable memory at the link's rate on this platform, tools/ubench/host_copy.cpp),
         // kernels, then ONE read-back of length + liveness flag through pinned words, then exactly `len` bytes out

@@ -166,15 +166,21 @@ def test_round_trip_random_host_api(api, oracle):
             assert np.array_equal(got, want), (it, chn)
 
 
-def test_host_encode_result_outgrows_the_expected_size(api, oracle):
+@pytest.mark.parametrize("worst_case", ["0", "1"])
+def test_host_encode_result_outgrows_the_expected_size(api, oracle, worst_case):
     """qoi_encode sizes its malloc by the calling thread's previous stream (qoi_host.hip): a flat frame, then noise (the stream is
-    two hundred times longer than expected: the exact-size path), then flat again - byte-identical every time."""
+    two hundred times longer than expected: the exact-size path), then flat again - byte-identical every time; the same with the
+    reference's worst-case allocation (QOIMI_ENCODE_WORST_CASE_BUFFER=1)."""
     from qoi_amd import synth
     w, h = 1920, 1080
-    for kind in ("constant", "noise", "constant", "photo", "noise"):
-        px = synth.frame_rgba(kind, w, h, 11).reshape(-1, 4)
-        s = api.qoi_encode(px, api.QoiDesc(w, h, 4, 0))
-        assert s == oracle.encode(px, w, h, 4), kind
+    os.environ["QOIMI_ENCODE_WORST_CASE_BUFFER"] = worst_case
+    try:
+        for kind in ("constant", "noise", "constant", "photo", "noise"):
+            px = synth.frame_rgba(kind, w, h, 11).reshape(-1, 4)
+            s = api.qoi_encode(px, api.QoiDesc(w, h, 4, 0))
+            assert s == oracle.encode(px, w, h, 4), kind
+    finally:
+        del os.environ["QOIMI_ENCODE_WORST_CASE_BUFFER"]
 
 
 # ------------------------------------------------------------------ device batch API
