@@ -1051,12 +1051,24 @@ __global__ __launch_bounds__(64) void dec_chain_state_l3(DecParams p) {
 // SQ_WAIT_ANY 55 % of the wavefront cycles (profiles/r02), whatever the ring size or the occupancy.
 // Worst case (every chunk five bytes): a period consumes 20 bytes (+ 13 of look-ahead); with 128 bytes of ring, 32-byte
 // requests and up to three in flight the unread part never falls below 40 bytes (simulated over all phases).
-struct PipeReader {
+// DESC: the requests go through ONE raw buffer descriptor per wavefront (base: the stream of its first segment; the lanes' streams
+// follow it in memory) with 32-bit offsets: a lane without a request aims outside the descriptor - no memory access, no dummy
+// line - and neither the 64-bit address arithmetic nor the clamp to the stream's last granule is needed: two vector instructions
+// per period for the two loads instead of twelve (the refill was 9 of the transcoder's 28 vector instructions per chunk).
+// Bytes behind a stream's end are never parsed (qoi.h:539), so what a lane reads there - the slack up to the next stream, zeros
+// behind the wavefront's last stream - does not matter; the descriptor ends with the 16-byte granule of that last stream's last
+// byte, as the plain form's clamp does.  A lane whose stream lies 4 GiB or more behind the base (never with sane strides) cannot
+// be addressed: init() says so and the segment goes the way of the segments whose parse did not synchronise (MODE 1, plain form).
+template <bool DESC>
+struct PipeReaderT {
     static constexpr uint32_t RD = 32, kSlots = RD + 1, kPeriod = 4;
     uint32_t ring;             // LDS byte address of ring[0][lane]
-    const uint8_t* abase;      // 32-byte aligned start of the fetched range
-    const uint8_t* alast;      // last 16-byte granule that starts before stream + size
-    const uint8_t* dummy;      // 16 readable bytes every idle lane loads instead (one line for the whole wavefront)
+    const uint8_t* abase;      // 32-byte aligned start of the fetched range              (plain form)
+    const uint8_t* alast;      // last 16-byte granule that starts before stream + size   (plain form)
+    const uint8_t* dummy;      // 16 readable bytes every idle lane loads instead (one line for the whole wavefront; plain form)
+    __amdgpu_buffer_rsrc_t rs; // DESC: the wavefront's descriptor
+    uint32_t boff;             // DESC: offset of abase in the descriptor
+    uint32_t idle;             // DESC: an offset outside the descriptor (wave-uniform)
     uint32_t aoff;             // abase - stream
     uint32_t wr;               // dwords landed, counted from abase
     uint32_t req;              // dwords requested (landed + in flight)
@@ -1066,11 +1078,35 @@ struct PipeReader {
         const uint8_t* q = p < alast ? p : alast;                 // a granule past the end is replaced by the last one inside
         return load_global16(go ? q : dummy);
     }
+    __device__ __forceinline__ static uint4 as_uint4(u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
     __device__ __forceinline__ void put4(uint32_t at, const uint4& v) {
         const uint32_t a = ring + (at & (RD - 1u)) * 256u;
         lds_u32* q = (lds_u32*)a;
         q[0] = v.x; q[64] = v.y; q[128] = v.z; q[192] = v.w;
         if ((at & (RD - 1u)) == 0u) ((lds_u32*)ring)[RD * 64u] = v.x;         // mirror of slot 0
+    }
+    // DESC form.  wave_base: the stream of the wavefront's first segment; wave_bytes: from there to the end of the 16-byte granule
+    // that holds the last byte of the last stream a lane of the wavefront reads (both wave-uniform); lane_ok: the lane reads at all.
+    // Returns false for a lane whose stream the descriptor does not reach.
+    __device__ __forceinline__ bool init_desc(uint32_t ring_addr, const uint8_t* wave_base, unsigned long long wave_bytes, const uint8_t* stream, uint32_t pos0, bool lane_ok) {
+        ring = ring_addr;
+        const unsigned long long nrec = wave_bytes < 0xFFFFFFE0ull ? wave_bytes : 0xFFFFFFE0ull;
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)wave_base, 0, (int)(uint32_t)nrec, 0x00020000);
+        idle = (uint32_t)nrec;                                             // the first offset outside (and so is idle + 16)
+        const uint8_t* p = stream + pos0;
+        const uint8_t* a = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)31);
+        const unsigned long long d = (unsigned long long)(a - wave_base);
+        const bool reach = lane_ok && a >= wave_base && d < nrec;          // (what lies behind nrec reads as zeros: behind every stream of the wavefront)
+        boff = reach ? (uint32_t)d : idle;
+        aoff = pos0 - (uint32_t)(p - a);
+        u32x4 v[RD / 4u];
+#pragma unroll
+        for (uint32_t r = 0; r < RD / 4u; ++r) v[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, reach ? boff + 16u * r : idle, 0, 0);
+#pragma unroll
+        for (uint32_t r = 0; r < RD / 4u; ++r) put4(4u * r, as_uint4(v[r]));
+        wr = req = RD;
+        valid[0] = valid[1] = valid[2] = false;
+        return reach || !lane_ok;
     }
     __device__ __forceinline__ void init(uint32_t ring_addr, const uint8_t* stream, uint32_t pos0, uint32_t size, const uint8_t* dummy16) {
         ring = ring_addr; dummy = dummy16;
@@ -1121,8 +1157,14 @@ struct PipeReader {
         if (valid[S]) { put4(wr, set[S][0]); put4(wr + 4u, set[S][1]); wr += 8u; }
         const uint32_t space = RD - (req - ((pos - aoff) >> 2));      // dwords neither unread nor on their way
         const bool go = space >= 8u;
-        set[S][0] = load16(abase + (size_t)req * 4u, go);
-        set[S][1] = load16(abase + (size_t)req * 4u + 16u, go);
+        if (DESC) {
+            const uint32_t off = go ? boff + req * 4u : idle;
+            set[S][0] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            set[S][1] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u, 0, 0));
+        } else {
+            set[S][0] = load16(abase + (size_t)req * 4u, go);
+            set[S][1] = load16(abase + (size_t)req * 4u + 16u, go);
+        }
         valid[S] = go;
         req += go ? 8u : 0u;
     }
@@ -1131,7 +1173,7 @@ struct PipeReader {
 #ifndef QOIMI_TR_WAVES
 #define QOIMI_TR_WAVES 4
 #endif
-typedef PipeReader TransReader;
+typedef PipeReaderT<false> TransReader;
 constexpr uint32_t kTrThreads = 64u * QOIMI_TR_WAVES;
 // per tag byte: record template and chunk-table word (QOI_OP_RGBA's length set to 0: visited twice) side by side - ONE 8-byte LDS read per
 // step (two 4-byte reads of two arrays: a third of the kernel's LDS cycles were bank conflicts of these reads, profiles/r04_s6_sq_counters_decode.txt);
@@ -1179,7 +1221,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
     const uint32_t lut_base = lds_addr_of(&s_lut.e[0]);
-    TransReader R;
+    PipeReaderT<MODE == 0> R;                 // MODE 0: requests through a descriptor; MODE 1 (rare): plain pointers, reaches anything
     uint32_t pos;
     bool failed = false;
     const uint8_t* dummy16 = reinterpret_cast<const uint8_t*>(p.images);        // any 16 readable bytes: what lanes without a request load
@@ -1190,12 +1232,23 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         // ---- look-back synchronisation ------------------------------------------------------------------------------
         const bool from_start = base <= (uint32_t)kHeaderBytes + kSyncBytes;      // the stream's first chunk is in reach: one chain from byte 14
         const uint32_t t0 = from_start ? (uint32_t)kHeaderBytes : base - kSyncBytes;
-        R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, t0, im.chunks_end + kTrailerBytes, dummy16);
+        // the wavefront's descriptor: from the stream of its first segment to the last granule of the stream of its last one
+        const uint8_t* const my_stream = p.streams + im.stream_off;
+        const u64 hv = lanes_where(have);
+        const int last = 63 - __builtin_clzll(hv);                                                  // (hv != 0 here)
+        const uintptr_t my_end = ((reinterpret_cast<uintptr_t>(my_stream) + im.chunks_end + kTrailerBytes - 1u) & ~(uintptr_t)15) + 16u;
+        const uintptr_t last_end = ((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_end, last)) |
+                                   ((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_end >> 32), last) << 32);
+        const int first = __builtin_ctzll(hv);
+        const uintptr_t first_stream = ((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)reinterpret_cast<uintptr_t>(my_stream), first)) |
+                                       ((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(reinterpret_cast<uintptr_t>(my_stream) >> 32), first) << 32);
+        const bool reach = R.init_desc(lds_addr_of(&s_ring[wave][lane]), reinterpret_cast<const uint8_t*>(first_stream), (unsigned long long)(last_end - first_stream),
+                                       my_stream, t0, have);
         ParseState s; parse_init(s, t0);
         if (from_start) { s.p1 = s.p2 = s.p3 = s.p4 = t0; }
         uint32_t m = t0;
         bool merged = from_start;
-        bool going = have && m < base;
+        bool going = have && reach && m < base;
         auto sync_steps = [&]() {
 #pragma unroll
           for (uint32_t u = 0; u < TransReader::kPeriod; ++u) {
@@ -1214,11 +1267,11 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
           }
         };
         while (lanes_where(going)) {                              // three periods per turn of the register sets (PipeReader)
-            R.turn<0>(m); sync_steps();
-            R.turn<1>(m); sync_steps();
-            R.turn<2>(m); sync_steps();
+            R.template turn<0>(m); sync_steps();
+            R.template turn<1>(m); sync_steps();
+            R.template turn<2>(m); sync_steps();
         }
-        failed = have && !merged;
+        failed = have && (!merged || !reach);
         pos = m;                                              // merged: the first chunk start at or behind the segment start
         // the ring was refilled for the front position; the walk below continues the same byte stream
         const u64 fails = lanes_where(failed);
@@ -1303,9 +1356,9 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         }
     };
     while (lanes_where(active)) {                                 // a period = one granule of four steps; three periods per turn of the register sets
-        R.turn_rel<0>(rp); granule_steps();
-        R.turn_rel<1>(rp); granule_steps();
-        R.turn_rel<2>(rp); granule_steps();
+        R.template turn_rel<0>(rp); granule_steps();
+        R.template turn_rel<1>(rp); granule_steps();
+        R.template turn_rel<2>(rp); granule_steps();
     }
     pos = rp + R.aoff;
     if (have && !failed) {

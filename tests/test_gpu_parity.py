@@ -385,6 +385,29 @@ def test_decode_batch_mixed_shapes(api, ctx, oracle):
                 assert int(out[i * pstride + want.size]) == 0xCD, "wrote past the image"
 
 
+def test_decode_streams_gigabytes_apart(api, ctx, oracle):
+    """Small streams 2.5 GiB apart in one batch: the lanes of ONE transcoder wavefront then hold streams that its 32-bit buffer
+    descriptor does not reach (4 GiB from the wavefront's first stream) - those segments go the way of the unsynchronised ones
+    (plain 64-bit addresses) and decode to the same pixels."""
+    import torch
+    rng = np.random.default_rng(5)
+    w, h, n = 64, 40, 4
+    stride = 5 << 29                                                       # 2.5 GiB
+    imgs = [np.cumsum(rng.integers(-3, 4, size=(w * h, 4)), axis=0).astype(np.uint8) for _ in range(n)]
+    streams = [oracle.encode(px, w, h, 4) for px in imgs]
+    buf = torch.zeros((n - 1) * stride + 65536, dtype=torch.uint8, device="cuda")
+    for i, st in enumerate(streams):
+        buf[i * stride:i * stride + len(st)] = torch.from_numpy(np.frombuffer(st, dtype=np.uint8).copy()).cuda()
+    out = torch.full((n * w * h * 4 + 8,), 0xAB, dtype=torch.uint8, device="cuda")
+    ctx.decode_batch(buf.data_ptr(), stride, [len(st) for st in streams], [api.QoiDesc(w, h, 4, 0)] * n, 4, out.data_ptr(), w * h * 4)
+    got = out.cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i * w * h * 4:(i + 1) * w * h * 4], imgs[i].reshape(-1)), i
+    assert int(got[n * w * h * 4]) == 0xAB, "wrote past the last image"
+    assert ctx.decode_stats()["sync_fallback_segments"] > 0, "no segment lay out of the descriptor's reach: the test does not test"
+    del buf
+
+
 def test_decode_batch_many_small_images(api, ctx, oracle):
     """300 images of 1..40 pixels a side in ONE decode batch (every per-image chain has a single short group; image
     tables, group bases and the per-image kernels see hundreds of entries), all content classes, both output forms."""
