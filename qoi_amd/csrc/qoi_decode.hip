@@ -1154,7 +1154,17 @@ struct PipeReaderT {
     // one period's memory work for register set S (compile-time 0..2): land what S holds (asked for three periods ago), ask again
     template <int S>
     __device__ __forceinline__ void turn(uint32_t pos) {
-        if (valid[S]) { put4(wr, set[S][0]); put4(wr + 4u, set[S][1]); wr += 8u; }
+        if (valid[S]) {
+            // wr is a multiple of eight (init lands RD dwords, every turn eight): the second half sits four slots on without a wrap
+            // and is never slot 0
+            const uint32_t a = ring + (wr & (RD - 1u)) * 256u;
+            lds_u32* q = (lds_u32*)a;
+            const uint4 v0 = set[S][0], v1 = set[S][1];
+            q[0] = v0.x; q[64] = v0.y; q[128] = v0.z; q[192] = v0.w;
+            q[256] = v1.x; q[320] = v1.y; q[384] = v1.z; q[448] = v1.w;
+            if ((wr & (RD - 1u)) == 0u) ((lds_u32*)ring)[RD * 64u] = v0.x;        // mirror of slot 0
+            wr += 8u;
+        }
         const uint32_t space = RD - (req - ((pos - aoff) >> 2));      // dwords neither unread nor on their way
         const bool go = space >= 8u;
         if (DESC) {
