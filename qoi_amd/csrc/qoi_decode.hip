@@ -1305,9 +1305,12 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     uint32_t a_abs = 0u, a_last = 0u;            // a QOI_OP_RGBA occurred in the segment / the alpha of the last one (for dec_slot_tails)
     uint32_t pend = 0u;                          // 1 / 2: the first record of the QOI_OP_RGBA / QOI_OP_RGB chunk under the cursor is out
     bool any_pend = false;
-    uint32_t ngran = 0u, npix = 0u;
-    // granule row g of this wavefront's 64 segments: one contiguous KiB
-    u32x4* dst = reinterpret_cast<u32x4*>(p.recs + (size_t)(blockIdx.x * QOIMI_TR_WAVES + wave) * p.rec_rows * 256u) + lane;
+    uint32_t npix = 0u;
+    // granule row g of this wavefront's 64 segments: one contiguous KiB.  Stored through a descriptor over the block's rows with a
+    // 32-bit offset that moves on by a row per granule (the 64-bit address of every store was four vector instructions)
+    const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)(p.recs + (size_t)(blockIdx.x * QOIMI_TR_WAVES + wave) * p.rec_rows * 256u), 0,
+                                                                             (int)(p.rec_rows * 1024u), 0x00020000);
+    uint32_t roff = lane * 16u;                                          // byte offset of the lane's next granule
     auto granule_steps = [&]() {
         {
             const bool live = active;                                    // the granule holds at least one record of this lane
@@ -1362,7 +1365,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
             }
             // non-temporal: 13.7 GB of records per 412 frames must not sweep the stream lines out of the L2 between a lane's four
             // 32-byte requests to one 128-byte line (with plain stores FETCH_SIZE was 3.8 x the stream bytes, now 2.5 x)
-            if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; __builtin_nontemporal_store(v, &dst[(size_t)ngran * 64u]); ++ngran; }
+            if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; __builtin_amdgcn_raw_buffer_store_b128(v, rs_rec, roff, 0, 2 /* nt */); roff += 1024u; }
         }
     };
     while (lanes_where(active)) {                                 // a period = one granule of four steps; three periods per turn of the register sets
@@ -1372,7 +1375,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     }
     pos = rp + R.aoff;
     if (have && !failed) {
-        p.rec_gran[q] = ngran;
+        p.rec_gran[q] = roff >> 10;                                     // granules written
         SlotRec r; r.hc = 0; r.h_rel = 0; r.h_alpha = 0; r.a_abs = (uint8_t)a_abs; r.ac = (uint8_t)a_last;      // dec_slot_tails completes it
         p.slot_rec[q] = r;
         if (MODE == 0) {
