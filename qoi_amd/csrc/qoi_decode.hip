@@ -202,6 +202,9 @@ __device__ __forceinline__ void add_byte1(uint32_t& acc, uint32_t b) {
 __device__ __forceinline__ void add_byte2(uint32_t& acc, uint32_t b) {
     asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2" : "+v"(acc) : "v"(b));
 }
+__device__ __forceinline__ void add_dword_byte2(uint32_t& acc, uint32_t b) {     // acc += b.byte2
+    asm("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "+v"(acc) : "v"(b));
+}
 __device__ __forceinline__ void add_byte2_from0(uint32_t& acc, uint32_t b) {     // acc.byte2 += b.byte0
     asm("v_add_u32_sdwa %0, %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_0" : "+v"(acc) : "v"(b));
 }
@@ -1146,8 +1149,8 @@ struct PipeReaderT {
         asm("v_bfe_u32 %0, %1, 2, 5\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(a) : "v"(rp), "v"(ring));
         const lds_u32* q = (const lds_u32*)a;
         const uint32_t d0 = q[0]; hi = q[64];
-        sh = rp * 8u;                                                    // v_alignbit takes the shift modulo 32
-        w32 = __builtin_amdgcn_alignbit(hi, d0, sh);
+        sh = rp;                                                         // the caller who needs byte 4 shifts by 8 * (sh & 3)
+        w32 = __builtin_amdgcn_alignbyte(hi, d0, rp);                    // v_alignbyte takes the byte count from the low two bits
     }
     template <int S>
     __device__ __forceinline__ void turn_rel(uint32_t rp) { turn<S>(rp + aoff); }
@@ -1217,7 +1220,9 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         uint32_t d, i; lut_entry(b, d, i);
         // the transcoder's own info word: bits 0..2 chunk length (0 for QOI_OP_RGBA: visited twice), bits 8..15 all ones for
         // QOI_OP_LUMA (ANDed onto the chunk bytes it leaves the second byte there, nothing for every other chunk), bits 30..31 class
-        s_lut.e[b] = make_uint2(rec_template(b), (b == 0xFFu ? 0u : (i & 7u)) | ((i >> 28) & 1u ? 0x0000FF00u : 0u) | (i & 0xC0000000u));
+        // ... bits 16..21 the pixels of the chunk (0 for QOI_OP_RGBA, whose records count for themselves)
+        const uint32_t tplb = rec_template(b);
+        s_lut.e[b] = make_uint2(tplb, (b == 0xFFu ? 0u : (i & 7u)) | ((i >> 28) & 1u ? 0x0000FF00u : 0u) | (i & 0xC0000000u) | (b == 0xFFu ? 0u : rec_pixels(tplb) << 16));
     }
     if (threadIdx.x < 4u) s_lut.e[256u + threadIdx.x] = make_uint2(0u, 0u);
     __syncthreads();
@@ -1325,8 +1330,8 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                 const uint32_t wm = w32 & c_info;
                 const uint32_t er = __builtin_amdgcn_ubfe(wm, 12, 4), eb = __builtin_amdgcn_ubfe(wm, 8, 4);
                 add_byte0(rec, er); add_byte2_from0(rec, eb);
-                uint32_t cnt = (rec >> 24) & 63u;                        // pixels of the chunk (qoi.h:573-575); the stash marker is set right below
                 if (lanes_where(lut_hi(c_info)) != 0 || any_pend) {     // QOI_OP_RGB / QOI_OP_RGBA somewhere in the wavefront (rare in natural images)
+                    uint32_t cnt = (rec >> 24) & 63u;                    // pixels of the chunk (qoi.h:573-575); the stash marker is set right below
                     // These chunks leave a PAIR of records that begins on an even record index of the segment (u is a compile-time
                     // constant here): QOI_OP_RGBA = (stash half, alpha half), QOI_OP_RGB = (the record, a null record); a chunk met on
                     // an odd index leaves a null record first.  The chunk stays under the cursor until its second record is out.  So
@@ -1336,7 +1341,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                     const bool hi = lut_hi(c_info), lo = lut_lo(c_info);
                     const bool rgba = hi && lo;
                     const uint32_t rgb = (w32 >> 8) & 0x00FFFFFFu;
-                    const uint32_t b5 = (b5hi >> (b5sh & 24u)) & 0xFFu;                      // chunk byte 4: the alpha of a QOI_OP_RGBA
+                    const uint32_t b5 = (b5hi >> ((b5sh & 3u) * 8u)) & 0xFFu;                // chunk byte 4: the alpha of a QOI_OP_RGBA
                     if ((u & 1u) == 0u) {                                                    // a pair begins (no lane has one pending here)
                         rec = hi ? (rec | rgb) : rec;                                        // rec still is the class-2 template: stash marker / one pixel
                         adv = hi ? 0u : adv;
@@ -1352,8 +1357,10 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                         pend = 0u;
                     }
                     any_pend = lanes_where(pend != 0u) != 0;
+                    npix += cnt;
+                } else {
+                    add_dword_byte2(npix, c_info);                       // the chunk's pixels straight from the table word
                 }
-                npix += cnt;
                 const uint32_t nrp = rp + adv;
                 uint32_t nw32; R.peek4_rel(nrp, nw32, b5hi, b5sh);
                 active = active && nrp < end_rel;
