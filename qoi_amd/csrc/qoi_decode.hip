@@ -1186,6 +1186,9 @@ struct PipeReaderT {
 #ifndef QOIMI_TR_WAVES
 #define QOIMI_TR_WAVES 4
 #endif
+#ifndef QOIMI_TR_STORE_AUX
+#define QOIMI_TR_STORE_AUX 2                // cache policy of the record stores: nt
+#endif
 typedef PipeReaderT<false> TransReader;
 constexpr uint32_t kTrThreads = 64u * QOIMI_TR_WAVES;
 // per tag byte: record template and chunk-table word (QOI_OP_RGBA's length set to 0: visited twice) side by side - ONE 8-byte LDS read per
@@ -1372,7 +1375,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
             }
             // non-temporal: 13.7 GB of records per 412 frames must not sweep the stream lines out of the L2 between a lane's four
             // 32-byte requests to one 128-byte line (with plain stores FETCH_SIZE was 3.8 x the stream bytes, now 2.5 x)
-            if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; __builtin_amdgcn_raw_buffer_store_b128(v, rs_rec, roff, 0, 2 /* nt */); roff += 1024u; }
+            if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; __builtin_amdgcn_raw_buffer_store_b128(v, rs_rec, roff, 0, QOIMI_TR_STORE_AUX); roff += 1024u; }
         }
     };
     while (lanes_where(active)) {                                 // a period = one granule of four steps; three periods per turn of the register sets
@@ -1403,12 +1406,16 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
 // Record source of a P3 / P4 wavefront: lane l reads the granules of segment 64 * block + l through a raw buffer descriptor
 // over the granule rows of the block (row g: 64 lanes x 16 bytes, contiguous).  A lane that is through (or has no segment) asks for an offset outside the
 // descriptor and gets zeros - the null record - so the loops never mask lanes off.
-// cache policy bits of the record loads / P4's pixel bursts (buffer instructions: 2 = nt, streaming)
+// cache policy bits of the record loads / P4's pixel bursts (buffer instructions: 1 = sc0, 2 = nt, 16 = sc1).
+// The bursts are WRITE-THROUGH (sc0 sc1): with plain stores the L2 sent 1.26 x the pixels' bytes to the fabric (PMC WRITE_SIZE,
+// 1024 x 4K: 42.0 GB for 34.0) - a 128-byte line gets its two 64-byte bursts ~20 steps apart and partly dirty lines go out more
+// than once; written through, every burst leaves once: 1.002 x, dec_segments_rec 4.80 -> 4.64 ms per 256 frames (nt: 1.03 x but
+// 4.90 ms).
 #ifndef QOIMI_REC_LOAD_AUX
 #define QOIMI_REC_LOAD_AUX 0
 #endif
 #ifndef QOIMI_P4_STORE_AUX
-#define QOIMI_P4_STORE_AUX 0
+#define QOIMI_P4_STORE_AUX 17
 #endif
 struct RecSource {
     __amdgpu_buffer_rsrc_t rs;
@@ -1804,7 +1811,7 @@ struct BurstWriter : LaneWriter<OCH, RING_, GROUP_> {
                 const uint32_t raddr = this->row - lane * 4u + owner * 4u + ((rbo + 4u * piece) << 8);
                 u32x4 w;
                 w.x = *(const lds_u32*)(raddr); w.y = *(const lds_u32*)(raddr + 256u); w.z = *(const lds_u32*)(raddr + 512u); w.w = *(const lds_u32*)(raddr + 768u);
-                __builtin_amdgcn_raw_buffer_store_b128(w, rs, piece < 3u ? Ao + 16u * piece : kNowhere, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs, piece < 3u ? Ao + 16u * piece : kNowhere, 0, QOIMI_P4_STORE_AUX);
             }
         } else {
             const uint32_t rbase = this->row + ((this->fpos & kG) << 8);
@@ -1822,14 +1829,14 @@ struct BurstWriter : LaneWriter<OCH, RING_, GROUP_> {
 #pragma unroll
                 for (uint32_t k = 0; k < 12u; k += 4u) {
                     u32x4 w; w.x = d[k]; w.y = d[k + 1u]; w.z = d[k + 2u]; w.w = d[k + 3u];
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rs, off + 4u * k, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rs, off + 4u * k, 0, QOIMI_P4_STORE_AUX);
                 }
             } else {                                                               // 24 bytes: 16 + 8
                 u32x4 w; w.x = d[0]; w.y = d[1]; w.z = d[2]; w.w = d[3];
-                __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, QOIMI_P4_STORE_AUX);
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                 u32x2 w2; w2.x = d[4]; w2.y = d[5];
-                __builtin_amdgcn_raw_buffer_store_b64(w2, rs, off + 16u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(w2, rs, off + 16u, 0, QOIMI_P4_STORE_AUX);
             }
         }
         this->fpos += go ? kG : 0u;
