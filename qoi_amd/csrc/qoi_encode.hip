@@ -353,6 +353,19 @@ __device__ __forceinline__ uint32_t sub_byte2(uint32_t a, uint32_t b) {
     return r;
 }
 
+// repeat lanes (NE) whose predecessor is a repeat as well; lane 0's predecessor is the last pixel of the step before: a repeat
+// unless ccp == 64.  Scalar unit only (written in C the compiler moved the whole test to the vector unit: seven instructions).
+__device__ __forceinline__ u64 repeats_side_by_side(u64 NE, uint32_t ccp) {
+    u64 r, t;
+    asm("s_cmp_lg_u32 %2, 64\n\t"
+        "s_cselect_b64 %0, 1, 0\n\t"
+        "s_lshl_b64 %1, %3, 1\n\t"
+        "s_or_b64 %0, %0, %1\n\t"
+        "s_and_b64 %0, %0, %3"
+        : "=&s"(r), "=&s"(t) : "s"(__builtin_amdgcn_readfirstlane((int)ccp)), "s"(NE) : "scc");   // (ccp is wave-uniform: free where it already sits in an SGPR)
+    return r;
+}
+
 // chunk word tags (above the bytes a short chunk stores): length class of the lane.  1-byte chunks need no tag: nothing tests
 // for them.  A QOI_OP_LUMA word comes out of v_perm_b32 with byte 3 = 0xFF (the only constants it offers are 0x00 and 0xFF):
 // two-byte words are the NEGATIVE ones, the long marker is 0x40000000 (the inline constant 2.0).
@@ -461,7 +474,13 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, uint32_t
 
     // ---- repeats: run byte 0xC0|(run-1) on the pixel that closes a run (qoi.h:416-421,425-428) ----
     // clz of the edges below the lane; ccp stands in when the run began before this step
-    uint32_t w;
+    // A repeat pixel whose predecessor is an edge counts 1: where no two repeats stand side by side (and the step does not begin
+    // inside a run: ccp == 64 says the pixel before it was an edge) every run byte of the step is 0xC0 and the eight vector
+    // instructions of the count are skipped on a scalar test - three steps in four of a photograph.
+    uint32_t w = 0xC0u;
+#ifndef QOIMI_ENC_NO_SHORT_RUNS
+    if (repeats_side_by_side(NE, ccp))
+#endif
     {
         const uint32_t fhi = ffbh((uint32_t)(Ec >> 32) & C.below_hi);
         const uint32_t flo = ffbh((uint32_t)Ec & C.below_lo) | 32u;
