@@ -911,7 +911,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     u64 early_rec = kRecIncl;
     bool early = false;
     auto ask_early = [&]() {
-        if (p.lookback && set != 0u) { early_rec = lane < set ? granule_load(&rec_base[set - 1u - lane]) : kRecIncl; early = true; }
+        if (p.lookback == 1 && set != 0u) { early_rec = lane < set ? granule_load(&rec_base[set - 1u - lane]) : kRecIncl; early = true; }
     };
 
     uint32_t g = 0;
@@ -973,7 +973,45 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     // A record is an 8-byte granule: bits 62..63 = 0 nothing yet, 1 the set's own byte count, 2 the byte count of the image up
     // to and including the set; the count sits in the low dword (a stream is shorter than 2^31 bytes, qoi.h:328-332).
     uint32_t excl = 0;
-    {
+    if (p.lookback == 2) {
+        // ---- tree placement (calls of a few large images): three levels of byte counts, 64 to a window -------------------------
+        // With ONE image every wavefront in flight belongs to it - thousands of sets that finish at about the same time - and the
+        // inclusive prefixes of the look-back below travel 64 sets per round trip through them.  Here nothing travels: a set
+        // publishes its own count; the LAST set of a group of 64 adds the counts of its group and publishes the group's total, the
+        // last set of 64 groups the total of those; and every set adds, at once, the counts before it in its group, the group totals
+        // before its group in its block, and the block totals before its block - three loads per poll, depth three whatever the
+        // image's size (64^3 sets: 800 Mpx at one slab per set).  Sets are taken by workgroup index here (use_ticket = 0): a wait is
+        // for lower-numbered sets only, which the dispatcher has started already (the look-back's spin bound still guards it).
+        const uint32_t nsets = p.sets_per_image;
+        const uint32_t n1 = (nsets + 63u) >> 6, n2 = (n1 + 63u) >> 6;
+        u64* const t1 = p.tree1 + (size_t)img * n1;
+        u64* const t2 = p.tree2 + (size_t)img * n2;
+        const uint32_t g1 = set >> 6, j0 = set & 63u, g2 = g1 >> 6, j1 = g1 & 63u;
+        if (lane == 0) granule_store(&p.status[sg], kRecAgg | set_bytes);
+        const bool close1 = j0 == 63u || set + 1u == nsets;                // this set publishes its group's total ...
+        const bool close2 = close1 && (j1 == 63u || g1 + 1u == n1);        // ... and its block's
+        bool d0 = j0 == 0u, d1 = j1 == 0u, d2 = g2 == 0u, pub1 = !close1, pub2 = !close2;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, spins = 0;
+        while (!(d0 && d1 && d2)) {
+            u64 v0 = kRecAgg, v1 = kRecAgg, v2 = kRecAgg;
+            if (!d0 && lane < j0) v0 = granule_load(&rec_base[(g1 << 6) + lane]);
+            if (!d1 && lane < j1) v1 = granule_load(&t1[(g2 << 6) + lane]);
+            if (!d2 && lane < g2) v2 = granule_load(&t2[lane]);
+            if (!d0 && lanes_where((uint32_t)(v0 >> 62) == 0u) == 0ull) { a0 = wave_sum32_upto((uint32_t)v0, lane, 63); d0 = true; }
+            if (!d1 && lanes_where((uint32_t)(v1 >> 62) == 0u) == 0ull) { a1 = wave_sum32_upto((uint32_t)v1, lane, 63); d1 = true; }
+            if (!d2 && lanes_where((uint32_t)(v2 >> 62) == 0u) == 0ull) { a2 = wave_sum32_upto((uint32_t)v2, lane, 63); d2 = true; }
+            if (d0 && !pub1) { if (lane == 0) granule_store(&t1[g1], kRecAgg | (u64)(a0 + set_bytes)); pub1 = true; }
+            if (d0 && d1 && !pub2) { if (lane == 0) granule_store(&t2[g2], kRecAgg | (u64)(a1 + a0 + set_bytes)); pub2 = true; }
+            if (d0 && d1 && d2) break;
+            if (ENTRY == 1 && (spins & 7u) == 7u && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (slot_id != 0xFFFFFFFFu) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pool_give(p, slot_id, lane); }
+                return;
+            }
+            if (++spins > (1u << 22)) { if (lane == 0) atomicOr(p.err, 1u); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        excl = a0 + a1 + a2;
+    } else {
         u64* st = p.status;
         if (set == 0) {
             if (lane == 0) granule_store(&st[sg], kRecIncl | set_bytes);
@@ -1235,7 +1273,8 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     if (warm) {
         p.only_flagged = 0;
         // (p.persist: test knob - at most that many workgroups, each taking unit after unit in the kernel's grid-stride loop)
-        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1>), dim3(p.persist && p.n_units > p.persist ? p.persist : p.n_units), dim3(256), 0, st, p);
+        // (tree placement takes its sets by workgroup index and waits for lower-numbered ones: one workgroup per unit, no grid-stride loop)
+        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1>), dim3(p.persist && p.n_units > p.persist && p.lookback != 2 ? p.persist : p.n_units), dim3(256), 0, st, p);
         tm->mark(kT_enc_slabs, st);
         p.only_flagged = 1;
     } else {
@@ -1255,14 +1294,14 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         // ... by look-back as well, with records / tickets of their own (the first pass left some behind for these images) and
         // kEncGenSetSlabs slabs per set: flat content is a few bytes per slab, eight slabs per look-back instead of R.  (Round 3 parked
         // these sets order-free in per-set scratch slots - the worst-case slots of EVERY set of the batch, 42.5 GB for 1024 4K frames.)
-        g.status = p.status_gen; g.ticket = p.ticket_gen;
+        g.status = p.status_gen; g.ticket = p.ticket_gen; g.tree1 = p.tree1_gen; g.tree2 = p.tree2_gen;
         g.set_slabs = kEncGenSetSlabs; g.set_px = kEncGenSetSlabs * kEncSlabPx;
         g.sets_per_image = (p.spi + kEncGenSetSlabs - 1u) / kEncGenSetSlabs;
         g.n_units = ((g.sets_per_image + 3u) / 4u) * p.n_images;
     } else if (warm) {
         g.lookback = 0; p.lookback = 0;                      // an order-free call: the flagged images are parked and placed with the others
     }
-    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0>), dim3(g.n_units < small ? g.n_units : small), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0>), dim3(g.n_units < small || g.lookback == 2 ? g.n_units : small), dim3(256), 0, st, g);
     tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
     p.only_flagged = 0;
     }

@@ -103,7 +103,7 @@ struct qoimi_ctx {
     int enc_ticket = 1, enc_set_slabs = 0, enc_warm = 1;   // tuning / test knobs (env QOIMI_ENC_*)
     int enc_spread = 1;                 // env QOIMI_ENC_SPREAD: the wavefronts of a workgroup take their tickets from consecutive images (0: all four from one image)
     int enc_persist = 0;                // env QOIMI_ENC_PERSIST: workgroups of the first encode pass (0: one per unit)
-    int enc_lookback = -1;              // 1: sets place their bytes themselves (decoupled look-back); 0: order-free (scratch slots + enc_offsets + enc_compact); -1: by the number of sets per image
+    int enc_lookback = -1;              // 1: sets place their bytes themselves (decoupled look-back); 2: the same by the tree of byte counts; 0: order-free (scratch slots + enc_offsets + enc_compact); -1: by the call's shape
     std::string enc_debug_dump;         // env QOIMI_ENC_DEBUG_DUMP: file that receives the entry-state arrays of every encode call
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
@@ -309,27 +309,42 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.warm = c->enc_warm ? 1 : 0;
     p.persist = (uint32_t)c->enc_persist;
     p.spread = (uint32_t)c->enc_spread;
-    {   // slabs per set: a wavefront carries the colour table and its staged bytes from slab to slab, so the entry-state replay
-        // and the look-back are paid once per set - as long as the sets still fill the 256 CUs x 20 wavefronts several times
+    // Slabs per set and placement - functions of the call's shape only; QOIMI_ENC_SET_SLABS / QOIMI_ENC_LOOKBACK force them; every
+    // combination gives the same bytes.
+    // A wavefront carries the colour table and its staged bytes from slab to slab, so the entry-state replay and the placement are
+    // paid once per set - as long as the sets still fill the 256 CUs x 24 wavefronts several times.
+    // Look-back (1): a set finds its place in the stream by decoupled look-back over the earlier sets of its image and writes its
+    // bytes once, straight from the LDS (sets of more than ~1.4 bytes per pixel spill to a scratch slot and move that part
+    // themselves).  The inclusive prefixes travel 64 sets per poll (~1 us) through the sets of an image that finish at about the same
+    // time - the ~6000 resident wavefronts divided by the number of images.  With a batch that is a few sets; with ONE image it is
+    // all of them (a 4K frame: 71-131 us against 45 order-free), and its ticket counter serves every wavefront in turn.
+    // Tree (2, round 4; encode_set): calls of fewer than 8 images.  Every set adds three windows of byte counts - its group's, its
+    // block's group totals, the image's block totals - nothing travels from set to set, the sets go by workgroup index.  One frame,
+    // tree against the best of the other two forms (profiles/r04_s12_single_placement.txt): 640 x 360 20.2 us / 22.8, 1280 x 720
+    // 21.9 / 26.8, 1920 x 1080 27.2 / 27.6, 2560 x 1440 32.0 / 31.4, 3840 x 2160 39.9 / 42.6, 5120 x 2880 50.3 / 57.0.
+    // Order-free (0): every set parks its bytes in a scratch slot, enc_offsets scans the sizes with a whole workgroup, enc_compact
+    // places them (two more launches, a round trip through scratch).  No set ever waits: what very large images take (16384 x
+    // 16384: 552 us against 653 by the tree - 6000 sets in flight, each a few microseconds in its slot waiting for the totals).
+    {
         const size_t total_slabs = (size_t)n_images * p.spi;
         uint32_t r = total_slabs >= 3u * 65536u ? 3u : (total_slabs >= 16384u ? 2u : 1u);
+        int place = c->enc_lookback >= 0 ? (c->enc_lookback > 2 ? 1 : c->enc_lookback) : (n_images >= 8 ? 1 : 2);
+        if (place == 2 && c->enc_lookback < 0) {
+            const uint32_t rt = total_slabs < 1500u ? 1u : (total_slabs < 6000u ? 2u : 3u);       // measured above
+            if ((p.spi + rt - 1u) / rt > kEncTreeMaxSets) place = 0; else r = rt;
+        }
         if (c->enc_set_slabs > 0) r = (uint32_t)c->enc_set_slabs;
         if (r > kEncMaxSetSlabs) r = kEncMaxSetSlabs;
         p.set_slabs = r;
         p.set_px = r * kEncSlabPx;
         p.sets_per_image = (p.spi + r - 1u) / r;
         p.set_stride = r * kEncSlabWorst + 16u;
+        if (place == 2 && p.sets_per_image > 64u * 64u * 64u) place = 0;            // (three levels of 64; the generic pass has fewer sets)
+        p.lookback = (uint8_t)place;
+        if (place == 2) { p.use_ticket = 0; p.spread = 0; }
     }
-    // Placement.  Look-back: a set finds its place in the stream by decoupled look-back over the earlier sets of its image and
-    // writes its bytes once, straight from the LDS (sets of more than ~1.4 bytes per pixel spill to their scratch slot and move
-    // that part themselves).  The inclusive prefixes travel 64 sets per poll (~1 us) through the sets of an image that finish
-    // at about the same time - the ~5000 resident wavefronts divided by the number of images.  With a batch that is a few sets;
-    // with ONE large image it is thousands, and the sets would wait for the prefixes (a 16384 x 16384 image: 0.62 ms against
-    // 0.5): there the order-free form is used (every set parks its bytes, enc_offsets scans the sizes with a whole workgroup,
-    // enc_compact places them; three more launches).  A function of the shapes only; QOIMI_ENC_LOOKBACK=0/1 forces one form.
-    // Both give the same bytes.
-    const bool lookback = c->enc_lookback >= 0 ? c->enc_lookback != 0 : (n_images >= 8 || p.sets_per_image <= 1024u);
-    p.lookback = lookback ? 1 : 0;
+    const int place = p.lookback;
+    const bool lookback = place != 0;
     const size_t T = (size_t)p.n_images * p.spi, G = (size_t)p.n_images * p.gpi, S = (size_t)p.n_images * p.sets_per_image;
     if (T > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (slab index overflows 32 bits)");
     // Scratch.  Order-free: every set parks its bytes in a slot of its own until the placement passes run (few large images:
@@ -350,6 +365,13 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         p.status = w.take<u64>(S); p.ticket = w.take<uint32_t>((size_t)n_images); p.err = w.take<uint32_t>(1);
         p.need_generic = w.take<uint32_t>((size_t)n_images); p.any_generic = w.take<uint32_t>(1);
         p.status_gen = w.take<u64>(lookback ? S_gen : 0); p.ticket_gen = w.take<uint32_t>(lookback ? (size_t)n_images : 0);
+        {   // tree placement: totals of the groups of 64 sets and of the blocks of 64 groups, for the first pass and for the generic one
+            const size_t n1 = (p.sets_per_image + 63u) / 64u, n2 = (n1 + 63u) / 64u;
+            const size_t sg1 = (S_gen / (size_t)n_images + 63u) / 64u, sg2 = (sg1 + 63u) / 64u;
+            const size_t on = place == 2 ? (size_t)n_images : 0;
+            p.tree1 = w.take<u64>(on * n1); p.tree2 = w.take<u64>(on * n2);
+            p.tree1_gen = w.take<u64>(on * sg1); p.tree2_gen = w.take<u64>(on * sg2);
+        }
         p.pool_map = w.take<u64>(lookback ? (size_t)(p.pool_slots / 64u) * kEncPoolMapStride : 0);
         const size_t zero_bytes = w.off;
         p.sum_tab = w.take<uint32_t>(T * 64); p.sum_valid = w.take<u64>(T); p.sum_le = w.take<int>(T);

@@ -35,6 +35,7 @@ constexpr uint32_t kEncSlabWorst = kEncSlabPx * 5u;   // most bytes a slab can p
 constexpr uint32_t kEncPoolSlots = 8192;              // look-back mode: scratch slots of the sets that spill, handed out by a bitmap (more than the 6144
                                                       // wavefronts of enc_sets a chip holds at a time: a set keeps its slot from its first spill to its copy-out)
 constexpr uint32_t kEncPoolMapStride = 16;            // u64 words between two words of the pool's bitmap: one word per 128-byte line
+constexpr uint32_t kEncTreeMaxSets = 12288;          // automatic choice of the placement: an image of more sets than this is placed order-free, not by the tree
 constexpr uint32_t kEncGenSetSlabs = 8;               // slabs per set of the generic pass when it places by look-back (flat content: few bytes per slab)
 
 struct EncParams {
@@ -53,6 +54,7 @@ struct EncParams {
     uint8_t probe_xchg;      // 1: ds_wrxchg colour-table probe (needs the LDS order self-test to have passed)
     uint8_t use_ticket;      // 1: set ids by atomic ticket (start order); 0: by blockIdx
     uint8_t lookback;        // 1: a set finds its place in the stream by decoupled look-back and writes its bytes itself;
+                             // 2: the same by the three-level tree of byte counts (tree1 / tree2; calls of a few large images);
                              // 0: order-free - sets park their bytes in scratch slots, enc_offsets + enc_compact place them
     uint8_t warm;            // 1: sets find their entry state themselves (look-back window), E1/E2 only for flagged images
     uint8_t only_flagged;    // set by the launcher: this pass handles images with need_generic[img] != 0 only
@@ -65,6 +67,8 @@ struct EncParams {
     uint32_t* grp_tab;   u64* grp_valid;  int* grp_le;     // E2a aggregate [n_images*gpi]
     uint32_t* gent_tab;  int* gent_le;                     // E2b out       [n_images*gpi]
     u64* status;         // look-back records [n_images*sets_per_image]   -- zeroed before every launch
+    u64* tree1;          // lookback == 2: totals of the groups of 64 sets [n_images * ceil(sets_per_image / 64)]        -- zeroed before every launch
+    u64* tree2;          // lookback == 2: totals of the blocks of 64 groups [n_images * ceil(sets_per_image / 4096)]   -- zeroed before every launch
     uint32_t* ticket;    // per-image ticket counters [n_images]          -- zeroed before every launch
     uint32_t* err;       // liveness-bound flag               -- zeroed before every launch
     uint32_t* need_generic;  // [n_images] image needs the E1/E2 path  -- zeroed before every launch
@@ -77,6 +81,7 @@ struct EncParams {
     // the generic pass of a look-back call places by look-back too, with its own records / tickets and kEncGenSetSlabs slabs per set
     u64* status_gen;     // [n_images * ceil(spi / kEncGenSetSlabs)]                                     -- zeroed before every launch
     uint32_t* ticket_gen;    // [n_images]                                                             -- zeroed before every launch
+    u64* tree1_gen; u64* tree2_gen;   // lookback == 2: the generic pass's group / block totals                -- zeroed before every launch
     uint32_t* set_size;  // [n_images*sets_per_image]  order-free mode
     uint32_t* set_off;   // [n_images*sets_per_image]  order-free mode
     // output

@@ -205,6 +205,40 @@ def test_4k_frame_device_path(api, ctx, oracle, kind):
     assert ctx.decode_stats()["segments"] > 0
 
 
+@pytest.mark.parametrize("slabs", ["1", "3"])
+def test_tree_placement_three_levels(api, oracle, slabs):
+    """Tree placement with sets past one block of 64 groups (more than 4096 sets per image): three 2800 x 1600 images at one slab
+    per set (4375 sets each: 69 groups, 2 blocks) - a photograph, noise (every set spills through the pool) and a flat UI frame
+    (the generic pass, which places by its own tree) - byte-identical to the reference; 3 and 4 channels."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    old = {k: os.environ.get(k) for k in ("QOIMI_ENC_SET_SLABS", "QOIMI_ENC_LOOKBACK")}
+    os.environ["QOIMI_ENC_SET_SLABS"] = slabs
+    os.environ["QOIMI_ENC_LOOKBACK"] = "2"
+    try:
+        c = api.Context(0)
+        w, h = 2800, 1600
+        for ch in (4, 3):
+            kinds = ["photo", "noise", "uiflat"]
+            frames = [np.ascontiguousarray(synth.frame_rgba(k, w, h, 77 + i)[:, :, :ch]) for i, k in enumerate(kinds)]
+            b = DeviceBatch(c, w, h, ch, len(kinds))
+            for i, f in enumerate(frames):
+                b.upload(i, f)
+            lens = b.encode()
+            torch.cuda.synchronize()
+            for i, f in enumerate(frames):
+                want = oracle.encode(f, w, h, ch)
+                assert b.stream_bytes(i, lens[i]) == want, (slabs, ch, kinds[i], int(lens[i]), len(want))
+        c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_batch_1080p_frames(api, ctx, oracle):
     """BASELINE config 3 shape (batch of 1920x1080 frames), 12 distinct frames, mixed content."""
     import torch
@@ -295,6 +329,9 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_SET_SLABS": "4"},                         # four slabs per wavefront (what large batches use), look-back placement
     {"QOIMI_ENC_SET_SLABS": "8", "QOIMI_ENC_WARM": "0"},
     {"QOIMI_ENC_SET_SLABS": "3", "QOIMI_ENC_LOOKBACK": "0"},
+    {"QOIMI_ENC_LOOKBACK": "2"},                          # tree placement (what calls of a few large images take): three windows of byte counts per set
+    {"QOIMI_ENC_LOOKBACK": "2", "QOIMI_ENC_WARM": "0"},   # ... with the entry states from the summary passes
+    {"QOIMI_ENC_LOOKBACK": "2", "QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_PROBE": "0"},
     {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_PROBE": "0"},
     {"QOIMI_ENC_TICKET": "0"},                            # sets by workgroup index instead of by ticket
     {"QOIMI_ENC_PROBE": "0"},                             # order-independent colour-table probe (ds_or masks)
@@ -485,7 +522,7 @@ def test_decode_repair_loop_is_bounded(api, oracle, rounds):
 
 
 @pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_WARM": "0"}, {"QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_SET_SLABS": "4"},
-                                 {"QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "0"}])
+                                 {"QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_LOOKBACK": "2"}])
 def test_flat_frames_byte_identical(api, oracle, env):
     """Flat UI frames go through the generic entry-state path (per-slab summaries + scans).  Frame 60 of this sweep was
     encoded three bytes too long by every path until round 2: a 64-bit lane mask lost its upper half (sign extension of
@@ -564,10 +601,11 @@ def test_random_sweep_of_contents_and_shapes(api, oracle, env):
 
 
 @pytest.mark.parametrize("slabs", [1, 2, 3, 4, 5, 8])
-@pytest.mark.parametrize("lookback", ["1", "0", "nospread"])
+@pytest.mark.parametrize("lookback", ["1", "0", "nospread", "2"])
 def test_set_sizes_and_placements(api, oracle, slabs, lookback):
     """A wavefront encodes a SET of R consecutive slabs (R = 1..8; the library picks it from the batch size, here it is forced) and
-    places its bytes by look-back (bytes beyond the staging buffer spill through the set's scratch slot) or order-free.  Shapes
+    places its bytes by look-back (bytes beyond the staging buffer spill through the set's scratch slot), by the tree of byte
+    counts ("2") or order-free.  Shapes
     with a partial last set / last group / last step, every content class in 3 and 4 channels: byte-identical to the reference."""
     import torch
     from gpu_util import DeviceBatch
@@ -624,7 +662,8 @@ def _mixed_frame(rng, w, h, ch, seed):
 
 
 @pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_SET_SLABS": "3"}, {"QOIMI_ENC_SET_SLABS": "8"}, {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
-                                 {"QOIMI_ENC_SPREAD": "0"}, {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "3"}])
+                                 {"QOIMI_ENC_SPREAD": "0"}, {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "3"},
+                                 {"QOIMI_ENC_LOOKBACK": "2"}, {"QOIMI_ENC_LOOKBACK": "2", "QOIMI_ENC_SET_SLABS": "3"}])
 def test_mixed_content_partial_spills(api, oracle, env):
     """Sets whose bytes only partly fit the LDS staging buffer ."""
     import torch
