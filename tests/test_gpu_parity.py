@@ -323,17 +323,17 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
 
 
 @pytest.mark.parametrize("env", [
-    {"QOIMI_ENC_WARM": "0"},                              # entry states from per-slab summaries + scans for every image
+    {"QOIMI_ENC_WARM": "0", "QOIMI_ENC_LOOKBACK": "1"},   # entry states from per-slab summaries + scans for every image (look-back placement)
     {"QOIMI_ENC_LOOKBACK": "0"},                          # order-free placement: sets park their bytes, enc_offsets + enc_compact place them
     {"QOIMI_ENC_LOOKBACK": "0", "QOIMI_ENC_WARM": "0"},   # ... with the entry states from the summary passes
-    {"QOIMI_ENC_SET_SLABS": "4"},                         # four slabs per wavefront (what large batches use), look-back placement
-    {"QOIMI_ENC_SET_SLABS": "8", "QOIMI_ENC_WARM": "0"},
+    {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "1"},   # four slabs per wavefront, look-back placement (forced: a call of four images takes the tree)
+    {"QOIMI_ENC_SET_SLABS": "8", "QOIMI_ENC_WARM": "0", "QOIMI_ENC_LOOKBACK": "1"},
     {"QOIMI_ENC_SET_SLABS": "3", "QOIMI_ENC_LOOKBACK": "0"},
     {"QOIMI_ENC_LOOKBACK": "2"},                          # tree placement (what calls of a few large images take): three windows of byte counts per set
     {"QOIMI_ENC_LOOKBACK": "2", "QOIMI_ENC_WARM": "0"},   # ... with the entry states from the summary passes
     {"QOIMI_ENC_LOOKBACK": "2", "QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_PROBE": "0"},
-    {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_PROBE": "0"},
-    {"QOIMI_ENC_TICKET": "0"},                            # sets by workgroup index instead of by ticket
+    {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_PROBE": "0", "QOIMI_ENC_LOOKBACK": "1"},
+    {"QOIMI_ENC_TICKET": "0", "QOIMI_ENC_LOOKBACK": "1"},  # look-back with sets by workgroup index instead of by ticket
     {"QOIMI_ENC_PROBE": "0"},                             # order-independent colour-table probe (ds_or masks)
     {"QOIMI_DEC_FINE": "0", "QOIMI_SEG_BYTES": "2048"},   # lane-per-segment P1/P2 instead of 128-byte pieces
     {"QOIMI_SEG_BYTES": "1024"},                          # P1/P2 on 8 pieces per segment
@@ -347,10 +347,10 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_DEC_L2M": "2"},                               # the per-image level of the state chain as eight workgroups per image (calls of a few large images take it)
     {"QOIMI_DEC_L2M": "2", "QOIMI_SEG_BYTES": "128"},     # ... with many groups per image, several rounds (uiflat)
     {"QOIMI_DEC_L2M": "0"},                               # ... never
-    {"QOIMI_ENC_PERSIST": "3"},                           # three workgroups walk all units (grid-stride loop of enc_sets)
-    {"QOIMI_ENC_SPREAD": "0"},                            # the four wavefronts of a workgroup take their tickets from ONE image (the default: from consecutive images)
-    {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "2"},
-    {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_PERSIST": "3"},  # ... in the grid-stride loop
+    {"QOIMI_ENC_PERSIST": "3", "QOIMI_ENC_LOOKBACK": "1"},  # three workgroups walk all units (grid-stride loop of enc_sets; look-back with tickets)
+    {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_LOOKBACK": "1"},  # the four wavefronts of a workgroup take their tickets from ONE image (the default: from consecutive images)
+    {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "1"},
+    {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_PERSIST": "3", "QOIMI_ENC_LOOKBACK": "1"},  # ... in the grid-stride loop
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
@@ -522,7 +522,8 @@ def test_decode_repair_loop_is_bounded(api, oracle, rounds):
 
 
 @pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_WARM": "0"}, {"QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_SET_SLABS": "4"},
-                                 {"QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_LOOKBACK": "2"}])
+                                 {"QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_LOOKBACK": "2"}, {"QOIMI_ENC_LOOKBACK": "1"},
+                                 {"QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "4"}])
 def test_flat_frames_byte_identical(api, oracle, env):
     """Flat UI frames go through the generic entry-state path (per-slab summaries + scans).  Frame 60 of this sweep was
     encoded three bytes too long by every path until round 2: a 64-bit lane mask lost its upper half (sign extension of
@@ -661,9 +662,10 @@ def _mixed_frame(rng, w, h, ch, seed):
     return np.ascontiguousarray(a.reshape(h, w, 4)[:, :, :ch])
 
 
-@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_SET_SLABS": "3"}, {"QOIMI_ENC_SET_SLABS": "8"}, {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
-                                 {"QOIMI_ENC_SPREAD": "0"}, {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "3"},
-                                 {"QOIMI_ENC_LOOKBACK": "2"}, {"QOIMI_ENC_LOOKBACK": "2", "QOIMI_ENC_SET_SLABS": "3"}])
+@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_LOOKBACK": "1"}, {"QOIMI_ENC_SET_SLABS": "3", "QOIMI_ENC_LOOKBACK": "1"}, {"QOIMI_ENC_SET_SLABS": "8", "QOIMI_ENC_LOOKBACK": "1"},
+                                 {"QOIMI_ENC_SET_SLABS": "4", "QOIMI_ENC_LOOKBACK": "0"},
+                                 {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_LOOKBACK": "1"}, {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "3", "QOIMI_ENC_LOOKBACK": "1"},
+                                 {"QOIMI_ENC_LOOKBACK": "2", "QOIMI_ENC_SET_SLABS": "1"}, {"QOIMI_ENC_LOOKBACK": "2", "QOIMI_ENC_SET_SLABS": "3"}])
 def test_mixed_content_partial_spills(api, oracle, env):
     """Sets whose bytes only partly fit the LDS staging buffer ."""
     import torch
