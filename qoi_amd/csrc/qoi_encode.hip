@@ -863,7 +863,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     // The pipelined loop below handles the groups that lie inside the image (all 64 lanes of every step valid, the probe may
     // run with all lanes); the image's first set and the group that holds the image's last pixel take the general form after it.
     const bool gen_set = lo == 0u;
-    const uint32_t nint = gen_set ? 0u : (last_set ? ngroups - 1u : ngroups);
+    uint32_t nint = gen_set ? 0u : (last_set ? ngroups - 1u : ngroups);
     uint32_t ax[kGroupSteps], av[kGroupSteps], bx[kGroupSteps], bv[kGroupSteps];
     if (nint) load_group<CH>(pix, lo, lane, ax, av);
 
@@ -886,6 +886,13 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         last_edge = max(__builtin_amdgcn_readfirstlane(in.le_loc), __builtin_amdgcn_readfirstlane(in.le_far));   // max edge position < lo, or -1
     }
     if (PROBE == 0) L.mask[lane] = 0;
+    // A set that begins BEFORE the image's first edge - the image opens with more pixels of the start value {0,0,0,255} (qoi.h:396-399)
+    // than the sets in front of this one hold: a letterboxed frame's black rows - takes the general form too: its repeat pixels repeat
+    // a value that no edge has written to the table, and the all-lanes probe of the plain form (probe_swap_all) would write it
+    // there; the first later edge pixel of that value then found itself and became QOI_OP_INDEX 53 where qoi.h:430-436 finds the
+    // zeroed slot and writes a literal chunk (round trip exact, bytes not the reference's; found by tests/fuzz_encode.py in round 4:
+    // until then only the image's first set took the general form).  The group loaded ahead is dropped.
+    if (last_edge < 0) nint = 0u;
     uint32_t ccp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(63u + (uint32_t)((int)lo - last_edge)));
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_setprio(0);

@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Differential fuzz harness for the GPU ENCODER (companion of tests/fuzz_decode.py).
+
+Random images of random shapes, channel counts and batch sizes go through qoimi_encode_batch; every stream must be
+byte-identical to what the reference encoder (qoi.h:356-486; the unmodified reference where oracle/_ref is built, else the C
+restatement) writes for the same pixels, and decode back to the pixels through qoimi_decode_batch.  The images are made to
+exercise what the set-parallel encoder cuts across: runs that cross step / group / slab / set boundaries and the 62 cap
+(qoi.h:417-421), palettes whose colours share hash slots (qoi.h:430-436), alpha steps (qoi.h:461-474), stretches of noise that
+spill a set's bytes, and flat content that takes the generic entry-state path.  Batch sizes 1..12 cover the three placement
+forms (tree, look-back, order-free by QOIMI_ENC_LOOKBACK).
+
+    python tests/fuzz_encode.py --iters 300 --seed 1            # needs an MI355X
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def random_image(rng: np.random.Generator, w: int, h: int) -> np.ndarray:
+    """h x w x 4 uint8: a patchwork of stretches (along the scan order, as the encoder sees the pixels)."""
+    n = w * h
+    a = np.empty((n, 4), dtype=np.uint8)
+    palette = rng.integers(0, 256, size=(int(rng.integers(2, 40)), 4), dtype=np.uint8)
+    if rng.random() < 0.5:
+        palette[:, 3] = 255
+    elif rng.random() < 0.5:
+        palette[:, 3] = rng.choice([0, 128, 255], size=len(palette))
+    pos = 0
+    cur = palette[0].astype(np.int64)
+    while pos < n:
+        kind = int(rng.integers(0, 8))
+        L = int(rng.choice([1, 2, 3, 5, 61, 62, 63, 64, 65, 124, 125, 500, 1024, 1025, 3071, 3072, 3100, 9000, 40000]))
+        L = max(1, min(n - pos, int(L * rng.uniform(0.5, 1.5)) if rng.random() < 0.5 else L))
+        seg = a[pos:pos + L]
+        if kind == 0:                                             # one colour: a run (crosses whatever boundary lies in it)
+            seg[:] = palette[int(rng.integers(0, len(palette)))]
+        elif kind == 1:                                           # palette tiles of random width: INDEX hits and slot collisions
+            tw = int(rng.integers(1, 200))
+            idx = rng.integers(0, len(palette), size=L // tw + 2)
+            seg[:] = palette[np.repeat(idx, tw)[:L]]
+        elif kind == 2:                                           # noise (5-byte / 4-byte chunks: sets spill)
+            seg[:] = rng.integers(0, 256, size=(L, 4), dtype=np.uint8)
+            if rng.random() < 0.5:
+                seg[:, 3] = cur[3]
+        elif kind == 3:                                           # small steps: DIFF / LUMA with wrap-around
+            d = rng.integers(-3, 4, size=(L, 3))
+            if rng.random() < 0.5:
+                d[:, 1] = rng.integers(-33, 34, size=L)
+                d[:, 0] = d[:, 1] + rng.integers(-9, 9, size=L)
+                d[:, 2] = d[:, 1] + rng.integers(-9, 9, size=L)
+            seg[:, :3] = (cur[:3] + np.cumsum(d, axis=0)) & 255
+            seg[:, 3] = cur[3]
+        elif kind == 4:                                           # gradient with repeats: short runs between small deltas
+            rep = int(rng.integers(1, 9))
+            base = (cur[:3] + np.cumsum(rng.integers(-2, 2, size=(L // rep + 2, 3)), axis=0)) & 255
+            seg[:, :3] = np.repeat(base, rep, axis=0)[:L]
+            seg[:, 3] = cur[3]
+        elif kind == 5:                                           # alpha steps on an otherwise smooth stretch
+            seg[:, :3] = (cur[:3] + np.cumsum(rng.integers(-1, 2, size=(L, 3)), axis=0)) & 255
+            seg[:, 3] = np.repeat(rng.integers(0, 256, size=L // 7 + 2), 7)[:L]
+        elif kind == 6:                                           # two colours alternating: INDEX every pixel
+            c = palette[rng.integers(0, len(palette), size=2)]
+            seg[:] = c[np.arange(L) & 1]
+        else:                                                     # the start value and its neighbours (qoi.h:396-399: {0,0,0,255} is never in the table)
+            seg[:] = np.array([0, 0, 0, 255], dtype=np.uint8)
+            if L > 4 and rng.random() < 0.5:
+                seg[L // 2] = (0, 0, 0, 0)
+        cur = seg[-1].astype(np.int64)
+        pos += L
+    return a.reshape(h, w, 4)
+
+
+def random_shape(rng: np.random.Generator, max_px: int):
+    mode = int(rng.integers(0, 5))
+    if mode == 0:
+        w, h = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    elif mode == 1:                                               # around slab / set multiples (1024, 3072 pixels)
+        px = int(rng.choice([1023, 1024, 1025, 2048, 3071, 3072, 3073, 6144, 9216, 65536, 65537])) + int(rng.integers(-2, 3))
+        w = int(rng.choice([1, 2, 7, 64, 511, 1024])); h = max(1, px // w)
+    elif mode == 2:
+        w, h = int(rng.integers(200, 2000)), int(rng.integers(100, 1200))
+    elif mode == 3:                                               # very wide / very tall
+        w, h = (int(rng.integers(3000, 20000)), int(rng.integers(1, 40))) if rng.random() < 0.5 else (int(rng.integers(1, 40)), int(rng.integers(3000, 20000)))
+    else:
+        w, h = int(rng.integers(1500, 4200)), int(rng.integers(900, 2400))
+    while w * h > max_px:
+        h = max(1, h // 2)
+    return w, h
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=200, help="calls of qoimi_encode_batch (1..12 images each)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-pixels", type=int, default=6_000_000)
+    ap.add_argument("--only", type=int, default=-1, help="replay: run this iteration alone (the random sequence of the others is drawn and discarded)")
+    ap.add_argument("--form", default=None, help="replay: override QOIMI_ENC_LOOKBACK ('' = the library's choice)")
+    ap.add_argument("--slabs", default=None, help="replay: override QOIMI_ENC_SET_SLABS")
+    ap.add_argument("--keep-going", action="store_true", help="report every mismatch instead of stopping at the first")
+    args = ap.parse_args()
+    import torch
+    from gpu_util import DeviceBatch
+    from oracle import oracle_py
+    from qoi_amd import api
+    ref = oracle_py.load_ref() or oracle_py.load_port()
+    rng = np.random.default_rng(args.seed)
+    images = px_total = failures = 0
+    t0 = time.time()
+    forms = {"": 0, "0": 0, "1": 0, "2": 0}
+    for it in range(args.iters):
+        w, h = random_shape(rng, args.max_pixels)
+        ch = int(rng.choice([3, 4]))
+        n = int(rng.choice([1, 1, 1, 2, 3, 7, 8, 9, 12]))
+        while n > 1 and n * w * h > 2 * args.max_pixels:
+            n -= 1
+        form = str(rng.choice(["", "", "", "0", "1", "2"]))           # mostly the library's own choice
+        slabs = str(rng.choice(["", "", "1", "2", "3", "5"]))
+        for k, v in (("QOIMI_ENC_LOOKBACK", form), ("QOIMI_ENC_SET_SLABS", slabs)):
+            if v:
+                os.environ[k] = v
+            else:
+                os.environ.pop(k, None)
+        frames = [np.ascontiguousarray(random_image(rng, w, h)[:, :, :ch]) for _ in range(n)]
+        if args.only >= 0 and it != args.only:
+            continue
+        if args.form is not None:
+            form = args.form
+        if args.slabs is not None:
+            slabs = args.slabs
+        for k, v in (("QOIMI_ENC_LOOKBACK", form), ("QOIMI_ENC_SET_SLABS", slabs)):
+            if v:
+                os.environ[k] = v
+            else:
+                os.environ.pop(k, None)
+        forms[form] += 1
+        c = api.Context(0)
+        b = DeviceBatch(c, w, h, ch, n)
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        lens = b.encode()
+        torch.cuda.synchronize()
+        for i, f in enumerate(frames):
+            want = ref.encode(f, w, h, ch)
+            got = b.stream_bytes(i, lens[i])
+            if got != want:
+                path = f"/tmp/fuzz_encode_fail_{args.seed}_{it}_{i}.npy"
+                np.save(path, f)
+                g8, w8 = np.frombuffer(got, dtype=np.uint8), np.frombuffer(want, dtype=np.uint8)
+                m = min(len(g8), len(w8))
+                first = int(np.argmax(g8[:m] != w8[:m])) if (g8[:m] != w8[:m]).any() else m
+                print(f"MISMATCH iter {it} image {i}: {w}x{h}x{ch}, batch {n}, form '{form}', slabs '{slabs}': {len(got)} bytes against {len(want)}, first difference at byte {first}"
+                      f" (got {g8[first:first + 8].tolist()} want {w8[first:first + 8].tolist()}); pixels saved to {path}")
+                failures += 1
+                if not args.keep_going:
+                    return 1
+        out = torch.full((n * b.pixel_stride,), 0xCD, dtype=torch.uint8, device="cuda")
+        stride = b.decode_into(out, lens, ch)
+        got = out.cpu().numpy()
+        for i, f in enumerate(frames):
+            if not np.array_equal(got[i * stride:i * stride + w * h * ch], f.reshape(-1)):
+                print(f"ROUND TRIP MISMATCH iter {it} image {i}: {w}x{h}x{ch}, batch {n}")
+                return 1
+        images += n
+        px_total += n * w * h
+        c.close()
+        del b, out
+    print(f"fuzz_encode: {args.iters} calls, {images} images, {px_total / 1e6:.0f} Mpx, seed {args.seed}: every stream byte-identical to the {ref.kind} encoder's, "
+          f"every round trip exact; placement forced order-free / look-back / tree in {forms['0']} / {forms['1']} / {forms['2']} calls, the library's choice in {forms['']}; "
+          f"{time.time() - t0:.0f} s" + (f"; {failures} MISMATCHES" if failures else ""))
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

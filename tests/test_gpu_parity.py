@@ -239,6 +239,55 @@ def test_tree_placement_three_levels(api, oracle, slabs):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_LOOKBACK": "0", "QOIMI_ENC_SET_SLABS": "1"}, {"QOIMI_ENC_LOOKBACK": "1"},
+                                 {"QOIMI_ENC_LOOKBACK": "2", "QOIMI_ENC_SET_SLABS": "1"}, {"QOIMI_ENC_WARM": "0", "QOIMI_ENC_SET_SLABS": "2"},
+                                 {"QOIMI_ENC_PROBE": "0"}])
+def test_start_value_runs_past_the_first_set(api, oracle, env):
+    """An image that OPENS with pixels of the start value {0,0,0,255} (qoi.h:396-399) - a letterboxed frame's black rows - for longer
+    than its first set: those pixels are repeats of a value no edge has put into the colour table, so the first later pixel of that
+    value must NOT find itself there (qoi.h:430-436: the slot is still zero, a literal chunk follows).  Round 4's encoder fuzz
+    (tests/fuzz_encode.py) found the plain form of a step writing it through its all-lanes probe: QOI_OP_INDEX 53 instead of the
+    reference's chunk, round trip exact, four bytes short.  Opening runs around every set size, 3 and 4 channels, every placement."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = api.Context(0)
+        w, h = 1000, 40
+        for ch in (4, 3):
+            opens = [1000, 1024, 1025, 2047, 3072, 3073, 8191, 8192, 8193, 20000, 39999]
+            frames = []
+            for k, n0 in enumerate(opens):
+                a = np.zeros((w * h, 4), dtype=np.uint8); a[:, 3] = 255
+                rest = synth.frame_rgba("photo" if k % 2 else "uiflat", w, h, 50 + k).reshape(-1, 4)
+                a[n0:] = rest[n0:]
+                a[n0 + 1::97] = (0, 0, 0, 255)                 # the start value again, as an edge pixel, here and there
+                a[n0:, 3] = 255
+                frames.append(np.ascontiguousarray(a.reshape(h, w, 4)[:, :, :ch]))
+            # a letterboxed frame: black rows on top and bottom, a photograph between them
+            lb = synth.frame_rgba("photo", w, h, 99).copy(); lb[:12] = (0, 0, 0, 255); lb[-9:] = (0, 0, 0, 255); lb[:, :, 3] = 255
+            frames.append(np.ascontiguousarray(lb[:, :, :ch]))
+            for n in (1, len(frames)):                       # alone (tree / order-free) and as a batch (look-back)
+                b = DeviceBatch(c, w, h, ch, n)
+                use = frames[-n:]
+                for i, f in enumerate(use):
+                    b.upload(i, f)
+                lens = b.encode()
+                torch.cuda.synchronize()
+                for i, f in enumerate(use):
+                    want = oracle.encode(f, w, h, ch)
+                    assert b.stream_bytes(i, lens[i]) == want, (env, ch, n, i, int(lens[i]), len(want))
+        c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_batch_1080p_frames(api, ctx, oracle):
     """BASELINE config 3 shape (batch of 1920x1080 frames), 12 distinct frames, mixed content."""
     import torch
