@@ -37,7 +37,7 @@ def random_image(rng: np.random.Generator, w: int, h: int) -> np.ndarray:
     pos = 0
     cur = palette[0].astype(np.int64)
     while pos < n:
-        kind = int(rng.integers(0, 8))
+        kind = int(rng.integers(0, 10))
         L = int(rng.choice([1, 2, 3, 5, 61, 62, 63, 64, 65, 124, 125, 500, 1024, 1025, 3071, 3072, 3100, 9000, 40000]))
         L = max(1, min(n - pos, int(L * rng.uniform(0.5, 1.5)) if rng.random() < 0.5 else L))
         seg = a[pos:pos + L]
@@ -70,6 +70,20 @@ def random_image(rng: np.random.Generator, w: int, h: int) -> np.ndarray:
         elif kind == 6:                                           # two colours alternating: INDEX every pixel
             c = palette[rng.integers(0, len(palette), size=2)]
             seg[:] = c[np.arange(L) & 1]
+        elif kind == 7:                                           # colours that share ONE hash slot, in short tiles: every change evicts (qoi.h:430-436)
+            k = int(rng.integers(2, 6))
+            c = rng.integers(0, 256, size=(k, 4), dtype=np.int64)
+            if rng.random() < 0.5:
+                c[:, 3] = cur[3]
+            slot = int(rng.integers(0, 64))
+            c[:, 0] = ((slot - 5 * c[:, 1] - 7 * c[:, 2] - 11 * c[:, 3]) * 43 % 64) + 64 * rng.integers(0, 4, size=k)   # 3 * 43 = 1 (mod 64)
+            tw = int(rng.integers(1, 6))
+            seg[:] = c[np.repeat(rng.integers(0, k, size=L // tw + 2), tw)[:L]].astype(np.uint8)
+        elif kind == 8:                                           # all-zero pixels: equal to the zeroed table's words (qoi.h:393), INDEX 0 without ever having been stored
+            seg[:] = palette[np.repeat(rng.integers(0, len(palette), size=L // 9 + 2), 9)[:L]]
+            seg[rng.random(L) < 0.2] = 0
+            if rng.random() < 0.3:
+                seg[: L // 2] = 0
         else:                                                     # the start value and its neighbours (qoi.h:396-399: {0,0,0,255} is never in the table)
             seg[:] = np.array([0, 0, 0, 255], dtype=np.uint8)
             if L > 4 and rng.random() < 0.5:

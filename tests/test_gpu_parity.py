@@ -963,3 +963,15 @@ def test_spilling_sets_share_a_scratch_pool(api, oracle):
     ws = c.workspace_bytes()["encode"]
     assert ws < 700 << 20, ws            # generic-path tables 0.13 GB + pool 0.34 GB (a worst-case slot per set: 1.3 GB more)
     c.close()
+
+
+def test_encoder_fuzz_short_campaign(api):
+    """A short campaign of tests/fuzz_encode.py (random patchwork images, shapes, channel counts, batch sizes 1..12, forced and
+    free placement / set sizes): every stream byte-identical to the reference encoder's, every round trip exact.  Longer runs are
+    kept under profiles/ (r04_fuzz_encode.txt)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_encode.py"), "--iters", "60", "--seed", "11",
+                        "--max-pixels", "3000000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "every stream byte-identical" in r.stdout
