@@ -6,7 +6,7 @@ byte-identical to what the reference encoder (qoi.h:356-486; the unmodified refe
 restatement) writes for the same pixels, and decode back to the pixels through qoimi_decode_batch.  The images are made to
 exercise what the set-parallel encoder cuts across: runs that cross step / group / slab / set boundaries and the 62 cap
 (qoi.h:417-421), palettes whose colours share hash slots (qoi.h:430-436), alpha steps (qoi.h:461-474), stretches of noise that
-spill a set's bytes, and flat content that takes the generic entry-state path.  Batch sizes 1..12 cover the three placement
+spill a set's bytes, and flat content that takes the generic entry-state path.  Batch sizes 1..300 cover the three placement
 forms (tree, look-back, order-free by QOIMI_ENC_LOOKBACK).
 
     python tests/fuzz_encode.py --iters 300 --seed 1            # needs an MI355X
@@ -113,7 +113,7 @@ def random_shape(rng: np.random.Generator, max_px: int):
 
 def main() -> int:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=200, help="calls of qoimi_encode_batch (1..12 images each)")
+    ap.add_argument("--iters", type=int, default=200, help="calls of qoimi_encode_batch (1..300 images each)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-pixels", type=int, default=6_000_000)
     ap.add_argument("--only", type=int, default=-1, help="replay: run this iteration alone (the random sequence of the others is drawn and discarded)")
@@ -133,7 +133,7 @@ def main() -> int:
     for it in range(args.iters):
         w, h = random_shape(rng, args.max_pixels)
         ch = int(rng.choice([3, 4]))
-        n = int(rng.choice([1, 1, 1, 2, 3, 7, 8, 9, 12]))
+        n = int(rng.choice([1, 1, 1, 2, 3, 7, 8, 9, 12, 40, 150, 300]))      # (the large counts only stay large for small shapes)
         while n > 1 and n * w * h > 2 * args.max_pixels:
             n -= 1
         form = str(rng.choice(["", "", "", "0", "1", "2"]))           # mostly the library's own choice
