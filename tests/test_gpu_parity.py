@@ -975,3 +975,15 @@ def test_encoder_fuzz_short_campaign(api):
                         "--max-pixels", "3000000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "every stream byte-identical" in r.stdout
+
+
+def test_decoder_batch_fuzz_short_campaign(api):
+    """A short campaign of tests/fuzz_decode_batch.py: hostile valid-grammar streams (chunk soups no encoder would write, too short and
+    too long for their image) through qoimi_decode_batch in batches, random segment sizes, 3- and 4-channel output - every image equal
+    to the reference decoder's.  Longer runs: profiles/r04_fuzz_decode_batch.txt."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_decode_batch.py"), "--iters", "60", "--seed", "12"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "every image equal" in r.stdout
