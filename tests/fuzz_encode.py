@@ -120,6 +120,8 @@ def main() -> int:
     ap.add_argument("--form", default=None, help="replay: override QOIMI_ENC_LOOKBACK ('' = the library's choice)")
     ap.add_argument("--slabs", default=None, help="replay: override QOIMI_ENC_SET_SLABS")
     ap.add_argument("--keep-going", action="store_true", help="report every mismatch instead of stopping at the first")
+    ap.add_argument("--dropin", action="store_true", help="drive the drop-in qoi_encode / qoi_decode on host pointers instead (one image per call, sizes jumping "
+                    "up and down: the result buffer of qoi_encode is sized by the thread's previous stream)")
     args = ap.parse_args()
     import torch
     from gpu_util import DeviceBatch
@@ -129,6 +131,29 @@ def main() -> int:
     rng = np.random.default_rng(args.seed)
     images = px_total = failures = 0
     t0 = time.time()
+    if args.dropin:
+        for it in range(args.iters):
+            w, h = random_shape(rng, args.max_pixels)
+            ch = int(rng.choice([3, 4]))
+            f = np.ascontiguousarray(random_image(rng, w, h)[:, :, :ch])
+            if rng.random() < 0.25:                                   # all noise: the longest stream right behind a short one
+                f = rng.integers(0, 256, size=f.shape, dtype=np.uint8)
+            got = api.qoi_encode(f, api.QoiDesc(w, h, ch, int(rng.integers(0, 2))))
+            want = ref.encode(f, w, h, ch)
+            ok = got is not None and got[:12] == want[:12] and got[14:] == want[14:]      # (byte 13 = the colorspace handed in)
+            och = int(rng.choice([0, 3, 4]))
+            back, d = api.qoi_decode(want, och) if ok else (None, None)
+            wpx, _ = ref.decode(want, och)
+            if not ok or back is None or not np.array_equal(back, wpx):
+                print(f"DROP-IN MISMATCH iter {it}: {w}x{h}x{ch} -> {och}: encode {'ok' if ok else 'differs'}")
+                failures += 1
+                if not args.keep_going:
+                    return 1
+            images += 1
+            px_total += w * h
+        print(f"fuzz_encode --dropin: {images} qoi_encode + qoi_decode calls on host pointers, {px_total / 1e6:.0f} Mpx, seed {args.seed}: every stream byte-identical to the "
+              f"{ref.kind} encoder's, every decode equal to its decoder's; {time.time() - t0:.0f} s" + (f"; {failures} MISMATCHES" if failures else ""))
+        return 1 if failures else 0
     forms = {"": 0, "0": 0, "1": 0, "2": 0}
     for it in range(args.iters):
         w, h = random_shape(rng, args.max_pixels)
