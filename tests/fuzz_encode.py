@@ -106,6 +106,8 @@ def random_shape(rng: np.random.Generator, max_px: int):
         w, h = (int(rng.integers(3000, 20000)), int(rng.integers(1, 40))) if rng.random() < 0.5 else (int(rng.integers(1, 40)), int(rng.integers(3000, 20000)))
     else:
         w, h = int(rng.integers(1500, 4200)), int(rng.integers(900, 2400))
+    if max_px >= 30_000_000 and rng.random() < 0.35:              # (--max-pixels 45000000: images past 12288 sets, which are placed order-free by default)
+        w, h = int(rng.integers(5000, 9000)), int(rng.integers(3500, 6000))
     while w * h > max_px:
         h = max(1, h // 2)
     return w, h
