@@ -122,6 +122,7 @@ def main() -> int:
     ap.add_argument("--form", default=None, help="replay: override QOIMI_ENC_LOOKBACK ('' = the library's choice)")
     ap.add_argument("--slabs", default=None, help="replay: override QOIMI_ENC_SET_SLABS")
     ap.add_argument("--keep-going", action="store_true", help="report every mismatch instead of stopping at the first")
+    ap.add_argument("--odd-strides", action="store_true", help="device buffers at odd addresses with odd strides; also checks that nothing is written outside a stream / an image")
     ap.add_argument("--dropin", action="store_true", help="drive the drop-in qoi_encode / qoi_decode on host pointers instead (one image per call, sizes jumping "
                     "up and down: the result buffer of qoi_encode is sized by the thread's previous stream)")
     args = ap.parse_args()
@@ -184,6 +185,50 @@ def main() -> int:
                 os.environ.pop(k, None)
         forms[form] += 1
         c = api.Context(0)
+        if args.odd_strides:
+            # buffers at odd addresses with odd strides: the C-ABI states no alignment for d_pixels / d_streams or their strides
+            npx = w * h
+            desc = api.QoiDesc(w, h, ch, 0)
+            po, so, oo = (int(x) for x in rng.integers(0, 16, size=3))
+            ps = npx * ch + int(rng.integers(0, 19)); ss = api.encode_bound(w, h, ch) + int(rng.integers(0, 35)); ost = npx * ch + int(rng.integers(0, 19))
+            d_pix = torch.zeros(po + n * ps + 64, dtype=torch.uint8, device="cuda")
+            d_str = torch.full((so + n * ss + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+            d_out = torch.full((oo + n * ost + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+            d_len = torch.zeros(n, dtype=torch.int32, device="cuda")
+            for i, f in enumerate(frames):
+                d_pix[po + i * ps:po + i * ps + npx * ch].copy_(torch.from_numpy(f.reshape(-1)))
+            st = torch.cuda.current_stream().cuda_stream
+            c.encode_batch(d_pix.data_ptr() + po, ps, desc, n, d_str.data_ptr() + so, ss, d_len.data_ptr(), st)
+            c.encode_status(st)
+            lens = d_len.cpu().numpy()
+            hs = d_str.cpu().numpy()
+            ok = True
+            for i, f in enumerate(frames):
+                want = np.frombuffer(ref.encode(f, w, h, ch), dtype=np.uint8)
+                got = hs[so + i * ss:so + i * ss + int(lens[i])]
+                guard = hs[so + i * ss + int(lens[i]):so + (i + 1) * ss]          # nothing written behind a stream (up to the next one)
+                if len(got) != len(want) or not np.array_equal(got, want) or (len(want) < ss and not (guard == 0xEE).all()):
+                    print(f"MISMATCH (odd strides) iter {it} image {i}: {w}x{h}x{ch}, batch {n}, form '{form}', slabs '{slabs}', offsets {po} {so}, strides {ps} {ss}: "
+                          f"{len(got)} bytes against {len(want)}, bytes behind the stream untouched: {bool((guard == 0xEE).all())}")
+                    ok = False
+            c.decode_batch(d_str.data_ptr() + so, ss, [int(x) for x in lens], [desc] * n, ch, d_out.data_ptr() + oo, ost, st)
+            ho = d_out.cpu().numpy()
+            for i, f in enumerate(frames):
+                if not np.array_equal(ho[oo + i * ost:oo + i * ost + npx * ch], f.reshape(-1)) or not (ho[oo + i * ost + npx * ch:oo + (i + 1) * ost] == 0xCD).all():
+                    print(f"ROUND TRIP MISMATCH (odd strides) iter {it} image {i}: {w}x{h}x{ch}, batch {n}, offset {oo}, stride {ost}")
+                    ok = False
+            if not (ho[:oo] == 0xCD).all() or not (hs[:so] == 0xEE).all():
+                print(f"WRITE IN FRONT OF A BUFFER iter {it}")
+                ok = False
+            if not ok:
+                failures += 1
+                if not args.keep_going:
+                    return 1
+            images += n
+            px_total += n * npx
+            c.close()
+            del d_pix, d_str, d_out
+            continue
         b = DeviceBatch(c, w, h, ch, n)
         for i, f in enumerate(frames):
             b.upload(i, f)
