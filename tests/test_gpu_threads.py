@@ -44,3 +44,16 @@ def test_concurrent_encode_decode(ref, port):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_concurrent_device_frames_under_waiting_placements():
+    """tests/stress_threads.py, short: six threads with their own contexts and streams encode 4K frames at the same time under the tree,
+    look-back and order-free placements - kernels whose sets wait on lower-numbered ones compete for the workgroup slots; every stream
+    equals the reference's, no spin bound trips (qoimi_encode_status).  Longer runs: profiles/r04_stress_threads.txt."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress_threads.py"), "--threads", "6", "--calls", "12"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "no spin bound tripped" in r.stdout
