@@ -102,3 +102,31 @@ def test_port_vs_reference_live(port, ref):
         assert (pa is None) == (pb is None)
         if pa is not None:
             assert np.array_equal(pa, pb)
+
+
+def test_port_vs_reference_on_the_fuzzers_inputs(port, ref):
+    """The generators of the GPU fuzzers (tests/fuzz_encode.py: patchwork images with runs across the 62 cap, colours in one hash
+    slot, alpha steps, all-zero and start-value pixels; tests/fuzz_decode_batch.py: hostile valid-grammar chunk soups, too short and
+    too long for their image) against the C restatement on the CPU: its streams and pixels must equal the unmodified reference's -
+    the restatement is the checker on boxes without oracle/_ref, and these are the inputs that found a deviation in the GPU encoder."""
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    import fuzz_decode_batch
+    import fuzz_encode
+    rng = np.random.default_rng(2024)
+    for _ in range(120):
+        w, h = fuzz_encode.random_shape(rng, 400_000)
+        ch = int(rng.choice([3, 4]))
+        img = np.ascontiguousarray(fuzz_encode.random_image(rng, w, h)[:, :, :ch])
+        a, b = port.encode(img, w, h, ch), ref.encode(img, w, h, ch)
+        assert a == b, (w, h, ch)
+        pa, _ = port.decode(a, 0)
+        assert np.array_equal(pa, img.reshape(-1))
+    for _ in range(120):
+        w, h, ch = int(rng.integers(1, 500)), int(rng.integers(1, 300)), int(rng.choice([3, 4]))
+        s = fuzz_decode_batch.random_stream(rng, w, h, ch, ref)
+        for och in (0, 3, 4):
+            pa, da = port.decode(s, och)
+            pb, db = ref.decode(s, och)
+            assert (pa is None) == (pb is None) and (da.width, da.height, da.channels, da.colorspace) == (db.width, db.height, db.channels, db.colorspace)
+            assert pa is None or np.array_equal(pa, pb), (w, h, ch, och, len(s))
