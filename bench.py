@@ -537,6 +537,8 @@ def main() -> None:
     my_frames = range(first_frame, first_frame + (len(mine) if strong else F))
     px_coded = float(len(my_frames) * npx * args.steps) if regen else float(F * npx * launches)
     st_coded = bytes_coded[0] if regen else float(sum(sizes)) * launches
+    elapsed_mine = elapsed
+    elapsed_min = qdist.reduce_min(elapsed_mine, cdev)               # the fastest rank (skew between ranks = max - min)
     elapsed, (total_px, total_stream_bytes, n_ok, frames_coded, frame_id_sum, synth_ms_max) = qdist.reduce_counters(
         elapsed, [px_coded, st_coded, float(ok), float(len(my_frames)), float(sum(my_frames)), float(synth_ms)], cdev)
 
@@ -577,6 +579,8 @@ def main() -> None:
         out = {
             "metric": "Mpixels/s encode+decode, 4K RGBA", "value": round(value, 1), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "ms_per_step_ranks": {"min": round(elapsed_min / args.steps * 1e3, 4), "max": round(ms_step, 4), "rank0": round(elapsed_mine / args.steps * 1e3, 4),
+                                  "note": "wall clock of the timed region per rank / steps; ms_per_step is the slowest rank's"},
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": (f"batch of {F} x {w}x{h} RGBA frames per GPU per step = one GPU's shard of BASELINE configs[4] (8192 frames over 8 GPUs)"
@@ -645,14 +649,17 @@ def main() -> None:
             out["rgb_input"] = rgb
         if args.encode_only:
             out["config"]["workload"] += " [ENCODE ONLY - diagnostic run, not the benchmark]"
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.kind, w, h, args.cpu_seconds)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.kind, w, h, min(args.cpu_seconds, 6.0))
-        print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # The reference CPU path beside the GPU figure, for EVERY world size: rank 0 times it after the final barrier (the other
+        # ranks are through; the GPUs are idle), so the line the driver parses at N = 2, 4, 8 carries the same objects as at N = 1.
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.kind, w, h, args.cpu_seconds)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.kind, w, h, min(args.cpu_seconds, 6.0))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -56,6 +56,16 @@ def reduce_counters(elapsed_s: float, counters: Sequence[float], device="cpu") -
     return float(t.item()), [float(x) for x in c.cpu().numpy()]
 
 
+def reduce_min(value: float, device="cpu") -> float:
+    """MIN of a per-rank figure over all ranks (the fastest rank's elapsed time: skew = max - min)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
