@@ -29,7 +29,8 @@ Extra objects on the JSON line (rank 0, N = 1 unless noted):
   single_frame         BASELINE configs[1], with its own encode roofline
   encode_1080p_batch   BASELINE configs[2]: 1024 x 1920x1080, encode only
   single_16k           BASELINE configs[3]: one 16384 x 16384 image, encode + decode
-  other_content        the batch with noise / constant / uiflat content
+  other_content        the batch with noise / constant / uiflat / photo_hard (2.1 B/px, LUMA / RGB heavy) / sprite_alpha (soft alpha edges)
+                       content: encode and decode timed apart, both against the roofline, 64 frames per class hashed against the reference encoder
   rgb_input            a quarter of the batch as 3-channel input and output
   cpu_baseline         the unmodified reference (oracle/_ref, else our C port) timed on this
                        host with qoibench.c's BENCHMARK_FN semantics on a bounded sample.
@@ -174,6 +175,34 @@ def check_against_reference(torch, pixels, pstride, streams, sstride, sizes, w, 
     return {"checker": kind, "frames": list(frames), "streams_byte_identical": bool(ident), "reference_decoder_round_trips": bool(rt)}
 
 
+def hash_check_against_reference(torch, ctx, pixels, pstride, streams, sstride, lens, F, w, h, channels, stream, n_sample=64) -> dict:
+    """Byte identity of a whole batch without moving it: the device hashes EVERY stream (qoimi_hash_streams), the reference
+    encoder codes n_sample frames spread over the batch on the host cores (outside every timed region) and its streams are
+    hashed with the same function (synth.stream_hash64): equal 64-bit hashes on all of them."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle_py
+    from qoi_amd import synth
+    lib = oracle_py.load_ref()
+    kind = "reference"
+    if lib is None:
+        lib, kind = oracle_py.load_port(), "port"
+    hashes = torch.zeros(F, dtype=torch.int64, device=pixels.device)
+    ctx.hash_streams(streams.data_ptr(), sstride, lens.data_ptr(), F, hashes.data_ptr(), stream)
+    torch.cuda.synchronize()
+    mine = hashes.cpu().numpy().view(np.uint64)
+    frames = sorted({int(round(x)) for x in np.linspace(0, F - 1, min(n_sample, F))})
+    npx = w * h
+
+    def ref_hash(f):
+        px = pixels[f * pstride:f * pstride + npx * channels].cpu().numpy()
+        return synth.stream_hash64(lib.encode(px, w, h, channels))
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:     # ctypes releases the GIL inside the reference's qoi_encode
+        want = list(ex.map(ref_hash, frames))
+    bad = [f for f, hw in zip(frames, want) if int(mine[f]) != hw]
+    return {"checker": kind, "frames_hashed_on_device": F, "frames_checked_against_reference": len(frames), "mismatches": bad[:8],
+            "all_equal": not bad, "device_hashes": mine}
+
+
 def equal_batches(torch, a, b, F, stride, nbytes) -> bool:
     """decoded == source over the first nbytes of every frame, 64 frames at a time (no batch-sized temporaries)."""
     av, bv = a.view(F, stride), b.view(F, stride)
@@ -265,7 +294,7 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=1024, help="4K frames resident per GPU (= per step when scaling is weak); 1024 = one GPU's shard of BASELINE configs[4]")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="strong: 8192 frames in total (configs[4]), 8192/N per GPU in passes over <= --frames resident frames")
     ap.add_argument("--total-frames", type=int, default=8192, help="frames of the whole job under --scaling strong")
-    ap.add_argument("--kind", default="photo", choices=["photo", "noise", "uiflat", "constant"])
+    ap.add_argument("--kind", default="photo", choices=["photo", "noise", "uiflat", "constant", "photo_hard", "sprite_alpha"])
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -329,6 +358,8 @@ def main() -> None:
     ctx.encode_status(stream)
     sizes = [int(x) for x in lens[:F].cpu().numpy()]
     descs = [desc] * F
+    hash_first = torch.zeros(F, dtype=torch.int64, device=dev)        # every stream of the first encode, hashed on the device
+    ctx.hash_streams(streams.data_ptr(), sstride, lens.data_ptr(), F, hash_first.data_ptr(), stream)
 
     # Strong scaling with more frames per rank than fit at once: every pass codes DIFFERENT frames - the resident buffer is refilled
     # with the pass's frame ids (synthetic frames are made on the device) and the stream lengths are read back after the encode,
@@ -386,6 +417,15 @@ def main() -> None:
     if rank == 0 and not args.encode_only:
         refcheck = check_against_reference(torch, pixels, pstride, streams, sstride, sizes, w, h, sorted({0, min(1, n_last - 1), n_last // 2, n_last - 1}))
         ok = ok and refcheck["streams_byte_identical"] and refcheck["reference_decoder_round_trips"]
+        # ... and byte identity as a property of the whole batch: every stream the LAST timed step wrote is hashed on the device; 64
+        # frames spread over the batch must hash like the reference encoder's streams, and (one pass per step: the same frames every
+        # step) all of them like the streams of the very first encode - a step that wrote other bytes anywhere would show
+        hc = hash_check_against_reference(torch, ctx, pixels, pstride, streams, sstride, lens, n_last, w, h, 4, stream)
+        same_as_first = None if regen else bool(np.array_equal(hc.pop("device_hashes"), hash_first[:n_last].cpu().numpy().view(np.uint64)))
+        hc.pop("device_hashes", None)
+        hc["every_stream_equals_first_encode"] = same_as_first
+        refcheck["hash_check"] = hc
+        ok = ok and hc["all_equal"] and same_as_first is not False
 
     def timed(fn, reps):
         torch.cuda.synchronize()
@@ -426,7 +466,7 @@ def main() -> None:
     other = None
     if world == 1 and not args.encode_only and not args.no_others:
         other = {}
-        for kind in ("noise", "constant", "uiflat"):
+        for kind in ("noise", "constant", "uiflat", "photo_hard", "sprite_alpha", "photo"):
             if kind == args.kind:
                 continue
             ctx.synth_frames(synth.KIND_ID[kind], synth.DEFAULT_SEED, 0, F, w, h, pixels.data_ptr(), pstride, stream)
@@ -434,19 +474,28 @@ def main() -> None:
             ctx.encode_status(stream)
             ksizes = [int(x) for x in lens[:F].cpu().numpy()]
             ctx.decode_batch(streams.data_ptr(), sstride, ksizes, descs, 4, decoded.data_ptr(), pstride, stream)   # warm-up
-
-            def both():
-                ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
-                ctx.decode_batch(streams.data_ptr(), sstride, ksizes, descs, 4, decoded.data_ptr(), pstride, stream)
-            dt = timed(both, 3)
+            enc_k = lambda: ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
+            dec_k = lambda: ctx.decode_batch(streams.data_ptr(), sstride, ksizes, descs, 4, decoded.data_ptr(), pstride, stream)
+            te, td = timed(enc_k, 3), timed(dec_k, 3)
+            dt = te + td
             kok = equal_batches(torch, decoded, pixels, F, pstride, npx * 4)
-            # two frames of every content class against the REFERENCE codec as well (a valid, round-tripping but longer stream -
-            # round 1's uiflat error - is only visible in a byte comparison)
+            # two frames of every content class against the REFERENCE codec (a valid, round-tripping but longer stream - round 1's
+            # uiflat error - is only visible in a byte comparison) and 64 frames spread over the batch by hash
             kchk = check_against_reference(torch, pixels, pstride, streams, sstride, ksizes, w, h, sorted({0, F - 1})) if rank == 0 else None
-            kok = kok and (kchk is None or (kchk["streams_byte_identical"] and kchk["reference_decoder_round_trips"]))
+            if kchk is not None:
+                khc = hash_check_against_reference(torch, ctx, pixels, pstride, streams, sstride, lens, F, w, h, 4, stream)
+                khc.pop("device_hashes", None)
+                kchk["hash_check"] = khc
+            kok = kok and (kchk is None or (kchk["streams_byte_identical"] and kchk["reference_decoder_round_trips"] and kchk["hash_check"]["all_equal"]))
+            kbytes = float(sum(ksizes))
             other[kind] = {"mpixels_per_s": round(F * npx / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
-                           "stream_bytes_per_px": round(sum(ksizes) / (F * npx), 4), "decode_rounds": ctx.decode_stats()["rounds"],
-                           "verified_bit_exact": kok, "reference_check": kchk}
+                           "encode_ms": round(te * 1e3, 3), "decode_ms": round(td * 1e3, 3),
+                           "roofline_encode_frac": round(F * npx * 4 / te / 1e9 / HBM_PEAK_GBS, 4),
+                           "roofline_decode_frac": round((F * npx * 4 + kbytes) / td / 1e9 / HBM_PEAK_GBS, 4),
+                           "stream_bytes_per_px": round(kbytes / (F * npx), 4), "decode_rounds": ctx.decode_stats()["rounds"],
+                           "verified_bit_exact": kok, "reference_check": kchk,
+                           "note": "wall clock of 3 whole qoimi_encode_batch / qoimi_decode_batch calls each; fractions against SURVEY.md 8d's bytes "
+                                   "(encode: 4 B read per pixel; decode: stream bytes + 4 B written per pixel) and the 8 TB/s peak"}
 
     # the same photographs as 3-channel input and output (qoi.h:406-413, 580-586: channels = 3), a quarter of the batch
     rgb = None

@@ -77,7 +77,7 @@ enum {
 };
 
 /* Synthetic content classes (qoi_amd/synth.py states the exact per-pixel function). */
-enum { QOIMI_NOISE = 0, QOIMI_PHOTO = 1, QOIMI_UIFLAT = 2, QOIMI_CONSTANT = 3 };
+enum { QOIMI_NOISE = 0, QOIMI_PHOTO = 1, QOIMI_UIFLAT = 2, QOIMI_CONSTANT = 3, QOIMI_PHOTO_HARD = 4, QOIMI_SPRITE_ALPHA = 5 };
 
 /* Create / destroy a context bound to one GPU.  A context owns a growable device
  * workspace, so steady-state calls do no hipMalloc/hipFree.  ONE call at a time per
@@ -149,6 +149,13 @@ int qoimi_decode_batch(qoimi_ctx *ctx, const void *d_streams, size_t stream_stri
 int qoimi_synth_frames(qoimi_ctx *ctx, int kind, unsigned seed, unsigned first_frame,
                        int n_frames, unsigned width, unsigned height,
                        void *d_pixels, size_t pixel_stride, void *stream);
+
+/* 64-bit content hash of n_streams streams in device memory (stream i: d_stream_len[i] bytes at d_streams + i*stream_stride),
+ * written to the device array d_hash[n_streams]; asynchronous on `stream`.  Benchmark / test utility: whole batches are compared
+ * with hashes of the REFERENCE encoder's streams without copying the streams out (bench.py, qoi_amd/synth.py: stream_hash64 states
+ * the function: sum over the 8-byte little-endian words w_j, last one zero-padded, of splitmix64(w_j + (j+1) * 0x9E3779B97F4A7C15)). */
+int qoimi_hash_streams(qoimi_ctx *ctx, const void *d_streams, size_t stream_stride, const int *d_stream_len, int n_streams,
+                       unsigned long long *d_hash, void *stream);
 
 /* Device memory the context's growable arenas hold at the moment (bytes): [0] encode workspace, [1] decode workspace,
  * [2] staging buffers of the host-pointer entry points (qoi_encode / qoi_decode of the calling thread's context). */

@@ -34,7 +34,7 @@ EXPORTS = (
     "qoimi_ctx_create", "qoimi_ctx_destroy", "qoimi_last_error", "qoimi_encode_bound",
     "qoimi_encode_batch", "qoimi_encode_status", "qoimi_decode_batch", "qoimi_synth_frames",
     "qoimi_decode_stats", "qoimi_version", "qoimi_set_profiling", "qoimi_get_profile", "qoimi_kernel_name",
-    "qoimi_encode_suspect_calls", "qoimi_workspace_bytes",
+    "qoimi_encode_suspect_calls", "qoimi_workspace_bytes", "qoimi_hash_streams",
 )
 
 
@@ -62,6 +62,9 @@ def load_library() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise QoiError(f"{LIB_PATH} not built - run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)")
+    if os.environ.get("QOIMI_LIB"):
+        import sys
+        print(f"qoi_amd: QOIMI_LIB is set - loading {LIB_PATH} instead of the in-tree library (measurement builds only)", file=sys.stderr)
     lib = ctypes.CDLL(LIB_PATH)
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     lib.qoi_encode.restype = vp
@@ -102,6 +105,8 @@ def load_library() -> ctypes.CDLL:
     lib.qoimi_workspace_bytes.argtypes = [vp, ctypes.POINTER(sz)]
     lib.qoimi_encode_suspect_calls.restype = ctypes.c_longlong
     lib.qoimi_encode_suspect_calls.argtypes = [vp]
+    lib.qoimi_hash_streams.restype = ci
+    lib.qoimi_hash_streams.argtypes = [vp, vp, sz, vp, ci, vp, vp]
     _lib = lib
     return lib
 
@@ -245,6 +250,10 @@ class Context:
                      d_pixels: int, pixel_stride: int, stream: int = 0) -> None:
         self._check(self._lib.qoimi_synth_frames(self._h, kind, seed, first_frame, n_frames, width, height,
                                                  d_pixels, pixel_stride, stream), "qoimi_synth_frames")
+
+    def hash_streams(self, d_streams: int, stream_stride: int, d_stream_len: int, n_streams: int, d_hash: int, stream: int = 0) -> None:
+        """64-bit content hash of every stream into the device array d_hash (uint64[n_streams]); synth.stream_hash64 is the same function."""
+        self._check(self._lib.qoimi_hash_streams(self._h, d_streams, stream_stride, d_stream_len, n_streams, d_hash, stream), "qoimi_hash_streams")
 
     def set_profiling(self, on: bool) -> None:
         self._check(self._lib.qoimi_set_profiling(self._h, 1 if on else 0), "qoimi_set_profiling")

@@ -638,7 +638,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
 extern "C" int qoimi_synth_frames(qoimi_ctx* c, int kind, unsigned seed, unsigned first_frame,
                                   int n_frames, unsigned width, unsigned height,
                                   void* d_pixels, size_t pixel_stride, void* stream) {
-    if (!c || !d_pixels || n_frames <= 0 || kind < 0 || kind > 3 || width == 0 || height == 0)
+    if (!c || !d_pixels || n_frames <= 0 || kind < 0 || kind > 5 || width == 0 || height == 0)
         return fail(QOIMI_E_ARG, "bad argument");
     const size_t npx = (size_t)width * height;
     if (npx >= kPixelCap || pixel_stride < npx * 4 || n_frames > 65535) return fail(QOIMI_E_ARG, "bad frame geometry");
@@ -647,6 +647,15 @@ extern "C" int qoimi_synth_frames(qoimi_ctx* c, int kind, unsigned seed, unsigne
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride; p.npx = (uint32_t)npx; p.width = width;
     p.n_frames = (uint32_t)n_frames; p.first_frame = first_frame; p.seed = seed; p.kind = kind;
     launch_synth(p, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return QOIMI_OK;
+}
+
+extern "C" int qoimi_hash_streams(qoimi_ctx* c, const void* d_streams, size_t stream_stride, const int* d_stream_len, int n_streams,
+                                  unsigned long long* d_hash, void* stream) {
+    if (!c || !d_streams || !d_stream_len || !d_hash || n_streams <= 0) return fail(QOIMI_E_ARG, "NULL/empty argument");
+    DeviceGuard guard(c->device);
+    launch_hash_streams((const uint8_t*)d_streams, stream_stride, d_stream_len, (uint32_t)n_streams, (u64*)d_hash, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return QOIMI_OK;
 }

@@ -177,5 +177,6 @@ struct SynthParams {
     int kind;
 };
 void launch_synth(const SynthParams& p, hipStream_t st);
+void launch_hash_streams(const uint8_t* streams, size_t stride, const int* lens, uint32_t n, u64* out, hipStream_t st);
 
 }  // namespace qoimi

@@ -17,12 +17,18 @@ kinds
   ``uiflat``    96x64 tiles from a 16-colour palette with two alpha levels
                                                   -> ~0.1 B/px, RUN/INDEX/RGB(A)
   ``constant``  one colour per frame              -> 0.016 B/px, all QOI_OP_RUN
+  ``photo_hard``  Kodak-like: steeper ramps + 4-bit luma noise shared by r,g,b, 3-bit noise of their own on r and b,
+                a red kick on 1 pixel in 16, low-noise 32-pixel patches (1 in 8), 1 repeat in 64
+                                                  -> ~2.1 B/px; LUMA 73 % / RGB 12 % / DIFF 9 % / INDEX 4 % / RUN 3 %
+  ``sprite_alpha``  256 x 256 sprites of ``photo`` content: opaque disc, an 18-pixel soft edge whose alpha falls
+                255 -> 0, fully transparent {0,0,0,0} outside
+                                                  -> ~1.6 B/px; 29 % of the chunks QOI_OP_RGBA, the rest the photo mix + runs
 """
 from __future__ import annotations
 
 import numpy as np
 
-KINDS = ("noise", "photo", "uiflat", "constant")
+KINDS = ("noise", "photo", "uiflat", "constant", "photo_hard", "sprite_alpha")
 KIND_ID = {k: i for i, k in enumerate(KINDS)}
 DEFAULT_SEED = 12345
 
@@ -67,6 +73,36 @@ def frame_u32(kind: str, width: int, height: int, frame: int = 0,
             return np.full(n, c, dtype=np.uint32)
         x = i % np.uint32(width)
         y = i // np.uint32(width)
+        if kind == "sprite_alpha":
+            base = frame_u32("photo", width, height, frame, seed)
+            dx = (x & np.uint32(255)).astype(np.int64) - 128
+            dy = (y & np.uint32(255)).astype(np.int64) - 128
+            d2 = (dx * dx + dy * dy).astype(np.uint32)
+            a = np.minimum((np.uint32(14000) - np.minimum(d2, np.uint32(14000))) >> np.uint32(4), np.uint32(255))
+            return np.where(a == 0, np.uint32(0), (base & np.uint32(0x00FFFFFF)) | (a << np.uint32(24))).astype(np.uint32)
+        if kind == "photo_hard":
+            w = _rnd(key, i)
+            w2 = _rnd(key ^ np.uint32(0x3C3C3C3C), i)
+            base_r = (x >> np.uint32(2)) + (y >> np.uint32(3))
+            base_g = (x >> np.uint32(3)) + (y >> np.uint32(2))
+            base_b = (x + y) >> np.uint32(3)
+            lum = w & np.uint32(15)
+            nr = (w >> np.uint32(4)) & np.uint32(7)
+            nb = (w >> np.uint32(8)) & np.uint32(7)
+            kick = (((w >> np.uint32(12)) & np.uint32(15)) == 0).astype(np.uint32)
+            kv = (np.uint32(24) + ((w >> np.uint32(16)) & np.uint32(31))) * kick
+            blk = _rnd(key ^ np.uint32(0x77777777), (y >> np.uint32(2)) * np.uint32(8191) + (x >> np.uint32(5)))
+            smooth = (blk & np.uint32(7)) == 0
+            lum = np.where(smooth, lum & np.uint32(1), lum)
+            nr = np.where(smooth, nr & np.uint32(1), nr)
+            nb = np.where(smooth, nb & np.uint32(1), nb)
+            r = (base_r + lum + nr + kv) & np.uint32(255)
+            g = (base_g + lum) & np.uint32(255)
+            b = (base_b + lum + nb) & np.uint32(255)
+            px = r | (g << np.uint32(8)) | (b << np.uint32(16)) | np.uint32(0xFF000000)
+            # 1 pixel in 64 repeats its left neighbour's (own) value
+            left = np.concatenate([px[:1], px[:-1]])
+            return np.where((w2 & np.uint32(63)) == 0, left, px).astype(np.uint32)
         if kind == "photo":
             # Correlated noise: a pixel reuses its left neighbour's random word (and ramp
             # position) with probability 1/16, which yields true repeats (-> QOI_OP_RUN).
@@ -107,3 +143,19 @@ def frame_rgb(kind: str, width: int, height: int, frame: int = 0,
               seed: int = DEFAULT_SEED) -> np.ndarray:
     """3-channel variant (alpha dropped) for channels==3 tests."""
     return np.ascontiguousarray(frame_rgba(kind, width, height, frame, seed)[..., :3])
+
+
+def stream_hash64(stream) -> int:
+    """The 64-bit content hash ``qoimi_hash_streams`` computes on the device (csrc/qoi_synth.hip: hash_streams), restated in
+    numpy: sum over the 8-byte little-endian words w_j (the last one zero-padded) of splitmix64(w_j + (j+1) * 0x9E3779B97F4A7C15)."""
+    b = np.frombuffer(bytes(stream), dtype=np.uint8)
+    pad = (-len(b)) % 8
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, dtype=np.uint8)])
+    w = b.view("<u8").astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z = w + (np.arange(1, len(w) + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        return int(z.sum(dtype=np.uint64))

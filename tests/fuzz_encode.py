@@ -123,6 +123,9 @@ def main() -> int:
     ap.add_argument("--slabs", default=None, help="replay: override QOIMI_ENC_SET_SLABS")
     ap.add_argument("--keep-going", action="store_true", help="report every mismatch instead of stopping at the first")
     ap.add_argument("--odd-strides", action="store_true", help="device buffers at odd addresses with odd strides; also checks that nothing is written outside a stream / an image")
+    ap.add_argument("--seconds", type=float, default=0.0, help="time budget: stop after the call during which this many seconds have passed (with --iters as the upper bound)")
+    ap.add_argument("--batch8-half", action="store_true", help="half of the calls carry 8 or more images (shapes shrunk to fit): look-back placement with tickets and "
+                    "SPREAD - the path of the benchmark's batches")
     ap.add_argument("--dropin", action="store_true", help="drive the drop-in qoi_encode / qoi_decode on host pointers instead (one image per call, sizes jumping "
                     "up and down: the result buffer of qoi_encode is sized by the thread's previous stream)")
     args = ap.parse_args()
@@ -158,12 +161,19 @@ def main() -> int:
               f"{ref.kind} encoder's, every decode equal to its decoder's; {time.time() - t0:.0f} s" + (f"; {failures} MISMATCHES" if failures else ""))
         return 1 if failures else 0
     forms = {"": 0, "0": 0, "1": 0, "2": 0}
+    calls_done = 0
     for it in range(args.iters):
         w, h = random_shape(rng, args.max_pixels)
         ch = int(rng.choice([3, 4]))
         n = int(rng.choice([1, 1, 1, 2, 3, 7, 8, 9, 12, 40, 150, 300]))      # (the large counts only stay large for small shapes)
         while n > 1 and n * w * h > 2 * args.max_pixels:
             n -= 1
+        if args.batch8_half and rng.random() < 0.5 and n < 8:
+            n = int(rng.choice([8, 9, 12, 16, 33, 64]))
+            while n * w * h > 2 * args.max_pixels and h > 1:
+                h = max(1, h // 2)
+            while n * w * h > 2 * args.max_pixels and w > 1:
+                w = max(1, w // 2)
         form = str(rng.choice(["", "", "", "0", "1", "2"]))           # mostly the library's own choice
         slabs = str(rng.choice(["", "", "1", "2", "3", "5"]))
         for k, v in (("QOIMI_ENC_LOOKBACK", form), ("QOIMI_ENC_SET_SLABS", slabs)):
@@ -259,7 +269,12 @@ def main() -> int:
         px_total += n * w * h
         c.close()
         del b, out
-    print(f"fuzz_encode: {args.iters} calls, {images} images, {px_total / 1e6:.0f} Mpx, seed {args.seed}: every stream byte-identical to the {ref.kind} encoder's, "
+        calls_done = it + 1
+        if args.seconds > 0 and time.time() - t0 > args.seconds:
+            break
+    else:
+        calls_done = args.iters
+    print(f"fuzz_encode: {calls_done} calls, {images} images, {px_total / 1e6:.0f} Mpx, seed {args.seed}: every stream byte-identical to the {ref.kind} encoder's, "
           f"every round trip exact; placement forced order-free / look-back / tree in {forms['0']} / {forms['1']} / {forms['2']} calls, the library's choice in {forms['']}; "
           f"{time.time() - t0:.0f} s" + (f"; {failures} MISMATCHES" if failures else ""))
     return 1 if failures else 0

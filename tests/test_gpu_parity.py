@@ -184,7 +184,7 @@ def test_host_encode_result_outgrows_the_expected_size(api, oracle, worst_case):
 
 
 # ------------------------------------------------------------------ device batch API
-@pytest.mark.parametrize("kind", ["photo", "noise", "uiflat", "constant"])
+@pytest.mark.parametrize("kind", ["photo", "noise", "uiflat", "constant", "photo_hard", "sprite_alpha"])
 def test_4k_frame_device_path(api, ctx, oracle, kind):
     """BASELINE config 2: one 3840x2160 RGBA frame, encode + decode on the GPU, bit-exact."""
     import torch
@@ -975,6 +975,35 @@ def test_encoder_fuzz_short_campaign(api):
                         "--max-pixels", "3000000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "every stream byte-identical" in r.stdout
+
+
+def test_encoder_fuzz_batches_of_eight_and_more(api):
+    """60 seconds of tests/fuzz_encode.py with 8 or more images in half of the calls: look-back placement with per-image tickets and
+    the four wavefronts of a workgroup on consecutive images - the path every benchmark batch takes - against the reference encoder,
+    byte for byte."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_encode.py"), "--iters", "100000", "--seconds", "60", "--seed", "21",
+                        "--batch8-half", "--max-pixels", "2500000"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "every stream byte-identical" in r.stdout
+
+
+def test_stream_hashes_equal_their_numpy_restatement(api, ctx):
+    """qoimi_hash_streams (what bench.py compares whole batches with) against synth.stream_hash64 on streams of odd lengths."""
+    import torch
+    rng = np.random.default_rng(5)
+    n, stride = 9, 5000
+    lens = [0, 1, 7, 8, 9, 22, 4095, 4096, 4999]
+    host = rng.integers(0, 256, size=n * stride, dtype=np.uint8)
+    d = torch.from_numpy(host).cuda()
+    dl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = torch.zeros(n, dtype=torch.int64, device="cuda")
+    ctx.hash_streams(d.data_ptr(), stride, dl.data_ptr(), n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    for i in range(n):
+        assert int(got[i]) == synth.stream_hash64(host[i * stride:i * stride + lens[i]].tobytes()), i
 
 
 def test_decoder_batch_fuzz_short_campaign(api):
