@@ -992,6 +992,7 @@ def test_encoder_fuzz_batches_of_eight_and_more(api):
 def test_stream_hashes_equal_their_numpy_restatement(api, ctx):
     """qoimi_hash_streams (what bench.py compares whole batches with) against synth.stream_hash64 on streams of odd lengths."""
     import torch
+    from qoi_amd import synth
     rng = np.random.default_rng(5)
     n, stride = 9, 5000
     lens = [0, 1, 7, 8, 9, 22, 4095, 4096, 4999]
