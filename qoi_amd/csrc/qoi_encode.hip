@@ -987,8 +987,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         // publishes its own count; the LAST set of a group of 64 adds the counts of its group and publishes the group's total, the
         // last set of 64 groups the total of those; and every set adds, at once, the counts before it in its group, the group totals
         // before its group in its block, and the block totals before its block - three loads per poll, depth three whatever the
-        // image's size (64^3 sets: 800 Mpx at one slab per set).  Sets are taken by workgroup index here (use_ticket = 0): a wait is
-        // for lower-numbered sets only, which the dispatcher has started already (the look-back's spin bound still guards it).
+        // image's size (64^3 sets: 800 Mpx at one slab per set).  A wait is for lower-numbered sets only; units go to the workgroups in
+        // START order (enc_sets: one ticket per workgroup), so those are resident or done (the spin bound still guards it).
         const uint32_t nsets = p.sets_per_image;
         const uint32_t n1 = (nsets + 63u) >> 6, n2 = (n1 + 63u) >> 6;
         u64* const t1 = p.tree1 + (size_t)img * n1;
@@ -1014,7 +1014,13 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 if (slot_id != 0xFFFFFFFFu) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pool_give(p, slot_id, lane); }
                 return;
             }
-            if (++spins > (1u << 22)) { if (lane == 0) atomicOr(p.err, 1u); break; }
+            // A tripped bound (never observed) is published at once and ends every wait of the launch: the waiters look at the flag every
+            // 64th poll and leave WITHOUT copying out (their offsets would be wrong); the host re-encodes such a call order-free.
+            if (++spins > (1u << 22) || ((spins & 63u) == 63u && __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (lane == 0) atomicOr(p.err, 1u);
+                if (slot_id != 0xFFFFFFFFu) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pool_give(p, slot_id, lane); }
+                return;
+            }
             __builtin_amdgcn_s_sleep(2);
         }
         excl = a0 + a1 + a2;
@@ -1043,7 +1049,11 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                         if (slot_id != 0xFFFFFFFFu) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pool_give(p, slot_id, lane); }
                         return;
                     }
-                    if (++spins > (1u << 22)) { if (lane == 0) atomicOr(p.err, 1u); break; }
+                    if (++spins > (1u << 22) || ((spins & 63u) == 63u && __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        if (lane == 0) atomicOr(p.err, 1u);           // (see the tree's wait above)
+                        if (slot_id != 0xFFFFFFFFu) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pool_give(p, slot_id, lane); }
+                        return;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                     continue;
                 }
@@ -1097,19 +1107,31 @@ template <int CH, int PROBE, int ENTRY>
 // (the generic 3-channel form - flat 3-channel images only - takes a register more than six wavefronts per SIMD leave it: five)
 __global__ __launch_bounds__(256, PROBE == 1 ? (CH == 3 && ENTRY == 0 ? QOIMI_ENC_WAVES_PER_SIMD - 1 : QOIMI_ENC_WAVES_PER_SIMD) : 4) void enc_sets(EncParams p) {
     __shared__ EncLdsFor<PROBE> s_lds[4];
+    __shared__ uint32_t s_unit;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
 #pragma unroll 1
-    for (uint32_t unit = blockIdx.x; unit < p.n_units; unit += gridDim.x) {
+    for (uint32_t unit0 = blockIdx.x; unit0 < p.n_units; unit0 += gridDim.x) {
+        uint32_t unit = unit0;
+        if (p.lookback == 2 && p.use_ticket) {
+            // Tree placement waits for LOWER-numbered sets of the same launch.  Units handed out by workgroup index would make that a bet
+            // on in-order dispatch (every XCD dispatches its share on its own: two launches from different streams could wait on each
+            // other in a circle).  One ticket per WORKGROUP (a quarter of the per-wavefront tickets that cost a lone image 60 us,
+            // EXPERIMENTS.md): units in START order - whatever a set waits for is resident or done.  (One pass of this loop: the
+            // launcher gives tree calls one workgroup per unit.)
+            if (threadIdx.x == 0) s_unit = atomicAdd(&p.ticket[0], 1u);
+            __syncthreads();
+            unit = s_unit;
+        }
         // p.spread (look-back + ticket mode; the default): the four wavefronts of a workgroup serve four consecutive IMAGES instead of
         // taking four consecutive tickets of one image at the same instant.  An image's consecutive tickets then go to wavefronts that
         // started at different times (1024 x 4K photographs: 12.45 -> 12.23 ms, profiles/r04_s1_enc_knobs.txt).
         // Every image still receives sets_per_image tickets' worth of wavefronts (4 n_units / n_images of them).
-        const uint32_t img = (p.spread && p.use_ticket && p.lookback) ? (unit * 4u + wave) % p.n_images : unit % p.n_images;
+        const uint32_t img = (p.spread && p.use_ticket && p.lookback == 1) ? (unit * 4u + wave) % p.n_images : unit % p.n_images;
         if (p.only_flagged && p.need_generic[img] == 0u) continue;
         if (ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;   // image already sent to the generic path
         uint32_t set = (unit / p.n_images) * 4u + wave;    // order-free mode: any order will do
-        if (p.use_ticket && p.lookback) {
+        if (p.use_ticket && p.lookback == 1) {
             // look-back mode: the sets of an image are handed out by the image's ticket counter, one ticket per WAVEFRONT, i.e.
             // in START order: every predecessor a look-back can wait on is already running or finished (no reliance on
             // dispatch order; guide G16).  One counter per image keeps the atomics off a single hot word; no workgroup barrier,

@@ -341,7 +341,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         p.set_stride = r * kEncSlabWorst + 16u;
         if (place == 2 && p.sets_per_image > 64u * 64u * 64u) place = 0;            // (three levels of 64; the generic pass has fewer sets)
         p.lookback = (uint8_t)place;
-        if (place == 2) { p.use_ticket = 0; p.spread = 0; }
+        if (place == 2) p.spread = 0;      // (use_ticket: one ticket per WORKGROUP hands out the units in start order, enc_sets; QOIMI_ENC_TICKET=0: by workgroup index)
     }
     const int place = p.lookback;
     const bool lookback = place != 0;
