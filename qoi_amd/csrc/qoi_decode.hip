@@ -1845,7 +1845,15 @@ struct BurstWriter : LaneWriter<OCH, RING_, GROUP_> {
 
 // P4 on records: genuine decode of every active segment + exit-state check (lane = segment), see dec_segments.
 // 16 KiB of colour tables + the 4 KiB pixel ring = 20 KiB: eight wavefronts per CU.
-template <int OCH>
+// FLAT (round 5): the segments of "flat" images (dec_image_is_flat: UI frames, constant frames - their stream is a fraction of a
+// byte per pixel, nearly all of it QOI_OP_RUN) run as a second launch of this kernel that does NOT write their long runs: P4 wrote a
+// run lane by lane in 16-byte pieces, 64 lanes 0.3-30 KB apart (34 GB in 19 ms on 1024 UI frames, a third of what the memory system
+// gives coalesced writes).  Consecutive records that leave the pixel as it is - QOI_OP_RUN after QOI_OP_RUN: a run is cut every 62
+// pixels, qoi.h:417 - are merged into ONE run; its head (up to a 4-pixel boundary) and tail go through the ring as before, the
+// aligned middle becomes an 8-byte run descriptor (start pixel, length) in the segment's descriptor region, and dec_expand_runs
+// writes all descriptors of the launch afterwards with whole wavefronts, 1 KiB per store instruction.  The run's pixel is the one
+// in front of `start` (written by this kernel through the ring: a run's first pixel always is).
+template <int OCH, bool FLAT>
 __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
 #ifndef QOIMI_SEGREC_GROUP
 #define QOIMI_SEGREC_GROUP 16
@@ -1866,10 +1874,13 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
-    have = have && j >= im.start_seg && j < im.n_active;
+    have = have && j >= im.start_seg && j < im.n_active && (im.desc_base != kNoRunDesc) == FLAT;
     if (!lanes_where(have)) return;
     const uint32_t limit = im.npx;
     const uint32_t px_first = have ? p.px_off[q] : 0u;
+    // FLAT: the lane's run descriptors (8 bytes each: start pixel, pixels) and the run in the making
+    uint2* const my_desc = FLAT ? p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap : nullptr;
+    uint32_t n_desc = 0u, run_start = 0u, run_len = 0u;       // run_len != 0: a run is pending - W.ppos is behind it, the ring is empty
     RecSource S; S.init(p, blockIdx.x, lane, have && px_first < limit ? p.rec_gran[q] : 0u);
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);
 #ifndef QOIMI_P4_DEPTH
@@ -1903,6 +1914,17 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     constexpr uint32_t kLongRun = 12;
     // only a wavefront that holds a segment which may reach the image's pixel limit pays for the clipping (see dec_segments)
     const bool clip_lane = have && (j + 1u >= im.n_active || p.px_off[q + 1u] >= limit);
+    // ends the lane's pending run: the 4-pixel aligned part [run_start, run_start + aligned) becomes a descriptor, the rest goes
+    // through the ring (W.ppos already stands behind the whole run; px still is the run's pixel)
+    auto flush_run = [&]() {
+        const uint32_t aligned = run_len & ~3u, tail = run_len & 3u;
+        const uint32_t end = W.ppos;
+        if (aligned != 0u && n_desc < p.desc_cap) { my_desc[n_desc] = make_uint2(run_start, aligned); ++n_desc; W.ppos = W.fpos = run_start + aligned; }
+        else { W.ppos = W.fpos = run_start; uint32_t n = run_len - tail; if (n) W.splat(px, n); }     // (no room: never - at most every second record ends a run)
+        for (uint32_t k = 0; k < tail; ++k) W.put(px);
+        W.ppos = end; run_len = 0u;
+        (void)end;
+    };
     auto run = [&](auto clip_tag) {
         constexpr bool CLIP = decltype(clip_tag)::value;
         // (no early exit from the unrolled blocks and the ring slot refilled at the END of its block: see dec_summarize_rec)
@@ -1923,7 +1945,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
             // RGBA-dense content (see the same test in dec_summarize_rec): the pair names r,g,b and perhaps alpha absolutely
             // (qoi.h:547-557), one short step per pair instead of two passes through the rare body.  Looked for only where the
             // block's first record is such a chunk in some lane, so photographs never pay for the question.
-            if (__builtin_expect(hm[0] != 0ull, 0) &&
+            if (!FLAT && __builtin_expect(hm[0] != 0ull, 0) &&
                 lanes_where(!(pair_head(rc[0]) && pair_tail(rc[1]) && pair_head(rc[2]) && pair_tail(rc[3]) &&
                               pair_head(rc[4]) && pair_tail(rc[5]) && pair_head(rc[6]) && pair_tail(rc[7]))) == 0) {
 #pragma unroll
@@ -1945,6 +1967,22 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                 if (kDrainEvery < 8u && u == 4u) W.drain_block();
                 const uint32_t rec = rc[u];
                 uint32_t rem = (rec >> 24) & 63u;                                 // 0: null record
+                if (FLAT) {
+                    // a pending run: a record that leaves the pixel as it is (QOI_OP_RUN, a null record) adds its pixels to it and is
+                    // through - its table store would put the pixel where it already stands (qoi_decode_core.h: the null record) -
+                    // any other record ends it: descriptor out, tail (< 4 pixels) into the ring, then the record as usual
+                    const bool pending = run_len != 0u;
+                    if (lanes_where(pending) != 0ull) {
+                        const bool pure = (rec & 0xC0FFFFFFu) == 0u;
+                        if (lanes_where(pending && !pure) != 0ull) { if (pending && !pure) flush_run(); }
+                        if (pending && pure) {
+                            uint32_t add = rem;
+                            if (CLIP) add = min(add, limit - W.ppos);     // over-long run clipped (Appendix B item 8)
+                            run_len += add; W.ppos += add; W.fpos = W.ppos;
+                            rem = 0u;
+                        }
+                    }
+                }
                 // two complete bodies (see dec_summarize_rec: a step costs its instruction count): the common one knows nothing of
                 // QOI_OP_RGB / QOI_OP_RGBA
                 if (__builtin_expect(hm[u] != 0ull, 0)) {                        // QOI_OP_RGB keeps the alpha; QOI_OP_RGBA = stash record + alpha record (qoi.h:548-557)
@@ -1987,7 +2025,16 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                 if (__builtin_expect(lm[u] != 0ull, 0)) {                  // QOI_OP_RUN of three or more (qoi.h:573-575) in some lane
                     rem -= n2;
                     if (rem) {
-                        if (rem >= kLongRun) W.splat(px, rem);
+                        if (FLAT) {
+                            if (rem >= kLongRun) {
+                                // the run leaves the ring here: up to a 4-pixel boundary through it, the ring out, the rest pending
+                                while ((W.ppos & 3u) != 0u && rem) { W.put(px); --rem; }
+                                W.finish();
+                                run_start = W.ppos; run_len = rem;
+                                W.ppos += rem; W.fpos = W.ppos;
+                                rem = 0u;
+                            }
+                        } else if (rem >= kLongRun) W.splat(px, rem);
                         while (rem) { W.put(px); --rem; }
                         if (W.ppos - W.fpos > Writer::kRing - 2u * kDrainEvery) W.drain();
                     }
@@ -2004,6 +2051,10 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
         }
     };
     if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
+    if (FLAT) {
+        if (run_len != 0u) flush_run();
+        if (have) p.run_cnt[q] = n_desc;
+    }
     if (have) {
         W.finish();
         if (j + 1u < im.n_active) {
@@ -2025,6 +2076,53 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
             }
         } else {
             p.images[img].final_px = px;     // pixel repeated when the stream ends early (qoi.h:544)
+        }
+    }
+}
+
+// The run descriptors of a round (dec_segments_rec<OCH, true>), written out: one wavefront per 64 segments (the geometry of the
+// kernel that made them) takes its segments one after the other, 64 descriptors at a time - lane i fetches descriptor i and the
+// pixel in front of its run - and writes every run with all 64 lanes, 16 bytes (OCH 3: 12 bytes, four pixels) per lane and store
+// instruction: whole KiB-sized pieces of one image row after the other instead of 64 lanes 16 bytes each at 64 places.
+template <int OCH>
+__global__ __launch_bounds__(256) void dec_expand_runs(DecParams p) {
+    const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t q = (blockIdx.x * 4u + wave) * 64u + lane;
+    bool have = q < p.total_segs;
+    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
+    const DecImage im = p.images[img];
+    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
+    have = have && j >= im.start_seg && j < im.n_active && im.desc_base != kNoRunDesc;
+    const uint32_t cnt = have ? p.run_cnt[q] : 0u;
+    u64 todo = lanes_where(cnt != 0u);
+    const u64 dbase = (u64)(uintptr_t)(p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap);
+    const u64 obase = (u64)(uintptr_t)(p.pixels + (size_t)img * p.pixel_stride);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t n = read_lane_dyn(cnt, (uint32_t)l);
+        const uint2* __restrict__ dsc = reinterpret_cast<const uint2*>((uintptr_t)((u64)read_lane_dyn((uint32_t)dbase, (uint32_t)l) | ((u64)read_lane_dyn((uint32_t)(dbase >> 32), (uint32_t)l) << 32)));
+        uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>((uintptr_t)((u64)read_lane_dyn((uint32_t)obase, (uint32_t)l) | ((u64)read_lane_dyn((uint32_t)(obase >> 32), (uint32_t)l) << 32)));
+        for (uint32_t d0 = 0; d0 < n; d0 += 64u) {
+            const bool mine = d0 + lane < n;
+            const uint2 dd = mine ? dsc[d0 + lane] : make_uint2(1u, 0u);
+            uint32_t v;                                              // the run's pixel: the one in front of it
+            if (OCH == 4) v = mine ? reinterpret_cast<const uint32_t*>(out)[dd.x - 1u] : 0u;
+            else { const uint8_t* s3 = out + (size_t)(dd.x - 1u) * 3u; v = mine ? ((uint32_t)s3[0] | ((uint32_t)s3[1] << 8) | ((uint32_t)s3[2] << 16)) : 0u; }
+            const uint32_t m = min(n - d0, 64u);
+            for (uint32_t i = 0; i < m; ++i) {
+                const uint32_t start = read_lane_dyn(dd.x, i), len = read_lane_dyn(dd.y, i), px = read_lane_dyn(v, i);
+                if (OCH == 4) {
+                    uint4* __restrict__ o = reinterpret_cast<uint4*>(out + (size_t)start * 4u);          // start is a multiple of 4 pixels: 16-byte aligned
+                    const uint4 w4 = make_uint4(px, px, px, px);
+                    for (uint32_t k = lane; k < (len >> 2); k += 64u) o[k] = w4;
+                } else {
+                    uint32_t* __restrict__ o = reinterpret_cast<uint32_t*>(out + (size_t)start * 3u);      // 12-byte groups of four pixels
+                    const uint32_t a = px & 0xFFFFFFu;
+                    const uint32_t w0 = a | (a << 24), w1 = (a >> 8) | (a << 16), w2 = (a >> 16) | (a << 8);
+                    for (uint32_t k = lane; k < (len >> 2); k += 64u) { o[3u * k] = w0; o[3u * k + 1u] = w1; o[3u * k + 2u] = w2; }
+                }
+            }
         }
     }
 }
@@ -2182,9 +2280,18 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
             chain_state();
         }
     }
-    if (out_channels == 4) hipLaunchKernelGGL(dec_segments_rec<4>, dim3(b64), dim3(64), 0, st, p);
-    else hipLaunchKernelGGL(dec_segments_rec<3>, dim3(b64), dim3(64), 0, st, p);
+    if (out_channels == 4) hipLaunchKernelGGL((dec_segments_rec<4, false>), dim3(b64), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL((dec_segments_rec<3, false>), dim3(b64), dim3(64), 0, st, p);
+    if (p.flat_segs) {                   // the call holds flat images: their segments (run descriptors instead of lane-written runs), then the runs
+        if (out_channels == 4) hipLaunchKernelGGL((dec_segments_rec<4, true>), dim3(b64), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((dec_segments_rec<3, true>), dim3(b64), dim3(64), 0, st, p);
+    }
     tm->mark(kT_dec_segments, st);
+    if (p.flat_segs) {
+        if (out_channels == 4) hipLaunchKernelGGL(dec_expand_runs<4>, dim3((b64 + 3u) / 4u), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(dec_expand_runs<3>, dim3((b64 + 3u) / 4u), dim3(256), 0, st, p);
+        tm->mark(kT_dec_expand, st);
+    }
     // (the restart of the images whose check failed is prepared by dec_fill, which every round ends with)
 }
 

@@ -1016,7 +1016,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
             }
             // A tripped bound (never observed) is published at once and ends every wait of the launch: the waiters look at the flag every
             // 64th poll and leave WITHOUT copying out (their offsets would be wrong); the host re-encodes such a call order-free.
-            if (++spins > (1u << 22) || ((spins & 63u) == 63u && __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            if (++spins > p.spin_bound || ((spins & 63u) == 63u && __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                 if (lane == 0) atomicOr(p.err, 1u);
                 if (slot_id != 0xFFFFFFFFu) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pool_give(p, slot_id, lane); }
                 return;
@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                         if (slot_id != 0xFFFFFFFFu) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pool_give(p, slot_id, lane); }
                         return;
                     }
-                    if (++spins > (1u << 22) || ((spins & 63u) == 63u && __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    if (++spins > p.spin_bound || ((spins & 63u) == 63u && __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                         if (lane == 0) atomicOr(p.err, 1u);           // (see the tree's wait above)
                         if (slot_id != 0xFFFFFFFFu) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pool_give(p, slot_id, lane); }
                         return;

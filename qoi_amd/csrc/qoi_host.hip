@@ -101,6 +101,12 @@ struct qoimi_ctx {
     bool recheck_failed_unreported = false;   // a repeat failed: the next qoimi_encode_status reports it (once)
     bool test_force_recheck_fail = false;     // env QOIMI_TEST_FORCE_RECHECK_FAIL (tests): every repeat counts as failed
     int enc_ticket = 1, enc_set_slabs = 0, enc_warm = 1;   // tuning / test knobs (env QOIMI_ENC_*)
+    int enc_tree_ticket = 0;            // env QOIMI_ENC_TREE_TICKET=1: tree placement hands its units out by one ticket per workgroup (start order) instead of by workgroup index
+    uint32_t test_spin_bound = 0;       // env QOIMI_TEST_SPIN_BOUND (tests): polls before a placement wait gives up
+    bool worst_case_buffer = false;     // env QOIMI_ENCODE_WORST_CASE_BUFFER=1 (read once, at creation): qoi_encode returns the reference's worst-case allocation
+    int enc_adapt = 1;                  // env QOIMI_ENC_ADAPT=0: the set size ignores what the previous call's streams looked like
+    uint32_t enc_hint_npx = 0;          // pixels per image of the batch call whose first stream length stands in host_word[12] (0: none)
+    struct { const void* px; size_t ps; qoi_desc desc; int n; void* out; size_t os; int* len; void* st; bool valid = false; } last_enc;   // the last qoimi_encode_batch (qoimi_encode_status re-encodes it order-free if a wait gave up)
     int enc_spread = 1;                 // env QOIMI_ENC_SPREAD: the wavefronts of a workgroup take their tickets from consecutive images (0: all four from one image)
     int enc_persist = 0;                // env QOIMI_ENC_PERSIST: workgroups of the first encode pass (0: one per unit)
     int enc_lookback = -1;              // 1: sets place their bytes themselves (decoupled look-back); 2: the same by the tree of byte counts; 0: order-free (scratch slots + enc_offsets + enc_compact); -1: by the call's shape
@@ -109,8 +115,11 @@ struct qoimi_ctx {
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
     int dec_p3_plain = 1, dec_inner = 4, dec_inner1 = 3;   // env QOIMI_P3_PLAIN, QOIMI_DEC_INNER, QOIMI_DEC_INNER1 (read once, at creation)
     int dec_l2_wgs = 1;          // dec_chain_state_l2m: 0 never, 1 for calls of up to four images of 128 groups or more, 2 for every call of up to four images (env QOIMI_DEC_L2M, tests)
+    int dec_flat_seg = 1;        // 0: calls of flat images take the segment size of the general cost model (env QOIMI_DEC_FLAT_SEG, A/B)
+    int dec_run_desc = 1;        // 0: flat images write their long runs lane by lane as every image does (env QOIMI_DEC_RUN_DESC, A/B and tests)
     int dec_max_rounds = kMaxSpecRounds;   // speculation rounds before the sequential last resort (env QOIMI_DEC_MAX_ROUNDS, tests)
     size_t last_drop_len = 0;           // length of the last stream the drop-in qoi_encode returned on this context (page populate-ahead)
+    long long enc_retries = 0;          // calls qoimi_encode_status encoded again order-free after a placement wait gave up
     long long dec_seq_images = 0;       // images finished by dec_sequential since the context was created
     size_t dec_rec_cap = (size_t)16 << 30;   // largest record arena: a call whose streams need more is decoded in sub-batches (set from the device's memory at creation)
     KernelTimer timer;                  // optional per-kernel HIP-event timing
@@ -167,6 +176,11 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_WARM")) c->enc_warm = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
     if (const char* e = getenv("QOIMI_ENC_SPREAD")) c->enc_spread = atoi(e) != 0;
+    if (const char* e = getenv("QOIMI_ENC_TREE_TICKET")) c->enc_tree_ticket = atoi(e) != 0;
+    if (const char* e = getenv("QOIMI_ENC_ADAPT")) c->enc_adapt = atoi(e) != 0;
+    if (const char* e = getenv("QOIMI_TEST_SPIN_BOUND")) { const long v = atol(e); if (v >= 1) c->test_spin_bound = (uint32_t)v; }
+    if (const char* e = getenv("QOIMI_ENCODE_WORST_CASE_BUFFER")) c->worst_case_buffer = atoi(e) != 0;
+    c->host_word[12] = 0u;
     if (const char* e = getenv("QOIMI_ENC_PERSIST")) { const int v = atoi(e); if (v >= 0) c->enc_persist = v; }
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
@@ -174,6 +188,8 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_DEC_INNER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner = v; }
     if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
     if (const char* e = getenv("QOIMI_DEC_L2M")) c->dec_l2_wgs = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_RUN_DESC")) c->dec_run_desc = atoi(e);
+    if (const char* e = getenv("QOIMI_DEC_FLAT_SEG")) c->dec_flat_seg = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
     if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
     if (const char* e = getenv("QOIMI_SEG_BYTES")) {
@@ -241,7 +257,7 @@ extern "C" int qoimi_get_profile(qoimi_ctx* c, void* stream, double* ms, long lo
 extern "C" const char* qoimi_kernel_name(int i) {
     static const char* names[kT_count] = {"", "enc_slab_summary", "enc_scan_groups", "enc_scan_images", "enc_slabs", "enc_slabs_generic", "enc_offsets", "enc_compact",
         "dec_parse", "dec_chain_parse", "dec_transcode", "dec_chain_slots", "dec_summarize", "dec_chain_state",
-        "dec_segments", "dec_prepare_restart", "dec_fill", "encode_total", "decode_total"};
+        "dec_segments", "dec_prepare_restart", "dec_fill", "dec_expand_runs", "encode_total", "decode_total"};
     return (i >= 0 && i < kT_count) ? names[i] : "";
 }
 
@@ -333,6 +349,14 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
             const uint32_t rt = total_slabs < 1500u ? 1u : (total_slabs < 6000u ? 2u : 3u);       // measured above
             if ((p.spi + rt - 1u) / rt > kEncTreeMaxSets) place = 0; else r = rt;
         }
+        // Look-back batches: three slabs per set is the size for ~1.2 bytes per pixel - above ~1.4 a set outgrows its 6.3 KB staging
+        // buffer and sends what it has through a scratch slot (a second trip through memory for those bytes).  Two slabs stay staged
+        // up to 3 bytes per pixel (photo_hard, 2.1 B/px, 128 frames: 3.00 ms at three slabs, 2.77 at two, 3.86 at one;
+        // photographs of 1.2 B/px lose 10 % at two).  What the content looks like is taken from the previous batch call of the context:
+        // the length of its first stream, copied to a pinned word behind that call (read here without a wait: a stale or missing
+        // value only picks the other set size, the streams are the same bytes either way).
+        if (c->enc_adapt && place == 1 && r == 3u && c->enc_hint_npx != 0u && c->host_word[12] != 0u &&
+            (double)c->host_word[12] > 1.4 * (double)c->enc_hint_npx) r = 2u;
         if (c->enc_set_slabs > 0) r = (uint32_t)c->enc_set_slabs;
         if (r > kEncMaxSetSlabs) r = kEncMaxSetSlabs;
         p.set_slabs = r;
@@ -341,10 +365,18 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         p.set_stride = r * kEncSlabWorst + 16u;
         if (place == 2 && p.sets_per_image > 64u * 64u * 64u) place = 0;            // (three levels of 64; the generic pass has fewer sets)
         p.lookback = (uint8_t)place;
-        if (place == 2) p.spread = 0;      // (use_ticket: one ticket per WORKGROUP hands out the units in start order, enc_sets; QOIMI_ENC_TICKET=0: by workgroup index)
+        // Tree: units by workgroup index (a wait is for lower-numbered sets, which the dispatcher started earlier - true of one launch
+        // on an idle device; two launches from different streams could in principle hold each other's predecessors out: the waits are
+        // bounded - 2^15 polls, tens of milliseconds, where a set's predecessors finish within microseconds - a tripped bound ends every
+        // wait of the launch and the call is encoded again order-free by qoi_encode / qoimi_encode_status).  QOIMI_ENC_TREE_TICKET=1:
+        // one ticket per workgroup hands the units out in START order instead - no assumption at all, 4 us more per 4K frame
+        // (46.8 against 42.6 us, 720p 23.8 against 21.5: profiles/r05_s1_single_ticket.txt).
+        if (place == 2) { p.spread = 0; p.use_ticket = c->enc_tree_ticket ? 1 : 0; }
     }
     const int place = p.lookback;
     const bool lookback = place != 0;
+    p.spin_bound = (place == 2 && !p.use_ticket) ? (1u << 15) : (1u << 22);
+    if (c->test_spin_bound) p.spin_bound = c->test_spin_bound;            // tests: make a wait give up
     const size_t T = (size_t)p.n_images * p.spi, G = (size_t)p.n_images * p.gpi, S = (size_t)p.n_images * p.sets_per_image;
     if (T > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (slab index overflows 32 bits)");
     // Scratch.  Order-free: every set parks its bytes in a slot of its own until the placement passes run (few large images:
@@ -391,6 +423,11 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     c->timer.mark(kT_begin, st);
     launch_encode(p, st, &c->timer);
     c->timer.mark(kT_enc_total, st);
+    if (c->enc_adapt && place == 1) {                       // what this batch's streams look like, for the next call's set size (see above)
+        if (hipMemcpyAsync(&c->host_word[12], d_stream_len, sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess) c->enc_hint_npx = p.npx;
+    }
+    c->last_enc.px = d_pixels; c->last_enc.ps = pixel_stride; c->last_enc.desc = *desc; c->last_enc.n = n_images;
+    c->last_enc.out = d_streams; c->last_enc.os = stream_stride; c->last_enc.len = d_stream_len; c->last_enc.st = stream; c->last_enc.valid = true;
     if (const char* dump = c->enc_debug_dump.empty() ? nullptr : c->enc_debug_dump.c_str()) {          // diagnostics: the entry-state arrays of this call, raw
         (void)hipStreamSynchronize(st);
         if (FILE* fo = fopen(dump, "wb")) {
@@ -421,6 +458,20 @@ extern "C" int qoimi_encode_status(qoimi_ctx* c, void* stream) {
     if (!c->last_enc_err) return QOIMI_OK;
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, c->last_enc_err, sizeof err, hipMemcpyDeviceToHost));
+    if (err && c->last_enc.valid && c->enc_lookback != 0) {
+        // A placement wait gave up (never observed: the sets a wait is for are resident or done unless another stream's launch holds
+        // them out) or the scratch pool ran dry: the call is encoded again ORDER-FREE - no set waits for another, every set has a
+        // scratch slot of its own - from the caller's buffers, which it has not read yet (it is asking for the status first).
+        const int forced = c->enc_lookback;
+        c->enc_lookback = 0;
+        c->last_enc.valid = false;
+        const int rc = qoimi_encode_batch(c, c->last_enc.px, c->last_enc.ps, &c->last_enc.desc, c->last_enc.n, c->last_enc.out, c->last_enc.os, c->last_enc.len, c->last_enc.st);
+        c->enc_lookback = forced;
+        if (rc != QOIMI_OK) return rc;
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipMemcpy(&err, c->last_enc_err, sizeof err, hipMemcpyDeviceToHost));
+        c->enc_retries += 1;
+    }
     if (err) return fail(QOIMI_E_INTERNAL, (err & 2u) ? "encode scratch pool exhausted" : "encode look-back exceeded its spin bound");
     return QOIMI_OK;
 }
@@ -429,8 +480,22 @@ extern "C" int qoimi_encode_status(qoimi_ctx* c, void* stream) {
 // decode
 // ------------------------------------------------------------------------------------
 // segment size of a decode call (see the cost model below)
-static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, int n_images) {
+static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi_desc* descs, int n_images) {
     uint32_t B = c->seg_bytes;
+    if (B == 0 && c->dec_run_desc && c->dec_flat_seg) {
+        // A call of FLAT images only (run descriptors): a lane's walk over its segment no longer writes the segment's pixels, it costs
+        // its chunks alone - larger segments mean fewer entry states (780 bytes per segment whatever its size), fewer chances to miss
+        // (a round per miss) and the same work.  The largest size that still gives every CU three wavefronts of lanes.
+        bool all_flat = true;
+        uint64_t bytes = 0;
+        for (int i = 0; i < n_images && all_flat; ++i) {
+            all_flat = sizes[i] > 22 && descs[i].width != 0 && dec_image_is_flat((uint32_t)sizes[i] - 8u, (uint32_t)((uint64_t)descs[i].width * descs[i].height));
+            bytes += (uint64_t)(sizes[i] > 0 ? sizes[i] : 0);
+        }
+        if (all_flat)
+            for (uint32_t cand = 4096u; cand >= 256u; cand >>= 1)
+                if (bytes / cand >= 49152u) { B = cand; break; }
+    }
     if (B == 0) {
         // One lane decodes one segment.  Two costs pull in opposite directions (constants measured on MI355X):
         //   * a lane walks its segment serially, ~0.6 us per chunk-step over the four passes, and the two
@@ -464,7 +529,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
                        void* d_pixels, size_t pixel_stride, void* stream, uint32_t B, bool lone_image, long long stats[4]) {
     int och = 0;
     std::vector<DecImage> imgs((size_t)n_images);
-    uint64_t total = 0, total_g = 0;
+    uint64_t total = 0, total_g = 0, flat_total = 0;
     for (int i = 0; i < n_images; ++i) {
         if (sizes[i] < kHeaderBytes + kTrailerBytes) return fail(QOIMI_E_ARG, "stream shorter than 22 bytes (qoi.h:500)");
         if (!desc_ok(&descs[i])) return fail(QOIMI_E_ARG, "descriptor rejected (qoi.h:513-521 rules)");
@@ -483,6 +548,8 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         im.nseg = (im.chunks_end - kHeaderBytes + B - 1u) / B;
         im.grp_base = (uint32_t)total_g;
         im.ngrp = (im.nseg + 63u) / 64u;
+        im.desc_base = kNoRunDesc;
+        if (c->dec_run_desc && im.nseg != 0u && dec_image_is_flat(im.chunks_end, im.npx)) { im.desc_base = (uint32_t)flat_total; flat_total += im.nseg; }
         total += im.nseg;
         total_g += im.ngrp;
     }
@@ -495,6 +562,8 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
     p.rec_rows = rec_region_dwords(B) / 4u;
+    p.flat_segs = (uint32_t)flat_total;
+    p.desc_cap = rec_region_dwords(B) / 2u + 2u;            // a run ends with the record behind it: every second record at most
     p.sync_all = 0;
     p.p3_plain = (uint32_t)c->dec_p3_plain;
     p.refine_inner = (uint32_t)c->dec_inner;
@@ -534,6 +603,8 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.grp_summary = w.take<u64>(NG * 65); p.grp_entry = w.take<uint32_t>(NG * 65);
         p.l2_sum = w.take<u64>((size_t)n_images * p.l2_wgs * 65);
         p.rec_gran = w.take<uint32_t>(Q);
+        p.run_cnt = w.take<uint32_t>(flat_total ? Q : 0);
+        p.run_desc = w.take<uint2>((size_t)flat_total * p.desc_cap);
         p.sync_fail = w.take<uint8_t>(Q);
         p.recs = w.take<uint32_t>(((Q + 63u) / 64u) * p.rec_rows * 256u);
         if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }
@@ -608,7 +679,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     if (channels != 0 && channels != 3 && channels != 4) return fail(QOIMI_E_ARG, "channels must be 0, 3 or 4 (qoi.h:499)");
     for (int i = 1; i < n_images && channels == 0; ++i)
         if (descs[i].channels != descs[0].channels) return fail(QOIMI_E_ARG, "all images of a batch must share the output channel count");
-    const uint32_t B = choose_seg_bytes(c, sizes, n_images);
+    const uint32_t B = choose_seg_bytes(c, sizes, descs, n_images);
     // The chunk records take four bytes per stream byte (worst case) while a call is in flight.  Calls whose streams would
     // need more than dec_rec_cap are decoded as consecutive sub-batches of whole images through the same workspace.
     const uint64_t cap_stream = (uint64_t)(c->dec_rec_cap / 4u) - (uint64_t)(c->dec_rec_cap / 4u) / 64u;
@@ -791,8 +862,7 @@ extern "C" void* qoi_encode(const void* data, const qoi_desc* desc, int* out_len
     // call would map, populate and (in the caller's free) unmap it: 1.1 ms of a 2.0 ms call in qoibench's encode-free loop.  A buffer
     // of the expected size comes back from the allocator's heap with its pages in place.
     // QOIMI_ENCODE_WORST_CASE_BUFFER=1 restores the reference's allocation for callers that count on its capacity.
-    const char* const wc_env = getenv("QOIMI_ENCODE_WORST_CASE_BUFFER");
-    const bool worst_case = wc_env && atoi(wc_env) != 0;
+    const bool worst_case = c->worst_case_buffer;
     const size_t guess = worst_case ? bound : (c->last_drop_len ? c->last_drop_len + c->last_drop_len / 8u : bound / 3u);
     size_t ahead = guess < bound ? guess : bound;
     if (ahead < (size_t)kHeaderBytes + kTrailerBytes) ahead = (size_t)kHeaderBytes + kTrailerBytes;

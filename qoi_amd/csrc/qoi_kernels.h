@@ -15,7 +15,7 @@ constexpr int kHeaderBytes = 14, kTrailerBytes = 8;   // qoi.h:326, qoi.h:339
 enum KernelTag { kT_begin = 0,
                  kT_enc_summary, kT_enc_scan_groups, kT_enc_scan_images, kT_enc_slabs, kT_enc_slabs_generic, kT_enc_offsets, kT_enc_compact,
                  kT_dec_parse, kT_dec_chain_parse, kT_dec_slot_walk, kT_dec_chain_slots, kT_dec_summarize,
-                 kT_dec_chain_state, kT_dec_segments, kT_dec_restart, kT_dec_fill,
+                 kT_dec_chain_state, kT_dec_segments, kT_dec_restart, kT_dec_fill, kT_dec_expand,
                  kT_enc_total, kT_dec_total,    // a whole qoimi_encode_batch / qoimi_decode_batch on the caller's stream (kernels of a call may overlap)
                  kT_count };
 struct KernelTimer {
@@ -60,6 +60,7 @@ struct EncParams {
     uint8_t only_flagged;    // set by the launcher: this pass handles images with need_generic[img] != 0 only
     uint32_t n_units;        // set by the launcher: (image, four consecutive sets) work units
     uint32_t spread;         // 1 (default): the wavefronts of a workgroup serve consecutive images (env QOIMI_ENC_SPREAD=0: all four take tickets of one image)
+    uint32_t spin_bound;     // polls a placement wait makes before it gives up (err bit 0): 2^22 with tickets (start order), 2^15 for the tree by workgroup index
     uint32_t persist;        // 0: one workgroup per unit; else the first pass runs at most this many workgroups (env QOIMI_ENC_PERSIST, a test knob)
     // workspace
     uint32_t* sum_tab;   u64* sum_valid;  int* sum_le;     // E1 out        [n_images*spi]
@@ -111,7 +112,9 @@ struct DecImage {
     uint32_t n_active;     // segments that start before the pixel limit            (S1)
     uint32_t start_seg;    // first segment still to be (re)decoded; n_active: done
     uint32_t final_px;     // exit pixel of the last active segment                 (P4)
+    uint32_t desc_base;    // flat images (run descriptors): index of the image's first segment among the flat images' segments; kNoRunDesc: none
 };
+constexpr uint32_t kNoRunDesc = 0xFFFFFFFFu;
 
 // "Flat" images - a stream of less than a byte per eight pixels (UI frames, constant frames): a pass over their chunks costs a
 // fraction of a pass over their pixels, so the first round spends a few refinement passes of P3 + S3 on them before its P4.
@@ -146,6 +149,11 @@ struct DecParams {
     uint8_t*  grp_alpha_in;    // S2 l2
     u64*      grp_summary;     // S3 l1 [G][65]
     uint32_t* grp_entry;       // S3 l2 [G][65]
+    // run descriptors of the flat images (dec_segments_rec<OCH, true> -> dec_expand_runs)
+    uint2*    run_desc;        // [flat_segs][desc_cap] (start pixel, pixels) of the long runs of a segment, in stream order
+    uint32_t* run_cnt;         // [total_segs + 1] descriptors the segment wrote this round
+    uint32_t  desc_cap;        // descriptors a segment can hold: every second record at most ends a run
+    uint32_t  flat_segs;       // segments of flat images in this call (0: no run descriptors, one launch of dec_segments_rec)
     uint32_t* first_bad;       // [n_images] min failing segment, 0xFFFFFFFF: none
     uint32_t* pending;         // [1] images that need another round
     uint32_t* redo_segs;       // [1] statistics

@@ -284,3 +284,57 @@ def pair_streams():
         w = 97
         h = (npx + w - 1) // w + 1
         yield (f"pairs_seed{seed}", b"qoif" + struct.pack(">II", w, h) + bytes([4, 0]) + bytes(body) + bytes([0, 0, 0, 0, 0, 0, 0, 1]), w, h)
+
+
+def flat_run_streams():
+    """Streams of FLAT images (less than a byte per eight pixels: what the decoder gives run descriptors, dec_segments_rec<OCH, true>
+    + dec_expand_runs): long runs cut every 62 pixels (qoi.h:417) that begin at every alignment, end in every tail length, follow
+    each other with one literal chunk between them or none, open the image, run over its end (clipped, Appendix B item 8) or stop
+    short of it (the last pixel repeats, qoi.h:544); alpha levels that change through QOI_OP_RGBA and come back through QOI_OP_INDEX.
+    Yields (name, stream, width, height)."""
+    import struct
+    for seed, n_items, variant in ((1, 300, "exact"), (2, 300, "clipped"), (3, 300, "short"), (4, 3000, "exact"), (5, 3000, "clipped"),
+                                   (6, 40, "exact"), (7, 20000, "exact"), (8, 3000, "short")):
+        rng = np.random.default_rng(1000 + seed)
+        body = bytearray()
+        npx = 0
+        if seed % 2 == 0:                                           # the image opens with a run of the start value (qoi.h:396-399)
+            body += bytes([0xFD] * int(rng.integers(1, 6))) + bytes([0xC0 | int(rng.integers(0, 62))])
+        pal = rng.integers(0, 256, size=(12, 4))
+        pal[:, 3] = rng.choice([255, 255, 128, 0], size=12)
+        for it in range(n_items):
+            k = rng.random()
+            c = pal[int(rng.integers(0, 12))]
+            if k < 0.35:
+                body += bytes([0xFF, c[0], c[1], c[2], c[3]])       # QOI_OP_RGBA (alpha level)
+            elif k < 0.55:
+                body += bytes([0xFE, c[0], c[1], c[2]])             # QOI_OP_RGB
+            elif k < 0.75:
+                body.append(int(rng.integers(0, 64)))               # QOI_OP_INDEX (often a colour seen before)
+            elif k < 0.85:
+                body.append(0x40 | int(rng.integers(0, 64)))        # QOI_OP_DIFF
+            elif k < 0.9:
+                body += bytes([0x80 | int(rng.integers(0, 64)), int(rng.integers(0, 256))])   # QOI_OP_LUMA
+            # else: no chunk - the next run follows the previous one directly
+            # a run of 1 .. ~2500 pixels: full QOI_OP_RUN chunks of 62 and a rest
+            total = int(rng.choice([1, 2, 3, 5, 11, 12, 13, 14, 15, 16, 61, 62, 63, 64, 100, 124, 125, 300, 1000, 2500])) + int(rng.integers(0, 4))
+            full, rest = divmod(total, 62)
+            body += bytes([0xFD] * full)
+            if rest:
+                body.append(0xC0 | (rest - 1))
+        # pixels the chunks produce
+        i = 0
+        while i < len(body):
+            b = body[i]
+            i += 4 if b == 0xFE else 5 if b == 0xFF else 2 if (b >> 6) == 2 else 1
+            npx += (b & 0x3F) + 1 if (b >> 6) == 3 and b < 0xFE else 1
+        w = 251 if seed != 6 else 17
+        if variant == "exact":
+            h = max(1, npx // w)                                    # (the last partial row of chunks is cut off: clipped as well)
+        elif variant == "clipped":
+            h = max(1, (npx - int(rng.integers(1, 2000))) // w)
+        else:
+            h = (npx + w - 1) // w + int(rng.integers(1, 40))
+        while w * h < 8 * (len(body) + 14):                         # keep it flat (dec_image_is_flat): more rows of the last pixel
+            h += 7
+        yield (f"flat_seed{seed}_{variant}", b"qoif" + struct.pack(">II", w, h) + bytes([4, 0]) + bytes(body) + bytes([0, 0, 0, 0, 0, 0, 0, 1]), w, h)

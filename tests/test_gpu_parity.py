@@ -147,6 +147,56 @@ def test_decode_record_pairs(api, oracle, seg):
             del os.environ["QOIMI_SEG_BYTES"]
 
 
+@pytest.mark.parametrize("seg", [None, "64", "128", "512", "4096"])
+@pytest.mark.parametrize("run_desc", ["1", "0"])
+def test_decode_flat_images_run_descriptors(api, oracle, seg, run_desc):
+    """Flat images (less than a byte per eight pixels) write their long runs through run descriptors (dec_segments_rec<OCH, true>,
+    dec_expand_runs): cases.flat_run_streams - runs merged over the 62 cap, every head alignment and tail length, runs that open the
+    image, run over its end or stop short of it, alpha levels - one by one at every segment size, 3- and 4-channel output, and all of
+    them in ONE call beside a photograph and a noise image (which take the lane-written path).  run_desc 0: the same without
+    descriptors (QOIMI_DEC_RUN_DESC=0)."""
+    import torch
+    from qoi_amd import synth
+    if seg is not None:
+        os.environ["QOIMI_SEG_BYTES"] = seg
+    os.environ["QOIMI_DEC_RUN_DESC"] = run_desc
+    try:
+        c = api.Context(0)
+        streams = list(cases.flat_run_streams())
+        for name, stream, w, h in streams:
+            if seg in ("64", "128") and len(stream) > 100000:
+                continue
+            s = torch.from_numpy(np.frombuffer(stream + b"\0" * 8, dtype=np.uint8).copy()).cuda()
+            for och in (4, 3):
+                want, _ = oracle.decode(stream, och)
+                out = torch.full((w * h * och + 8,), 0xAB, dtype=torch.uint8, device="cuda")
+                c.decode_batch(s.data_ptr(), s.numel(), [len(stream)], [api.QoiDesc(w, h, 4, 0)], och, out.data_ptr(), w * h * och)
+                got = out[:w * h * och].cpu().numpy()
+                assert np.array_equal(got, want), (name, och, seg, int(np.argmax(got != want)))
+                assert int(out[w * h * och]) == 0xAB, "wrote past the image"
+        # one call: the flat images between a photograph and a noise image
+        extra = [(k, oracle.encode(synth.frame_rgba(k, 320, 200, 9), 320, 200, 4), 320, 200) for k in ("photo", "noise")]
+        items = [extra[0]] + streams[:6] + [extra[1]] + streams[6:]
+        sstride = max(len(x[1]) for x in items) + 64
+        for och in (4, 3):
+            pstride = max(x[2] * x[3] for x in items) * och + 32
+            buf = torch.zeros(len(items) * sstride, dtype=torch.uint8, device="cuda")
+            for i, (_, st, _, _) in enumerate(items):
+                buf[i * sstride:i * sstride + len(st)].copy_(torch.from_numpy(np.frombuffer(st, dtype=np.uint8).copy()))
+            out = torch.full((len(items) * pstride,), 0xAB, dtype=torch.uint8, device="cuda")
+            c.decode_batch(buf.data_ptr(), sstride, [len(x[1]) for x in items], [api.QoiDesc(x[2], x[3], 4, 0) for x in items], och, out.data_ptr(), pstride)
+            host = out.cpu().numpy()
+            for i, (name, st, w, h) in enumerate(items):
+                want, _ = oracle.decode(st, och)
+                assert np.array_equal(host[i * pstride:i * pstride + w * h * och], want), (name, och, seg, "batch")
+                assert (host[i * pstride + w * h * och:(i + 1) * pstride] == 0xAB).all(), (name, "wrote past the image")
+        c.close()
+    finally:
+        if seg is not None:
+            del os.environ["QOIMI_SEG_BYTES"]
+        del os.environ["QOIMI_DEC_RUN_DESC"]
+
+
 def test_round_trip_random_host_api(api, oracle):
     rng = np.random.default_rng(7)
     for it in range(40):
@@ -173,14 +223,43 @@ def test_host_encode_result_outgrows_the_expected_size(api, oracle, worst_case):
     reference's worst-case allocation (QOIMI_ENCODE_WORST_CASE_BUFFER=1)."""
     from qoi_amd import synth
     w, h = 1920, 1080
+    import threading
     os.environ["QOIMI_ENCODE_WORST_CASE_BUFFER"] = worst_case
-    try:
+    bad = []
+
+    def work():                       # a fresh thread: its context reads the variable when it is created (once, not per call)
         for kind in ("constant", "noise", "constant", "photo", "noise"):
             px = synth.frame_rgba(kind, w, h, 11).reshape(-1, 4)
             s = api.qoi_encode(px, api.QoiDesc(w, h, 4, 0))
-            assert s == oracle.encode(px, w, h, 4), kind
+            if s != oracle.encode(px, w, h, 4):
+                bad.append(kind)
+    try:
+        t = threading.Thread(target=work)
+        t.start(); t.join()
+        assert not bad, bad
     finally:
         del os.environ["QOIMI_ENCODE_WORST_CASE_BUFFER"]
+
+
+@pytest.mark.parametrize("n,w,h", [(1, 1920, 1080), (3, 1280, 720), (12, 1280, 720)])
+def test_a_placement_wait_that_gives_up_is_encoded_again_order_free(api, oracle, n, w, h):
+    """QOIMI_TEST_SPIN_BOUND=1: every placement wait (tree for fewer than 8 images, look-back for more) that needs a second poll gives up,
+    ends the launch's other waits and leaves err set; qoimi_encode_status then encodes the call again order-free - QOIMI_OK and the
+    reference's bytes."""
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    os.environ["QOIMI_TEST_SPIN_BOUND"] = "1"
+    try:
+        c = api.Context(0)
+    finally:
+        del os.environ["QOIMI_TEST_SPIN_BOUND"]
+    b = DeviceBatch(c, w, h, 4, n)
+    for i in range(n):
+        c.synth_frames(synth.KIND_ID["photo"], synth.DEFAULT_SEED, 300 + i, 1, w, h, b.pixels.data_ptr() + i * b.pixel_stride, b.pixel_stride, b.stream)
+    lens = b.encode()                 # encode_batch + encode_status (raises on an error status)
+    for i in range(n):
+        assert b.stream_bytes(i, lens[i]) == oracle.encode(synth.frame_rgba("photo", w, h, 300 + i), w, h, 4), i
+    c.close()
 
 
 # ------------------------------------------------------------------ device batch API
