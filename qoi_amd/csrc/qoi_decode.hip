@@ -24,6 +24,7 @@
 namespace qoimi {
 
 constexpr uint32_t kGrp = 64;      // segments per group of the two-level chains
+constexpr uint32_t kSummaryDescs = 65;   // run descriptors (8 bytes) that fit a segment's slot of symbolic summaries (65 x 8 bytes)
 
 // locate (image, segment-in-image) of global segment q / group G: images are few thousand at most
 __device__ __forceinline__ uint32_t find_image(const DecImage* __restrict__ im, uint32_t n_images, uint32_t q) {
@@ -1879,7 +1880,9 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     const uint32_t limit = im.npx;
     const uint32_t px_first = have ? p.px_off[q] : 0u;
     // FLAT: the lane's run descriptors (8 bytes each: start pixel, pixels) and the run in the making
-    uint2* const my_desc = FLAT ? p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap : nullptr;
+    // (the other images, desc_all: a QOI_OP_RUN of twelve pixels or more leaves a descriptor too - one per chunk, nothing pending between
+    // steps - in the segment's slot of the symbolic summaries, which are dead once the entry states stand: kSummaryDescs of them)
+    uint2* const my_desc = FLAT ? p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap : reinterpret_cast<uint2*>(p.summary + (size_t)(have ? q : 0u) * 65u);
     uint32_t n_desc = 0u, run_start = 0u, run_len = 0u;       // run_len != 0: a run is pending - W.ppos is behind it, the ring is empty
     RecSource S; S.init(p, blockIdx.x, lane, have && px_first < limit ? p.rec_gran[q] : 0u);
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);
@@ -2034,7 +2037,20 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                                 W.ppos += rem; W.fpos = W.ppos;
                                 rem = 0u;
                             }
-                        } else if (rem >= kLongRun) W.splat(px, rem);
+                        } else if (rem >= kLongRun) {
+                            if (p.desc_all) {
+                                // sprites, screenshots with photographs in them: the run's head up to a 4-pixel boundary through the ring, the ring
+                                // out, the aligned part as a descriptor for dec_expand_runs (the lane wrote it in 16-byte pieces of its own: fifteen
+                                // stores for a run of 62 while the other 63 lanes wait), the tail through the ring
+                                while ((W.ppos & 3u) != 0u && rem) { W.put(px); --rem; }
+                                const uint32_t aligned = rem & ~3u;
+                                if (aligned != 0u && n_desc < kSummaryDescs) {
+                                    W.finish();
+                                    my_desc[n_desc] = make_uint2(W.ppos, aligned); ++n_desc;
+                                    W.ppos += aligned; W.fpos = W.ppos; rem -= aligned;
+                                } else if (rem >= 4u) W.splat(px, rem);
+                            } else W.splat(px, rem);
+                        }
                         while (rem) { W.put(px); --rem; }
                         if (W.ppos - W.fpos > Writer::kRing - 2u * kDrainEvery) W.drain();
                     }
@@ -2053,6 +2069,8 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
     if (FLAT) {
         if (run_len != 0u) flush_run();
+        if (have) p.run_cnt[q] = n_desc;
+    } else if (p.desc_all) {
         if (have) p.run_cnt[q] = n_desc;
     }
     if (have) {
@@ -2092,10 +2110,11 @@ __global__ __launch_bounds__(256) void dec_expand_runs(DecParams p) {
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
-    have = have && j >= im.start_seg && j < im.n_active && im.desc_base != kNoRunDesc;
+    const bool flat = im.desc_base != kNoRunDesc;
+    have = have && j >= im.start_seg && j < im.n_active && (flat || p.desc_all != 0u);
     const uint32_t cnt = have ? p.run_cnt[q] : 0u;
     u64 todo = lanes_where(cnt != 0u);
-    const u64 dbase = (u64)(uintptr_t)(p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap);
+    const u64 dbase = flat ? (u64)(uintptr_t)(p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap) : (u64)(uintptr_t)(p.summary + (size_t)(have ? q : 0u) * 65u);
     const u64 obase = (u64)(uintptr_t)(p.pixels + (size_t)img * p.pixel_stride);
     while (todo) {
         const int l = __builtin_ctzll(todo);
@@ -2287,7 +2306,7 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
         else hipLaunchKernelGGL((dec_segments_rec<3, true>), dim3(b64), dim3(64), 0, st, p);
     }
     tm->mark(kT_dec_segments, st);
-    if (p.flat_segs) {
+    if (p.flat_segs || p.desc_all) {
         if (out_channels == 4) hipLaunchKernelGGL(dec_expand_runs<4>, dim3((b64 + 3u) / 4u), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(dec_expand_runs<3>, dim3((b64 + 3u) / 4u), dim3(256), 0, st, p);
         tm->mark(kT_dec_expand, st);

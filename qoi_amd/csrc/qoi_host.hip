@@ -116,7 +116,7 @@ struct qoimi_ctx {
     int dec_p3_plain = 1, dec_inner = 4, dec_inner1 = 3;   // env QOIMI_P3_PLAIN, QOIMI_DEC_INNER, QOIMI_DEC_INNER1 (read once, at creation)
     int dec_l2_wgs = 1;          // dec_chain_state_l2m: 0 never, 1 for calls of up to four images of 128 groups or more, 2 for every call of up to four images (env QOIMI_DEC_L2M, tests)
     int dec_flat_seg = 1;        // 0: calls of flat images take the segment size of the general cost model (env QOIMI_DEC_FLAT_SEG, A/B)
-    int dec_run_desc = 1;        // 0: flat images write their long runs lane by lane as every image does (env QOIMI_DEC_RUN_DESC, A/B and tests)
+    int dec_run_desc = 2;        // env QOIMI_DEC_RUN_DESC - 0: every long run is written lane by lane; 1: run descriptors for flat images; 2: and a descriptor per long QOI_OP_RUN chunk of the other images
     int dec_max_rounds = kMaxSpecRounds;   // speculation rounds before the sequential last resort (env QOIMI_DEC_MAX_ROUNDS, tests)
     size_t last_drop_len = 0;           // length of the last stream the drop-in qoi_encode returned on this context (page populate-ahead)
     long long enc_retries = 0;          // calls qoimi_encode_status encoded again order-free after a placement wait gave up
@@ -564,6 +564,9 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.rec_rows = rec_region_dwords(B) / 4u;
     p.flat_segs = (uint32_t)flat_total;
     p.desc_cap = rec_region_dwords(B) / 2u + 2u;            // a run ends with the record behind it: every second record at most
+    // descriptors for the long runs of the other images as well - not for calls of a few images without a flat one (one more launch
+    // on a path that counts them)
+    p.desc_all = (c->dec_run_desc >= 2 && (n_images > 4 || flat_total != 0)) ? 1u : 0u;
     p.sync_all = 0;
     p.p3_plain = (uint32_t)c->dec_p3_plain;
     p.refine_inner = (uint32_t)c->dec_inner;
@@ -603,7 +606,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.grp_summary = w.take<u64>(NG * 65); p.grp_entry = w.take<uint32_t>(NG * 65);
         p.l2_sum = w.take<u64>((size_t)n_images * p.l2_wgs * 65);
         p.rec_gran = w.take<uint32_t>(Q);
-        p.run_cnt = w.take<uint32_t>(flat_total ? Q : 0);
+        p.run_cnt = w.take<uint32_t>((flat_total || p.desc_all) ? Q : 0);
         p.run_desc = w.take<uint2>((size_t)flat_total * p.desc_cap);
         p.sync_fail = w.take<uint8_t>(Q);
         p.recs = w.take<uint32_t>(((Q + 63u) / 64u) * p.rec_rows * 256u);

@@ -153,7 +153,8 @@ struct DecParams {
     uint2*    run_desc;        // [flat_segs][desc_cap] (start pixel, pixels) of the long runs of a segment, in stream order
     uint32_t* run_cnt;         // [total_segs + 1] descriptors the segment wrote this round
     uint32_t  desc_cap;        // descriptors a segment can hold: every second record at most ends a run
-    uint32_t  flat_segs;       // segments of flat images in this call (0: no run descriptors, one launch of dec_segments_rec)
+    uint32_t  flat_segs;       // segments of flat images in this call (0: one launch of dec_segments_rec)
+    uint32_t  desc_all;        // 1: the other images leave a descriptor per long QOI_OP_RUN too (in their segments' summary slots)
     uint32_t* first_bad;       // [n_images] min failing segment, 0xFFFFFFFF: none
     uint32_t* pending;         // [1] images that need another round
     uint32_t* redo_segs;       // [1] statistics

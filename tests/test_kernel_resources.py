@@ -50,7 +50,7 @@ def test_decoder_passes_keep_their_workgroups_per_cu(kernels):
     assert 8 * p3["lds"] <= LDS_PER_CU and p3["vgpr"] <= 128, p3       # eight wavefronts (one per workgroup) per CU
     for och in (3, 4):
         p4 = _one(kernels, f"dec_segments_recILi{och}ELb0E")
-        assert 6 * p4["lds"] <= LDS_PER_CU and p4["vgpr"] <= 128, p4   # six per CU
+        assert 6 * p4["lds"] <= LDS_PER_CU and p4["vgpr"] <= (128 if och == 4 else 168), p4   # six per CU by LDS: two per SIMD at most, 256 registers each would do
         p4f = _one(kernels, f"dec_segments_recILi{och}ELb1E")         # flat images (run descriptors): LDS-bound all the same
         assert 6 * p4f["lds"] <= LDS_PER_CU and p4f["vgpr"] <= 168, p4f
 
