@@ -24,7 +24,7 @@
 namespace qoimi {
 
 constexpr uint32_t kGrp = 64;      // segments per group of the two-level chains
-constexpr uint32_t kSummaryDescs = 65;   // run descriptors (8 bytes) that fit a segment's slot of symbolic summaries (65 x 8 bytes)
+constexpr uint32_t kSummaryDescs = 32;   // run descriptors (16 bytes) that fit a segment's slot of symbolic summaries (65 x 8 bytes)
 
 // locate (image, segment-in-image) of global segment q / group G: images are few thousand at most
 __device__ __forceinline__ uint32_t find_image(const DecImage* __restrict__ im, uint32_t n_images, uint32_t q) {
@@ -1851,9 +1851,9 @@ struct BurstWriter : LaneWriter<OCH, RING_, GROUP_> {
 // run lane by lane in 16-byte pieces, 64 lanes 0.3-30 KB apart (34 GB in 19 ms on 1024 UI frames, a third of what the memory system
 // gives coalesced writes).  Consecutive records that leave the pixel as it is - QOI_OP_RUN after QOI_OP_RUN: a run is cut every 62
 // pixels, qoi.h:417 - are merged into ONE run; its head (up to a 4-pixel boundary) and tail go through the ring as before, the
-// aligned middle becomes an 8-byte run descriptor (start pixel, length) in the segment's descriptor region, and dec_expand_runs
-// writes all descriptors of the launch afterwards with whole wavefronts, 1 KiB per store instruction.  The run's pixel is the one
-// in front of `start` (written by this kernel through the ring: a run's first pixel always is).
+// aligned middle becomes a 16-byte run descriptor (start pixel, length, pixel) in the segment's descriptor region, and dec_expand_runs
+// writes all descriptors of the launch afterwards with whole wavefronts, 1 KiB per store instruction.  Segments that left
+// descriptors queue up (run_queue) for it.
 template <int OCH, bool FLAT>
 __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
 #ifndef QOIMI_SEGREC_GROUP
@@ -1882,7 +1882,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     // FLAT: the lane's run descriptors (8 bytes each: start pixel, pixels) and the run in the making
     // (the other images, desc_all: a QOI_OP_RUN of twelve pixels or more leaves a descriptor too - one per chunk, nothing pending between
     // steps - in the segment's slot of the symbolic summaries, which are dead once the entry states stand: kSummaryDescs of them)
-    uint2* const my_desc = FLAT ? p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap : reinterpret_cast<uint2*>(p.summary + (size_t)(have ? q : 0u) * 65u);
+    uint4* const my_desc = FLAT ? p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap : reinterpret_cast<uint4*>(p.summary + (size_t)(have ? q : 0u) * 65u);
     uint32_t n_desc = 0u, run_start = 0u, run_len = 0u;       // run_len != 0: a run is pending - W.ppos is behind it, the ring is empty
     RecSource S; S.init(p, blockIdx.x, lane, have && px_first < limit ? p.rec_gran[q] : 0u);
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);
@@ -1922,7 +1922,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     auto flush_run = [&]() {
         const uint32_t aligned = run_len & ~3u, tail = run_len & 3u;
         const uint32_t end = W.ppos;
-        if (aligned != 0u && n_desc < p.desc_cap) { my_desc[n_desc] = make_uint2(run_start, aligned); ++n_desc; W.ppos = W.fpos = run_start + aligned; }
+        if (aligned != 0u && n_desc < p.desc_cap) { my_desc[n_desc] = make_uint4(run_start, aligned, px, 0u); ++n_desc; W.ppos = W.fpos = run_start + aligned; }
         else { W.ppos = W.fpos = run_start; uint32_t n = run_len - tail; if (n) W.splat(px, n); }     // (no room: never - at most every second record ends a run)
         for (uint32_t k = 0; k < tail; ++k) W.put(px);
         W.ppos = end; run_len = 0u;
@@ -2046,7 +2046,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                                 const uint32_t aligned = rem & ~3u;
                                 if (aligned != 0u && n_desc < kSummaryDescs) {
                                     W.finish();
-                                    my_desc[n_desc] = make_uint2(W.ppos, aligned); ++n_desc;
+                                    my_desc[n_desc] = make_uint4(W.ppos, aligned, px, 0u); ++n_desc;
                                     W.ppos += aligned; W.fpos = W.ppos; rem -= aligned;
                                 } else if (rem >= 4u) W.splat(px, rem);
                             } else W.splat(px, rem);
@@ -2067,11 +2067,18 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
         }
     };
     if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
-    if (FLAT) {
-        if (run_len != 0u) flush_run();
-        if (have) p.run_cnt[q] = n_desc;
-    } else if (p.desc_all) {
-        if (have) p.run_cnt[q] = n_desc;
+    if (FLAT) { if (run_len != 0u) flush_run(); }
+    if (FLAT || p.desc_all) {
+        // segments with descriptors queue up for dec_expand_runs: one returning atomic per wavefront that has any
+        const bool some = have && n_desc != 0u;
+        const u64 m = lanes_where(some);
+        if (m != 0ull) {
+            uint32_t base = 0u;
+            const uint32_t first = (uint32_t)__builtin_ctzll(m);
+            if (lane == first) base = atomicAdd(p.run_queue_n, (uint32_t)__builtin_popcountll(m));
+            base = read_lane_dyn(base, first);
+            if (some) { p.run_queue[base + count_below(m)] = q; p.run_cnt[q] = n_desc; }
+        }
     }
     if (have) {
         W.finish();
@@ -2098,39 +2105,32 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     }
 }
 
-// The run descriptors of a round (dec_segments_rec<OCH, true>), written out: one wavefront per 64 segments (the geometry of the
-// kernel that made them) takes its segments one after the other, 64 descriptors at a time - lane i fetches descriptor i and the
-// pixel in front of its run - and writes every run with all 64 lanes, 16 bytes (OCH 3: 12 bytes, four pixels) per lane and store
-// instruction: whole KiB-sized pieces of one image row after the other instead of 64 lanes 16 bytes each at 64 places.
+// The run descriptors of a round, written out.  A wavefront takes the queued segments wave-th, wave + N-th, ... (N wavefronts in the
+// launch; the queue length is only known on the device): 64 descriptors at a time in registers (lane i holds descriptor i, the next
+// 64 on their way), every run written by all 64 lanes, 16 bytes (OCH 3: 12 bytes, four pixels) per lane and store instruction - KiB-sized
+// pieces of one image row after the other instead of 64 lanes 16 bytes each at 64 places.
+// (The first form gave a wavefront the 64 segments of the dec_segments_rec wavefront that made them: 1024 UI frames at 4 KiB segments
+// were 2600 wavefronts of 87 000 descriptors each, one after the other: 28.8 ms for 34 GB, profiles/r05_s2_dec_desc.txt.)
+constexpr uint32_t kExpandBlocks = 4096;
 template <int OCH>
 __global__ __launch_bounds__(256) void dec_expand_runs(DecParams p) {
     const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t q = (blockIdx.x * 4u + wave) * 64u + lane;
-    bool have = q < p.total_segs;
-    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
-    const DecImage im = p.images[img];
-    const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
-    const bool flat = im.desc_base != kNoRunDesc;
-    have = have && j >= im.start_seg && j < im.n_active && (flat || p.desc_all != 0u);
-    const uint32_t cnt = have ? p.run_cnt[q] : 0u;
-    u64 todo = lanes_where(cnt != 0u);
-    const u64 dbase = flat ? (u64)(uintptr_t)(p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap) : (u64)(uintptr_t)(p.summary + (size_t)(have ? q : 0u) * 65u);
-    const u64 obase = (u64)(uintptr_t)(p.pixels + (size_t)img * p.pixel_stride);
-    while (todo) {
-        const int l = __builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t n = read_lane_dyn(cnt, (uint32_t)l);
-        const uint2* __restrict__ dsc = reinterpret_cast<const uint2*>((uintptr_t)((u64)read_lane_dyn((uint32_t)dbase, (uint32_t)l) | ((u64)read_lane_dyn((uint32_t)(dbase >> 32), (uint32_t)l) << 32)));
-        uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>((uintptr_t)((u64)read_lane_dyn((uint32_t)obase, (uint32_t)l) | ((u64)read_lane_dyn((uint32_t)(obase >> 32), (uint32_t)l) << 32)));
+    const uint32_t n_items = *p.run_queue_n;
+    const uint32_t n_waves = gridDim.x * 4u;
+    for (uint32_t item = blockIdx.x * 4u + wave; item < n_items; item += n_waves) {
+        const uint32_t q = __builtin_amdgcn_readfirstlane(p.run_queue[item]);
+        const uint32_t img = find_image(p.images, p.n_images, q);
+        const uint32_t seg_base = p.images[img].seg_base, desc_base = p.images[img].desc_base;
+        const uint32_t n = p.run_cnt[q];
+        const uint4* __restrict__ dsc = desc_base != kNoRunDesc ? p.run_desc + (size_t)(desc_base + (q - seg_base)) * p.desc_cap
+                                                                 : reinterpret_cast<const uint4*>(p.summary + (size_t)q * 65u);
+        uint8_t* __restrict__ out = p.pixels + (size_t)img * p.pixel_stride;
+        uint4 cur = lane < n ? dsc[lane] : make_uint4(0u, 0u, 0u, 0u);
         for (uint32_t d0 = 0; d0 < n; d0 += 64u) {
-            const bool mine = d0 + lane < n;
-            const uint2 dd = mine ? dsc[d0 + lane] : make_uint2(1u, 0u);
-            uint32_t v;                                              // the run's pixel: the one in front of it
-            if (OCH == 4) v = mine ? reinterpret_cast<const uint32_t*>(out)[dd.x - 1u] : 0u;
-            else { const uint8_t* s3 = out + (size_t)(dd.x - 1u) * 3u; v = mine ? ((uint32_t)s3[0] | ((uint32_t)s3[1] << 8) | ((uint32_t)s3[2] << 16)) : 0u; }
+            const uint4 nxt = d0 + 64u + lane < n ? dsc[d0 + 64u + lane] : make_uint4(0u, 0u, 0u, 0u);
             const uint32_t m = min(n - d0, 64u);
             for (uint32_t i = 0; i < m; ++i) {
-                const uint32_t start = read_lane_dyn(dd.x, i), len = read_lane_dyn(dd.y, i), px = read_lane_dyn(v, i);
+                const uint32_t start = read_lane_dyn(cur.x, i), len = read_lane_dyn(cur.y, i), px = read_lane_dyn(cur.z, i);
                 if (OCH == 4) {
                     uint4* __restrict__ o = reinterpret_cast<uint4*>(out + (size_t)start * 4u);          // start is a multiple of 4 pixels: 16-byte aligned
                     const uint4 w4 = make_uint4(px, px, px, px);
@@ -2142,6 +2142,7 @@ __global__ __launch_bounds__(256) void dec_expand_runs(DecParams p) {
                     for (uint32_t k = lane; k < (len >> 2); k += 64u) { o[3u * k] = w0; o[3u * k + 1u] = w1; o[3u * k + 2u] = w2; }
                 }
             }
+            cur = nxt;
         }
     }
 }
@@ -2222,6 +2223,7 @@ __global__ __launch_bounds__(256) void dec_fill(DecParams p) {
     const uint32_t img = blockIdx.x / kFillSlices, slice = blockIdx.x % kFillSlices;
     const DecImage im = p.images[img];
     if (slice == 0u && threadIdx.x < 64u && p.total_segs != 0u) prepare_restart(p, img, threadIdx.x);
+    if (blockIdx.x == 0u && threadIdx.x == 64u) *p.run_queue_n = 0u;        // the round's run descriptors are written out (dec_expand_runs ran before this launch)
     if (im.total_px >= im.npx) return;
     const uint32_t px = im.n_active ? im.final_px : kInitPx;
     uint8_t* out = p.pixels + (size_t)img * p.pixel_stride;
@@ -2307,8 +2309,9 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     }
     tm->mark(kT_dec_segments, st);
     if (p.flat_segs || p.desc_all) {
-        if (out_channels == 4) hipLaunchKernelGGL(dec_expand_runs<4>, dim3((b64 + 3u) / 4u), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(dec_expand_runs<3>, dim3((b64 + 3u) / 4u), dim3(256), 0, st, p);
+        const uint32_t eb = (p.total_segs + 3u) / 4u < kExpandBlocks ? (p.total_segs + 3u) / 4u : kExpandBlocks;
+        if (out_channels == 4) hipLaunchKernelGGL(dec_expand_runs<4>, dim3(eb), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(dec_expand_runs<3>, dim3(eb), dim3(256), 0, st, p);
         tm->mark(kT_dec_expand, st);
     }
     // (the restart of the images whose check failed is prepared by dec_fill, which every round ends with)

@@ -485,7 +485,8 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
     if (B == 0 && c->dec_run_desc && c->dec_flat_seg) {
         // A call of FLAT images only (run descriptors): a lane's walk over its segment no longer writes the segment's pixels, it costs
         // its chunks alone - larger segments mean fewer entry states (780 bytes per segment whatever its size), fewer chances to miss
-        // (a round per miss) and the same work.  The largest size that still gives every CU three wavefronts of lanes.
+        // (a round per miss) and the same work.  The largest size that still fills the 98 K lanes dec_segments_rec holds at a time four
+        // times over (B = 4096 on 1024 UI frames: 165 K lanes, P3 11.9 ms and P4 10.7 against 7.7 and 8.0 at B = 1024, profiles/r05_s2_*).
         bool all_flat = true;
         uint64_t bytes = 0;
         for (int i = 0; i < n_images && all_flat; ++i) {
@@ -494,7 +495,7 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
         }
         if (all_flat)
             for (uint32_t cand = 4096u; cand >= 256u; cand >>= 1)
-                if (bytes / cand >= 49152u) { B = cand; break; }
+                if (bytes / cand >= 393216u) { B = cand; break; }
     }
     if (B == 0) {
         // One lane decodes one segment.  Two costs pull in opposite directions (constants measured on MI355X):
@@ -594,6 +595,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     for (int pass = 0; pass < 2; ++pass) {
         Carver w(pass ? c->dec_ws.base : nullptr);
         p.pending = w.take<uint32_t>(4); p.redo_segs = p.pending ? p.pending + 1 : nullptr; p.sync_fails = p.pending ? p.pending + 2 : nullptr;
+        p.run_queue_n = p.pending ? p.pending + 3 : nullptr;
         p.l2_ticket = p.pending ? p.pending + 8 : nullptr; p.l2_flag = p.pending ? p.pending + 16 : nullptr;       // words 8..11 and 16..47 of the zeroed 256-byte header
         p.images = w.take<DecImage>((size_t)n_images);
         p.first_bad = w.take<uint32_t>((size_t)n_images);
@@ -607,7 +609,8 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.l2_sum = w.take<u64>((size_t)n_images * p.l2_wgs * 65);
         p.rec_gran = w.take<uint32_t>(Q);
         p.run_cnt = w.take<uint32_t>((flat_total || p.desc_all) ? Q : 0);
-        p.run_desc = w.take<uint2>((size_t)flat_total * p.desc_cap);
+        p.run_queue = w.take<uint32_t>((flat_total || p.desc_all) ? Q : 0);
+        p.run_desc = w.take<uint4>((size_t)flat_total * p.desc_cap);
         p.sync_fail = w.take<uint8_t>(Q);
         p.recs = w.take<uint32_t>(((Q + 63u) / 64u) * p.rec_rows * 256u);
         if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }

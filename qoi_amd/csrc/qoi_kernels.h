@@ -150,8 +150,10 @@ struct DecParams {
     u64*      grp_summary;     // S3 l1 [G][65]
     uint32_t* grp_entry;       // S3 l2 [G][65]
     // run descriptors of the flat images (dec_segments_rec<OCH, true> -> dec_expand_runs)
-    uint2*    run_desc;        // [flat_segs][desc_cap] (start pixel, pixels) of the long runs of a segment, in stream order
-    uint32_t* run_cnt;         // [total_segs + 1] descriptors the segment wrote this round
+    uint4*    run_desc;        // [flat_segs][desc_cap] (start pixel, pixels, pixel value, -) of the long runs of a segment, in stream order
+    uint32_t* run_cnt;         // [total_segs + 1] descriptors the segment wrote this round (valid for the segments in run_queue)
+    uint32_t* run_queue;       // [total_segs] segments that wrote descriptors this round
+    uint32_t* run_queue_n;     // [1] their number (word 3 of the counter header; dec_fill zeroes it again)
     uint32_t  desc_cap;        // descriptors a segment can hold: every second record at most ends a run
     uint32_t  flat_segs;       // segments of flat images in this call (0: one launch of dec_segments_rec)
     uint32_t  desc_all;        // 1: the other images leave a descriptor per long QOI_OP_RUN too (in their segments' summary slots)
