@@ -112,6 +112,17 @@ int qoimi_encode_batch(qoimi_ctx *ctx, const void *d_pixels, size_t pixel_stride
                        void *d_streams, size_t stream_stride, int *d_stream_len,
                        void *stream);
 
+/* The same for images of DIFFERENT shapes and channel counts in one call (a directory of images, qoibench.c:491-555):
+ *   pixel_offsets  HOST size_t[n_images]: image i starts at d_pixels + pixel_offsets[i] (tightly packed, as above)
+ *   descs          HOST qoi_desc[n_images]: every one must pass the rules of qoi.h:364-372
+ *   stream_offsets HOST size_t[n_images]: stream i is written at d_streams + stream_offsets[i]; the caller leaves
+ *                  qoimi_encode_bound(&descs[i]) bytes there
+ * Streams are byte-identical to the reference encoder's.  Every set of slabs parks its bytes in a scratch slot of its own and two
+ * more passes place them (no set waits for another, whatever the mix of sizes): about 5 bytes of workspace per pixel of the call.
+ * Enqueues on `stream`; the call itself waits for the stream's earlier work once (its image table travels through pinned staging). */
+int qoimi_encode_images(qoimi_ctx *ctx, const void *d_pixels, const size_t *pixel_offsets, const qoi_desc *descs, int n_images,
+                        void *d_streams, const size_t *stream_offsets, int *d_stream_len, void *stream);
+
 /* The encoder's colour-table probe uses one LDS exchange instruction per 64 pixels and relies on the LDS serving the lanes of
  * that instruction in ascending order - a MEASURED property of gfx950, not a documented one (qoi_amd/csrc/qoi_encode.hip).  It
  * is measured alone and under contention when a context is created (a failure selects the order-independent probe) and again
@@ -134,8 +145,9 @@ int qoimi_encode_status(qoimi_ctx *ctx, void *stream);
  *   d_streams      stream i starts at d_streams + i*stream_stride and is sizes[i] bytes
  *   sizes          HOST int[n_images] (the `size` argument of qoi.h:289 per image)
  *   descs          HOST qoi_desc[n_images]: the header of each stream as parsed by the
- *                  caller (what qoi_decode would write to *desc); all images must decode
- *                  to the same w*h*out_channels byte count <= pixel_stride
+ *                  caller (what qoi_decode would write to *desc); the images may differ in
+ *                  shape - each must decode to w*h*out_channels <= pixel_stride bytes - but
+ *                  share the output channel count (channels, or their headers' when it is 0)
  *   channels       0, 3 or 4 — as qoi.h:289
  *   d_pixels       image i is written at d_pixels + i*pixel_stride
  * Synchronous with respect to `stream` (the exactness check of the speculative decoder

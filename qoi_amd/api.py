@@ -34,7 +34,7 @@ EXPORTS = (
     "qoimi_ctx_create", "qoimi_ctx_destroy", "qoimi_last_error", "qoimi_encode_bound",
     "qoimi_encode_batch", "qoimi_encode_status", "qoimi_decode_batch", "qoimi_synth_frames",
     "qoimi_decode_stats", "qoimi_version", "qoimi_set_profiling", "qoimi_get_profile", "qoimi_kernel_name",
-    "qoimi_encode_suspect_calls", "qoimi_workspace_bytes", "qoimi_hash_streams",
+    "qoimi_encode_suspect_calls", "qoimi_workspace_bytes", "qoimi_hash_streams", "qoimi_encode_images",
 )
 
 
@@ -105,6 +105,8 @@ def load_library() -> ctypes.CDLL:
     lib.qoimi_workspace_bytes.argtypes = [vp, ctypes.POINTER(sz)]
     lib.qoimi_encode_suspect_calls.restype = ctypes.c_longlong
     lib.qoimi_encode_suspect_calls.argtypes = [vp]
+    lib.qoimi_encode_images.restype = ci
+    lib.qoimi_encode_images.argtypes = [vp, vp, ctypes.POINTER(sz), ctypes.POINTER(QoiDesc), ci, vp, ctypes.POINTER(sz), vp, vp]
     lib.qoimi_hash_streams.restype = ci
     lib.qoimi_hash_streams.argtypes = [vp, vp, sz, vp, ci, vp, vp]
     _lib = lib
@@ -226,6 +228,16 @@ class Context:
                      d_streams: int, stream_stride: int, d_stream_len: int, stream: int = 0) -> None:
         self._check(self._lib.qoimi_encode_batch(self._h, d_pixels, pixel_stride, ctypes.byref(desc), n_images,
                                                  d_streams, stream_stride, d_stream_len, stream), "qoimi_encode_batch")
+
+    def encode_images(self, d_pixels: int, pixel_offsets: Sequence[int], descs: Sequence[QoiDesc], d_streams: int,
+                      stream_offsets: Sequence[int], d_stream_len: int, stream: int = 0) -> None:
+        """Images of different shapes / channel counts in one call (``qoimi_encode_images``)."""
+        n = len(descs)
+        if len(pixel_offsets) != n or len(stream_offsets) != n:
+            raise QoiError("encode_images: one pixel offset and one stream offset per descriptor")
+        po = (ctypes.c_size_t * n)(*[int(x) for x in pixel_offsets])
+        so = (ctypes.c_size_t * n)(*[int(x) for x in stream_offsets])
+        self._check(self._lib.qoimi_encode_images(self._h, d_pixels, po, (QoiDesc * n)(*descs), n, d_streams, so, d_stream_len, stream), "qoimi_encode_images")
 
     def encode_status(self, stream: int = 0) -> None:
         self._check(self._lib.qoimi_encode_status(self._h, stream), "qoimi_encode_status")

@@ -1922,8 +1922,9 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     auto flush_run = [&]() {
         const uint32_t aligned = run_len & ~3u, tail = run_len & 3u;
         const uint32_t end = W.ppos;
-        if (aligned != 0u && n_desc < p.desc_cap) { my_desc[n_desc] = make_uint4(run_start, aligned, px, 0u); ++n_desc; W.ppos = W.fpos = run_start + aligned; }
-        else { W.ppos = W.fpos = run_start; uint32_t n = run_len - tail; if (n) W.splat(px, n); }     // (no room: never - at most every second record ends a run)
+        if (aligned != 0u && n_desc < p.desc_cap) { my_desc[n_desc] = make_uint4(run_start, aligned, px, 0u); ++n_desc; }
+        else for (uint32_t i = run_start; i < run_start + aligned; i += 4u) W.store4(i, px, px, px, px);     // (no room: never - at most every second record ends a run)
+        W.ppos = W.fpos = run_start + aligned;
         for (uint32_t k = 0; k < tail; ++k) W.put(px);
         W.ppos = end; run_len = 0u;
         (void)end;

@@ -62,6 +62,30 @@ __device__ __forceinline__ uint32_t load_px_at(const uint8_t* __restrict__ q, in
 
 __device__ __forceinline__ int msb64(u64 m) { return 63 - __builtin_clzll(m); }
 
+// The geometry of image `img`: the call's one shape (MIXED false: the same expressions as ever, folded by the compiler), or its entry
+// of the image table (qoimi_encode_images).
+template <bool MIXED>
+__device__ __forceinline__ EncImage enc_image(const EncParams& p, uint32_t img) {
+    if (MIXED) return p.img_tab[img];
+    EncImage e;
+    e.pixel_off = (size_t)img * p.pixel_stride; e.out_off = (size_t)img * p.out_stride;
+    e.npx = p.npx; e.spi = p.spi; e.gpi = p.gpi; e.sets = p.sets_per_image;
+    e.set_base = img * p.sets_per_image; e.slab_base = img * p.spi; e.grp_base = img * p.gpi; e.unit_base = 0u;
+    e.width = p.width; e.height = p.height; e.colorspace = p.colorspace; e.len_index = img;
+    return e;
+}
+// image that holds global slab / group / set / unit `v` (MIXED): the last image whose base is <= v
+#define QOIMI_FIND_ENC_IMAGE(FIELD)                                                                    \
+    __device__ __forceinline__ uint32_t find_by_##FIELD(const EncParams& p, uint32_t v) {             \
+        uint32_t lo = 0, hi = p.n_images;                                                              \
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (p.img_tab[mid].FIELD <= v) lo = mid; else hi = mid; } \
+        return lo;                                                                                     \
+    }
+QOIMI_FIND_ENC_IMAGE(slab_base)
+QOIMI_FIND_ENC_IMAGE(grp_base)
+QOIMI_FIND_ENC_IMAGE(set_base)
+QOIMI_FIND_ENC_IMAGE(unit_base)
+
 // sum of v over lanes 0..stop (stop >= 63: all lanes), the same value for every lane.  Seven DPP adds: within the rows of 16
 // lanes (row_shr 1, 2, 3, then 4 and 8 on the banks that have such a neighbour), then row_bcast 15 / 31 carry the row totals
 // upwards; lane 63 holds the total.
@@ -83,20 +107,22 @@ __device__ __forceinline__ uint32_t wave_sum32_upto(uint32_t v, uint32_t lane, i
 // bit) and the position of the slab's last edge (-1: none).   [qoi.h:415,430,436]
 // One wavefront per slab; LDS ds_max_u64 on (position,value) keys keeps the latest.
 // ---------------------------------------------------------------------------------
-template <int CH, int K>
+template <int CH, int K, bool MIXED>
 __global__ __launch_bounds__(256) void enc_slab_summary(EncParams p) {
     __shared__ u64 s_key[4][64];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
-    const uint32_t total = p.n_images * p.spi;
+    const uint32_t total = p.total_slabs;
 #pragma unroll 1
     for (uint32_t blk = blockIdx.x; blk * 4u < total; blk += gridDim.x) {
     const uint32_t g = blk * 4u + wave;
     if (g >= total) continue;
-    const uint32_t img = g / p.spi, s = g - img * p.spi;
+    const uint32_t img = MIXED ? find_by_slab_base(p, g) : g / p.spi;
+    const EncImage I = enc_image<MIXED>(p, img);
+    const uint32_t s = g - I.slab_base;
     if (p.only_flagged && p.need_generic[img] == 0u) continue;
-    const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
-    const uint32_t n = p.npx, lo = s * (64u * K);
+    const uint8_t* __restrict__ pix = p.pixels + I.pixel_off;
+    const uint32_t n = I.npx, lo = s * (64u * K);
 
     s_key[wave][lane] = 0;
     // all K loads of the slab in flight at once (a streaming kernel with 4 loads per lane in flight
@@ -138,16 +164,19 @@ __global__ __launch_bounds__(256) void enc_slab_summary(EncParams p) {
 // E2a: exclusive "latest valid per slot" / max scan over the <=64 slabs of one group.
 // lane = hash slot.  Writes per-slab group-local entry state and the group aggregate.
 // ---------------------------------------------------------------------------------
+template <bool MIXED>
 __global__ __launch_bounds__(64) void enc_scan_groups(EncParams p) {
     const uint32_t lane = lane_id();
     const uint32_t G = blockIdx.x;                       // img * gpi + grp
-    const uint32_t img = G / p.gpi, grp = G - img * p.gpi;
+    const uint32_t img = MIXED ? find_by_grp_base(p, G) : G / p.gpi;
+    const EncImage I = enc_image<MIXED>(p, img);
+    const uint32_t grp = G - I.grp_base;
     if (p.only_flagged && p.need_generic[img] == 0u) return;
     const uint32_t s0 = grp * 64u;
-    const uint32_t s1 = min(p.spi, s0 + 64u);
+    const uint32_t s1 = min(I.spi, s0 + 64u);
     uint32_t cur = 0; bool curv = false; int curle = -1;
     for (uint32_t s = s0; s < s1; ++s) {
-        const size_t g = (size_t)img * p.spi + s;
+        const size_t g = (size_t)I.slab_base + s;
         const uint32_t t = p.sum_tab[g * 64u + lane];
         const u64 vm = p.sum_valid[g];
         const int l = p.sum_le[g];
@@ -163,13 +192,15 @@ __global__ __launch_bounds__(64) void enc_scan_groups(EncParams p) {
 }
 
 // E2b: exclusive scan over the groups of one image (one wavefront per image).
+template <bool MIXED>
 __global__ __launch_bounds__(64) void enc_scan_images(EncParams p) {
     const uint32_t lane = lane_id();
     const uint32_t img = blockIdx.x;
     if (p.only_flagged && p.need_generic[img] == 0u) return;
+    const EncImage I = enc_image<MIXED>(p, img);
     uint32_t cur = 0; int curle = -1;          // table starts zeroed (qoi.h:393), no edge yet
-    for (uint32_t gr = 0; gr < p.gpi; ++gr) {
-        const size_t G = (size_t)img * p.gpi + gr;
+    for (uint32_t gr = 0; gr < I.gpi; ++gr) {
+        const size_t G = (size_t)I.grp_base + gr;
         const uint32_t t = p.grp_tab[G * 64u + lane];
         const u64 vm = p.grp_valid[G];
         const int l = p.grp_le[G];
@@ -824,15 +855,16 @@ __device__ __forceinline__ void pool_give(const EncParams& p, uint32_t id, uint3
         (void)__hip_atomic_fetch_and((gu64*)&p.pool_map[(size_t)(id >> 6) * kEncPoolMapStride], ~(1ull << (id & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int CH, int PROBE, int ENTRY, class LDS>
+template <int CH, int PROBE, int ENTRY, bool MIXED, class LDS>
 __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, LDS& L) {
-    const uint8_t* __restrict__ pix = p.pixels + (size_t)img * p.pixel_stride;
-    const uint32_t n = p.npx;
+    const EncImage I = enc_image<MIXED>(p, img);
+    const uint8_t* __restrict__ pix = p.pixels + I.pixel_off;
+    const uint32_t n = I.npx;
     const uint32_t lo = set * p.set_px;                        // first pixel of the set (a slab boundary)
     const uint32_t hi = min(n, lo + p.set_px);                 // one past its last pixel
     const bool last_set = hi == n;
     const uint32_t ngroups = (hi - lo + kGroupPx - 1u) / kGroupPx;
-    const size_t sg = (size_t)img * p.sets_per_image + set;    // global index of the set
+    const size_t sg = (size_t)I.set_base + set;                // global index of the set
 #ifdef QOIMI_ENC_PHASES
     unsigned long long t_mark = __builtin_readcyclecounter();
     if (lane == 0) atomicAdd(&g_enc_phase[5], 1ull);
@@ -852,8 +884,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         }
     } else {
         const uint32_t s = set * p.set_slabs;                  // first slab of the set: its entry state is the set's
-        const size_t g = (size_t)img * p.spi + s;
-        const size_t G = (size_t)img * p.gpi + (s >> 6);
+        const size_t g = (size_t)I.slab_base + s;
+        const size_t G = (size_t)I.grp_base + (s >> 6);
         in.tab_loc = p.ent_tab[g * 64u + lane];
         in.tab_far = p.gent_tab[G * 64u + lane];
         in.tab_valid = p.ent_valid[g];
@@ -989,7 +1021,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         // before its group in its block, and the block totals before its block - three loads per poll, depth three whatever the
         // image's size (64^3 sets: 800 Mpx at one slab per set).  A wait is for lower-numbered sets only; units go to the workgroups in
         // START order (enc_sets: one ticket per workgroup), so those are resident or done (the spin bound still guards it).
-        const uint32_t nsets = p.sets_per_image;
+        const uint32_t nsets = I.sets;
         const uint32_t n1 = (nsets + 63u) >> 6, n2 = (n1 + 63u) >> 6;
         u64* const t1 = p.tree1 + (size_t)img * n1;
         u64* const t2 = p.tree2 + (size_t)img * n2;
@@ -1070,11 +1102,11 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 
     PHASE_MARK(3);
     // ---- copy the set's bytes out ----------------------------------------------------------
-    uint8_t* __restrict__ out = p.out + (size_t)img * p.out_stride;
+    uint8_t* __restrict__ out = p.out + I.out_off;
     if (set == 0 && lane < (uint32_t)kHeaderBytes) {        // 14-byte header (qoi.h:384-388)
-        const uint32_t w = p.width, h = p.height;
+        const uint32_t w = I.width, h = I.height;
         const u64 hdr_lo = 0x66696F71ull | ((u64)__builtin_bswap32(w) << 32);             // "qoif", width BE
-        const u64 hdr_hi = (u64)__builtin_bswap32(h) | ((u64)p.channels << 32) | ((u64)p.colorspace << 40);
+        const u64 hdr_hi = (u64)__builtin_bswap32(h) | ((u64)p.channels << 32) | ((u64)I.colorspace << 40);
         out[lane] = (uint8_t)((lane < 8u ? hdr_lo : hdr_hi) >> (8u * (lane & 7u)));
     }
     const u64 pos = (u64)kHeaderBytes + (u64)excl;
@@ -1090,7 +1122,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     if (last_set) {                                         // trailer (qoi.h:339,480-482) + *out_len
         const u64 end = pos + set_bytes;
         if (lane < (uint32_t)kTrailerBytes) out[end + lane] = (lane == 7u) ? 1 : 0;
-        if (lane == 0) p.out_len[img] = (int)(end + kTrailerBytes);
+        if (lane == 0) p.out_len[I.len_index] = (int)(end + kTrailerBytes);
     }
 #ifdef QOIMI_ENC_PHASES
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1103,9 +1135,10 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 // the ENTRY 0 passes with only_flagged set: small grid-stride grids that return at once when nothing was
 // flagged.  A workgroup serves unit u = (image u % n_images, four consecutive sets u / n_images) so that the
 // sets in flight spread over all images.
-template <int CH, int PROBE, int ENTRY>
+template <int CH, int PROBE, int ENTRY, bool MIXED>
 // (the generic 3-channel form - flat 3-channel images only - takes a register more than six wavefronts per SIMD leave it: five)
-__global__ __launch_bounds__(256, PROBE == 1 ? (CH == 3 && ENTRY == 0 ? QOIMI_ENC_WAVES_PER_SIMD - 1 : QOIMI_ENC_WAVES_PER_SIMD) : 4) void enc_sets(EncParams p) {
+// (and so do the forms for differently shaped images, whose geometry comes from a table)
+__global__ __launch_bounds__(256, PROBE == 1 ? ((CH == 3 && ENTRY == 0) || MIXED ? QOIMI_ENC_WAVES_PER_SIMD - 1 : QOIMI_ENC_WAVES_PER_SIMD) : 4) void enc_sets(EncParams p) {
     __shared__ EncLdsFor<PROBE> s_lds[4];
     __shared__ uint32_t s_unit;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
@@ -1127,10 +1160,18 @@ __global__ __launch_bounds__(256, PROBE == 1 ? (CH == 3 && ENTRY == 0 ? QOIMI_EN
         // taking four consecutive tickets of one image at the same instant.  An image's consecutive tickets then go to wavefronts that
         // started at different times (1024 x 4K photographs: 12.45 -> 12.23 ms, profiles/r04_s1_enc_knobs.txt).
         // Every image still receives sets_per_image tickets' worth of wavefronts (4 n_units / n_images of them).
-        const uint32_t img = (p.spread && p.use_ticket && p.lookback == 1) ? (unit * 4u + wave) % p.n_images : unit % p.n_images;
+        uint32_t img, set, sets_of_img = p.sets_per_image;
+        if (MIXED) {
+            // differently shaped images (order-free placement only): the units of an image follow each other
+            img = find_by_unit_base(p, unit);
+            set = (unit - p.img_tab[img].unit_base) * 4u + wave;
+            sets_of_img = p.img_tab[img].sets;
+        } else {
+            img = (p.spread && p.use_ticket && p.lookback == 1) ? (unit * 4u + wave) % p.n_images : unit % p.n_images;
+            set = (unit / p.n_images) * 4u + wave;         // order-free mode: any order will do
+        }
         if (p.only_flagged && p.need_generic[img] == 0u) continue;
         if (ENTRY == 1 && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;   // image already sent to the generic path
-        uint32_t set = (unit / p.n_images) * 4u + wave;    // order-free mode: any order will do
         if (p.use_ticket && p.lookback == 1) {
             // look-back mode: the sets of an image are handed out by the image's ticket counter, one ticket per WAVEFRONT, i.e.
             // in START order: every predecessor a look-back can wait on is already running or finished (no reliance on
@@ -1140,7 +1181,7 @@ __global__ __launch_bounds__(256, PROBE == 1 ? (CH == 3 && ENTRY == 0 ? QOIMI_EN
             if (lane == 0) t = atomicAdd(&p.ticket[img], 1u);
             set = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         }
-        if (set < p.sets_per_image) encode_set<CH, PROBE, ENTRY>(p, img, set, lane, s_lds[wave]);
+        if (set < sets_of_img) encode_set<CH, PROBE, ENTRY, MIXED>(p, img, set, lane, s_lds[wave]);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1154,15 +1195,17 @@ __global__ __launch_bounds__(256, PROBE == 1 ? (CH == 3 && ENTRY == 0 ? QOIMI_EN
 // while this one is scanned), turned through a wavefront-private LDS stripe so that a lane holds 16 consecutive
 // counts, scanned (lane-serial, then six rounds over the wavefront, then over the 16 wavefronts) and written back
 // the same way.
+template <bool MIXED>
 __global__ __launch_bounds__(1024) void enc_offsets(EncParams p) {
     constexpr uint32_t kPer = 16, kStripe = 64u * kPer, kTile = 16u * kStripe;
     __shared__ uint32_t s_turn[16][kStripe + 64u];             // element e of a stripe at e + e/16 (bank spread)
     __shared__ uint32_t s_wave[16];
     const uint32_t img = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (p.only_flagged && (*p.any_generic == 0u || p.need_generic[img] == 0u)) return;     // placement of the generic pass's images only
-    const uint32_t* __restrict__ sz = p.set_size + (size_t)img * p.sets_per_image;
-    uint32_t* __restrict__ off = p.set_off + (size_t)img * p.sets_per_image;
-    const uint32_t n = p.sets_per_image;
+    const EncImage I = enc_image<MIXED>(p, img);
+    const uint32_t* __restrict__ sz = p.set_size + (size_t)I.set_base;
+    uint32_t* __restrict__ off = p.set_off + (size_t)I.set_base;
+    const uint32_t n = I.sets;
     uint32_t* turn = s_turn[wave];
     uint32_t carry = 0;
     uint32_t nv[kPer];
@@ -1200,31 +1243,33 @@ __global__ __launch_bounds__(1024) void enc_offsets(EncParams p) {
         __builtin_amdgcn_wave_barrier();
         carry += total;
     }
-    uint8_t* out = p.out + (size_t)img * p.out_stride;
+    uint8_t* out = p.out + I.out_off;
     const uint32_t total = carry;
     if (tid < (uint32_t)kHeaderBytes) {
-        const uint32_t w = p.width, h = p.height;
+        const uint32_t w = I.width, h = I.height;
         const u64 hdr_lo = 0x66696F71ull | ((u64)__builtin_bswap32(w) << 32);             // "qoif", width BE
-        const u64 hdr_hi = (u64)__builtin_bswap32(h) | ((u64)p.channels << 32) | ((u64)p.colorspace << 40);
+        const u64 hdr_hi = (u64)__builtin_bswap32(h) | ((u64)p.channels << 32) | ((u64)I.colorspace << 40);
         out[tid] = (uint8_t)((tid < 8u ? hdr_lo : hdr_hi) >> (8u * (tid & 7u)));
     }
     if (tid < (uint32_t)kTrailerBytes) out[(size_t)kHeaderBytes + total + tid] = (tid == 7u) ? 1 : 0;
-    if (tid == 0) p.out_len[img] = (int)(kHeaderBytes + total + kTrailerBytes);
+    if (tid == 0) p.out_len[I.len_index] = (int)(kHeaderBytes + total + kTrailerBytes);
 }
 
 // E4b (order-free mode): move every set's bytes from its scratch slot to its place in the stream
 // (one wavefront per set; aligned 16-byte stores, source re-aligned with v_alignbyte).
+template <bool MIXED>
 __global__ __launch_bounds__(256) void enc_compact(EncParams p) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
-    const size_t total = (size_t)p.n_images * p.sets_per_image;
+    const size_t total = MIXED ? (size_t)p.img_tab[p.n_images].set_base : (size_t)p.n_images * p.sets_per_image;
 #pragma unroll 1
     for (size_t sg = (size_t)blockIdx.x * 4u + wave; sg < total; sg += (size_t)gridDim.x * 4u) {
-        const uint32_t img = (uint32_t)(sg / p.sets_per_image);
+        const uint32_t img = MIXED ? find_by_set_base(p, (uint32_t)sg) : (uint32_t)(sg / p.sets_per_image);
         if (p.only_flagged && p.need_generic[img] == 0u) continue;
         const uint32_t n = p.set_size[sg];
         if (n == 0) continue;
-        copy_global_out(p.scratch + sg * p.set_stride, p.out + (size_t)img * p.out_stride + kHeaderBytes + p.set_off[sg], n, lane);
+        const size_t out_off = MIXED ? p.img_tab[img].out_off : (size_t)img * p.out_stride;
+        copy_global_out(p.scratch + sg * p.set_stride, p.out + out_off + kHeaderBytes + p.set_off[sg], n, lane);
     }
 }
 
@@ -1283,12 +1328,15 @@ __global__ __launch_bounds__(64 * WAVES) void lds_order_selftest(uint32_t* out) 
 // ---------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------
-template <int CH, int PROBE>
-static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int phases) {
-    const uint32_t total_slabs = p.n_images * p.spi;
+template <int CH, int PROBE, bool MIXED>
+static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int phases, uint32_t mixed_units, uint32_t mixed_slabs, uint32_t mixed_groups, uint32_t mixed_sets) {
+    const uint32_t total_slabs = MIXED ? mixed_slabs : p.n_images * p.spi;
+    const uint32_t total_groups = MIXED ? mixed_groups : p.n_images * p.gpi;
+    const uint32_t total_sets = MIXED ? mixed_sets : p.n_images * p.sets_per_image;
+    p.total_slabs = total_slabs;
     const uint32_t slab_blocks = (total_slabs + 3u) / 4u;
     const uint32_t quads_per_image = (p.sets_per_image + 3u) / 4u;
-    p.n_units = quads_per_image * p.n_images;
+    p.n_units = MIXED ? mixed_units : quads_per_image * p.n_images;
     const bool warm = p.warm && PROBE == 1;
     // grid of the passes that usually have nothing to do: they return at once then (a few microseconds for 2048 workgroups).  When
     // there IS work - flat content - a grid-stride loop over few long-lived workgroups is the slow way to run enc_sets (a persistent
@@ -1303,18 +1351,18 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         p.only_flagged = 0;
         // (p.persist: test knob - at most that many workgroups, each taking unit after unit in the kernel's grid-stride loop)
         // (tree placement takes its sets by workgroup index and waits for lower-numbered ones: one workgroup per unit, no grid-stride loop)
-        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1>), dim3(p.persist && p.n_units > p.persist && p.lookback != 2 ? p.persist : p.n_units), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, MIXED>), dim3(p.persist && p.n_units > p.persist && p.lookback != 2 ? p.persist : p.n_units), dim3(256), 0, st, p);
         tm->mark(kT_enc_slabs, st);
         p.only_flagged = 1;
     } else {
         p.only_flagged = 0;
         small = 0xFFFFFFFFu;
     }
-    hipLaunchKernelGGL((enc_slab_summary<CH, kEncSteps>), dim3(slab_blocks < small ? slab_blocks : small), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((enc_slab_summary<CH, kEncSteps, MIXED>), dim3(slab_blocks < small ? slab_blocks : small), dim3(256), 0, st, p);
     tm->mark(kT_enc_summary, st);
-    hipLaunchKernelGGL(enc_scan_groups, dim3(p.n_images * p.gpi), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(enc_scan_groups<MIXED>, dim3(total_groups), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_groups, st);
-    hipLaunchKernelGGL(enc_scan_images, dim3(p.n_images), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(enc_scan_images<MIXED>, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_images, st);
     // The images the first pass gave up on (flat content) are encoded again from their first set ...
     const bool first_lookback = p.lookback != 0;
@@ -1330,27 +1378,37 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     } else if (warm) {
         g.lookback = 0; p.lookback = 0;                      // an order-free call: the flagged images are parked and placed with the others
     }
-    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0>), dim3(g.n_units < small || g.lookback == 2 ? g.n_units : small), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((enc_sets<CH, PROBE, 0, MIXED>), dim3(g.n_units < small || g.lookback == 2 ? g.n_units : small), dim3(256), 0, st, g);
     tm->mark(warm ? kT_enc_slabs_generic : kT_enc_slabs, st);
     p.only_flagged = 0;
     }
     if (!p.lookback && (phases & kEncPlace)) {
-        const uint32_t set_blocks = (p.n_images * p.sets_per_image + 3u) / 4u;
-        hipLaunchKernelGGL(enc_offsets, dim3(p.n_images), dim3(1024), 0, st, p);
+        const uint32_t set_blocks = (total_sets + 3u) / 4u;
+        hipLaunchKernelGGL(enc_offsets<MIXED>, dim3(p.n_images), dim3(1024), 0, st, p);
         tm->mark(kT_enc_offsets, st);
-        hipLaunchKernelGGL(enc_compact, dim3(p.only_flagged && set_blocks > small ? small : set_blocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(enc_compact<MIXED>, dim3(p.only_flagged && set_blocks > small ? small : set_blocks), dim3(256), 0, st, p);
         tm->mark(kT_enc_compact, st);
     }
 }
 
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phases) {
     if (p.channels == 3) {
-        if (!p.probe_xchg) launch_encode_t<3, 0>(p, st, tm, phases);
-        else launch_encode_t<3, 1>(p, st, tm, phases);
+        if (!p.probe_xchg) launch_encode_t<3, 0, false>(p, st, tm, phases, 0, 0, 0, 0);
+        else launch_encode_t<3, 1, false>(p, st, tm, phases, 0, 0, 0, 0);
         return;
     }
-    if (!p.probe_xchg) launch_encode_t<4, 0>(p, st, tm, phases);
-    else launch_encode_t<4, 1>(p, st, tm, phases);
+    if (!p.probe_xchg) launch_encode_t<4, 0, false>(p, st, tm, phases, 0, 0, 0, 0);
+    else launch_encode_t<4, 1, false>(p, st, tm, phases, 0, 0, 0, 0);
+}
+// differently shaped images (EncParams::img_tab; order-free placement): totals of the image table
+void launch_encode_mixed(const EncParams& p, uint32_t units, uint32_t slabs, uint32_t groups, uint32_t sets, hipStream_t st, KernelTimer* tm) {
+    if (p.channels == 3) {
+        if (!p.probe_xchg) launch_encode_t<3, 0, true>(p, st, tm, kEncAll, units, slabs, groups, sets);
+        else launch_encode_t<3, 1, true>(p, st, tm, kEncAll, units, slabs, groups, sets);
+        return;
+    }
+    if (!p.probe_xchg) launch_encode_t<4, 0, true>(p, st, tm, kEncAll, units, slabs, groups, sets);
+    else launch_encode_t<4, 1, true>(p, st, tm, kEncAll, units, slabs, groups, sets);
 }
 
 // returns the number of mismatching patterns of the LDS exchange-order self-test (0 = ordered)

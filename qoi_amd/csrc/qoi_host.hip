@@ -443,6 +443,108 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     return QOIMI_OK;
 }
 
+// Differently shaped images in one call (qoibench.c:491-555 walks a directory): per-image descriptors and offsets.  The images are
+// grouped by channel count (the kernels are compiled per count) and every group is placed order-free - each set parks its bytes in a
+// scratch slot of its own, enc_offsets + enc_compact move them - so no set waits for another and any mix of sizes will do.
+extern "C" int qoimi_encode_images(qoimi_ctx* c, const void* d_pixels, const size_t* pixel_offsets, const qoi_desc* descs, int n_images,
+                                   void* d_streams, const size_t* stream_offsets, int* d_stream_len, void* stream) {
+    if (!c || !d_pixels || !pixel_offsets || !descs || !d_streams || !stream_offsets || !d_stream_len || n_images <= 0) return fail(QOIMI_E_ARG, "NULL/empty argument");
+    for (int i = 0; i < n_images; ++i) if (!desc_ok(&descs[i])) return fail(QOIMI_E_ARG, "descriptor rejected (qoi.h:364-372 rules)");
+    DeviceGuard guard(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (c->recheck_pending && hipStreamQuery(c->own_stream) == hipSuccess) {                  // (the repeat of the LDS-order self-test: see qoimi_encode_batch)
+        c->recheck_pending = false;
+        if (c->host_word[8] != 0u || c->test_force_recheck_fail) {
+            c->xchg_ordered = false;
+            c->enc_suspect_calls += c->enc_calls - c->enc_calls_last_passed;
+            c->enc_calls_last_passed = c->enc_calls;
+            c->recheck_failed_unreported = true;
+        } else c->enc_calls_last_passed = c->enc_calls_at_check;
+    }
+    ++c->enc_calls;
+    c->last_enc.valid = false;
+    c->last_enc_err = nullptr;
+    // the table of a channel group travels through pinned staging; both groups' tables and workspaces live side by side in the
+    // arena (the second group's launches follow the first's on the stream and must not overwrite what those still read)
+    size_t ws_off = 0;
+    std::vector<uint32_t*> errs;
+    for (int pass = 0; pass < 2; ++pass) {               // pass 0 measures the arena (both groups), pass 1 carves and launches
+        ws_off = 0;
+        size_t pin_off = 0;
+        for (uint32_t ch = 3; ch <= 4; ++ch) {
+            std::vector<EncImage> tab;
+            std::vector<int> who;
+            uint64_t slabs = 0, groups = 0, units = 0;
+            for (int i = 0; i < n_images; ++i) {
+                if (descs[i].channels != ch) continue;
+                EncImage e; memset(&e, 0, sizeof e);
+                e.pixel_off = pixel_offsets[i]; e.out_off = stream_offsets[i];
+                e.npx = descs[i].width * descs[i].height;
+                e.spi = (e.npx + kEncSlabPx - 1u) / kEncSlabPx; e.gpi = (e.spi + 63u) / 64u;
+                e.width = descs[i].width; e.height = descs[i].height; e.colorspace = descs[i].colorspace;
+                e.slab_base = (uint32_t)slabs; e.grp_base = (uint32_t)groups;
+                slabs += e.spi; groups += e.gpi;
+                e.len_index = (uint32_t)i;
+                tab.push_back(e); who.push_back(i);
+            }
+            if (tab.empty()) continue;
+            if (slabs > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (slab index overflows 32 bits)");
+            const uint32_t n = (uint32_t)tab.size();
+            const uint32_t r = c->enc_set_slabs > 0 ? (uint32_t)(c->enc_set_slabs > (int)kEncMaxSetSlabs ? kEncMaxSetSlabs : c->enc_set_slabs)
+                                                     : (slabs >= 3u * 65536u ? 3u : (slabs >= 16384u ? 2u : 1u));
+            uint64_t sets = 0;
+            for (EncImage& e : tab) { e.sets = (e.spi + r - 1u) / r; e.set_base = (uint32_t)sets; e.unit_base = (uint32_t)units; sets += e.sets; units += (e.sets + 3u) / 4u; }
+            EncImage tail; memset(&tail, 0, sizeof tail);
+            tail.set_base = (uint32_t)sets; tail.slab_base = (uint32_t)slabs; tail.grp_base = (uint32_t)groups; tail.unit_base = (uint32_t)units;
+            tab.push_back(tail);
+            EncParams p; memset(&p, 0, sizeof p);
+            p.pixels = (const uint8_t*)d_pixels; p.out = (uint8_t*)d_streams; p.n_images = n; p.channels = (uint8_t)ch;
+            p.set_slabs = r; p.set_px = r * kEncSlabPx; p.set_stride = r * kEncSlabWorst + 16u;
+            p.probe_xchg = c->xchg_ordered ? 1 : 0; p.use_ticket = 0; p.warm = c->enc_warm ? 1 : 0; p.lookback = 0; p.pool = 0; p.spin_bound = 1u << 22;
+            const size_t T = (size_t)slabs, G = (size_t)groups, S = (size_t)sets;
+            Carver w(pass ? (uint8_t*)c->enc_ws.base + ws_off : nullptr);
+            if (!pass) w.base = nullptr;
+            p.status = w.take<u64>(0); p.ticket = w.take<uint32_t>(n); p.err = w.take<uint32_t>(1);
+            p.need_generic = w.take<uint32_t>(n); p.any_generic = w.take<uint32_t>(1);
+            const size_t zero_bytes = w.off;
+            EncImage* d_tab = w.take<EncImage>(tab.size());
+            p.sum_tab = w.take<uint32_t>(T * 64); p.sum_valid = w.take<u64>(T); p.sum_le = w.take<int>(T);
+            p.ent_tab = w.take<uint32_t>(T * 64); p.ent_valid = w.take<u64>(T); p.ent_le = w.take<int>(T);
+            p.grp_tab = w.take<uint32_t>(G * 64); p.grp_valid = w.take<u64>(G); p.grp_le = w.take<int>(G);
+            p.gent_tab = w.take<uint32_t>(G * 64); p.gent_le = w.take<int>(G);
+            p.set_size = w.take<uint32_t>(S); p.set_off = w.take<uint32_t>(S);
+            p.scratch = w.take<uint8_t>(S * p.set_stride);
+            const size_t used = (w.off + 255u) & ~(size_t)255u;
+            if (pass) {
+                const size_t tbytes = tab.size() * sizeof(EncImage);
+                if (hipMemsetAsync((uint8_t*)c->enc_ws.base + ws_off, 0, zero_bytes, st) != hipSuccess) return fail(QOIMI_E_INTERNAL, "hipMemsetAsync failed");
+                memcpy((uint8_t*)c->pin_buf + pin_off, tab.data(), tbytes);
+                HIP_TRY(hipMemcpyAsync(d_tab, (uint8_t*)c->pin_buf + pin_off, tbytes, hipMemcpyHostToDevice, st));
+                p.img_tab = d_tab; p.out_len = d_stream_len;           // (written at EncImage::len_index: the caller's image number)
+                errs.push_back(p.err);
+                launch_encode_mixed(p, (uint32_t)units, (uint32_t)slabs, (uint32_t)groups, (uint32_t)sets, st, &c->timer);
+                c->last_enc_err = p.err;
+            }
+            ws_off += used;
+            pin_off += (tab.size() * sizeof(EncImage) + 255u) & ~(size_t)255u;
+        }
+        if (!pass) {
+            int rc = c->enc_ws.reserve(ws_off + 256); if (rc) return rc;
+            // (the staging of the previous call's tables may still be read by its copies: wait for the stream before it is overwritten)
+            const size_t need = (size_t)(n_images + 2) * sizeof(EncImage) + 1024u;
+            HIP_TRY(hipStreamSynchronize(st));
+            if (need > c->pin_cap) {
+                if (c->pin_buf) (void)hipHostFree(c->pin_buf);
+                c->pin_buf = nullptr; c->pin_cap = 0;
+                HIP_TRY(hipHostMalloc(&c->pin_buf, need + 4096));
+                c->pin_cap = need + 4096;
+            }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return QOIMI_OK;
+}
+
 // Synchronise `stream` and report whether the last encode on this context tripped a
 // device-side liveness bound (look-back spin limit).  Never expected; outputs of such a
 // call must be discarded.

@@ -38,7 +38,19 @@ constexpr uint32_t kEncPoolMapStride = 16;            // u64 words between two w
 constexpr uint32_t kEncTreeMaxSets = 12288;          // automatic choice of the placement: an image of more sets than this is placed order-free, not by the tree
 constexpr uint32_t kEncGenSetSlabs = 8;               // slabs per set of the generic pass when it places by look-back (flat content: few bytes per slab)
 
+// Calls of differently shaped images (qoimi_encode_images): everything the kernels take from the call's one shape otherwise, per image.
+// Such calls are placed order-free (every set parks its bytes in a slot of its own, enc_offsets + enc_compact): no set waits for another,
+// so any mix of sizes will do.
+struct EncImage {
+    size_t   pixel_off, out_off;   // image at pixels + pixel_off, stream at out + out_off
+    uint32_t npx, spi, gpi, sets;  // pixels, slabs, 64-slab groups, sets
+    uint32_t set_base, slab_base, grp_base, unit_base;   // global index of the image's first set / slab / group / (four-set) work unit
+    uint32_t width, height, colorspace, len_index;   // len_index: where the image's stream length goes in out_len (the caller's image number)
+};
+
 struct EncParams {
+    const EncImage* img_tab; // device [n_images + 1] (the last entry holds the totals in its *_base fields); nullptr: one shape (the fields below)
+    uint32_t total_slabs;    // set by the launcher: slabs of all images
     const uint8_t* pixels;   // image i at pixels + i*pixel_stride
     size_t pixel_stride;
     uint32_t npx;            // width*height
@@ -93,6 +105,7 @@ struct EncParams {
 // (exclusive scan of the sizes + compaction), or both back to back
 enum EncPhase { kEncSlabs = 1, kEncPlace = 2, kEncAll = 3 };
 void launch_encode(const EncParams& p, hipStream_t st, KernelTimer* tm, int phases = kEncAll);
+void launch_encode_mixed(const EncParams& p, uint32_t units, uint32_t slabs, uint32_t groups, uint32_t sets, hipStream_t st, KernelTimer* tm);
 int run_lds_order_selftest(hipStream_t st);
 void launch_lds_order_selftest(uint32_t* d_out, hipStream_t st);
 

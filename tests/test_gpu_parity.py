@@ -550,6 +550,67 @@ def test_decode_batch_mixed_shapes(api, ctx, oracle):
                 assert int(out[i * pstride + want.size]) == 0xCD, "wrote past the image"
 
 
+@pytest.mark.parametrize("slabs", [None, "2"])
+def test_encode_images_mixed_shapes(api, oracle, slabs):
+    """qoimi_encode_images: 60 images of 60 different shapes, 3 and 4 channels, every synthetic content class (flat ones take the
+    summary passes), odd pixel / stream offsets - ONE call, every stream byte-identical to the reference encoder's; then all of the
+    streams back through ONE qoimi_decode_batch call (4-channel output)."""
+    import torch
+    from qoi_amd import synth
+    if slabs is not None:
+        os.environ["QOIMI_ENC_SET_SLABS"] = slabs
+    try:
+        c = api.Context(0)
+        rng = np.random.default_rng(77)
+        shapes = [(1, 1), (1, 1500), (1023, 1), (1024, 1), (1025, 3), (64, 48), (3072, 1), (3073, 2), (1920, 1080), (2500, 1300), (640, 360), (37, 23)]
+        while len(shapes) < 60:
+            w, h = int(rng.integers(1, 1400)), int(rng.integers(1, 700))
+            if (w, h) not in shapes:
+                shapes.append((w, h))
+        imgs, descs, pix_off, str_off = [], [], [], []
+        po = so = 0
+        for i, (w, h) in enumerate(shapes):
+            ch = 3 if i % 3 == 1 else 4
+            kind = synth.KINDS[i % len(synth.KINDS)]
+            f = np.ascontiguousarray(synth.frame_rgba(kind, w, h, 500 + i)[:, :, :ch]).reshape(-1)
+            po += int(rng.integers(0, 7)); so += int(rng.integers(0, 7))         # no alignment is promised for either
+            imgs.append(f); descs.append(api.QoiDesc(w, h, ch, i & 1)); pix_off.append(po); str_off.append(so)
+            po += f.size; so += api.encode_bound(w, h, ch)
+        d_pix = torch.zeros(po + 64, dtype=torch.uint8, device="cuda")
+        d_str = torch.full((so + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+        d_len = torch.zeros(len(shapes), dtype=torch.int32, device="cuda")
+        for f, o in zip(imgs, pix_off):
+            d_pix[o:o + f.size].copy_(torch.from_numpy(f))
+        st = torch.cuda.current_stream().cuda_stream
+        for rep in range(2):                                                    # twice: the second call reuses the arena
+            c.encode_images(d_pix.data_ptr(), pix_off, descs, d_str.data_ptr(), str_off, d_len.data_ptr(), st)
+            c.encode_status(st)
+            lens = d_len.cpu().numpy()
+            host = d_str.cpu().numpy()
+            for i, (w, h) in enumerate(shapes):
+                want = bytearray(oracle.encode(imgs[i], w, h, descs[i].channels))
+                want[13] = descs[i].colorspace                                   # (the oracle helper encodes with colorspace 0)
+                got = host[str_off[i]:str_off[i] + int(lens[i])].tobytes()
+                assert got == bytes(want), (rep, i, shapes[i], descs[i].channels, synth.KINDS[i % len(synth.KINDS)], int(lens[i]), len(want))
+        # the streams back, all shapes in one decode call
+        sstride = max(int(x) for x in lens) + 64
+        pstride = max(w * h for w, h in shapes) * 4 + 16
+        buf = torch.zeros(len(shapes) * sstride, dtype=torch.uint8, device="cuda")
+        for i in range(len(shapes)):
+            buf[i * sstride:i * sstride + int(lens[i])].copy_(d_str[str_off[i]:str_off[i] + int(lens[i])])
+        out = torch.full((len(shapes) * pstride,), 0xAB, dtype=torch.uint8, device="cuda")
+        c.decode_batch(buf.data_ptr(), sstride, [int(x) for x in lens], descs, 4, out.data_ptr(), pstride, st)
+        ho = out.cpu().numpy()
+        for i, (w, h) in enumerate(shapes):
+            px = imgs[i].reshape(-1, descs[i].channels)
+            want = np.concatenate([px, np.full((w * h, 1), 255, dtype=np.uint8)], axis=1) if descs[i].channels == 3 else px
+            assert np.array_equal(ho[i * pstride:i * pstride + w * h * 4], want.reshape(-1)), (i, shapes[i])
+        c.close()
+    finally:
+        if slabs is not None:
+            del os.environ["QOIMI_ENC_SET_SLABS"]
+
+
 def test_decode_streams_gigabytes_apart(api, ctx, oracle):
     """Small streams 2.5 GiB apart in one batch: the lanes of ONE transcoder wavefront then hold streams that its 32-bit buffer
     descriptor does not reach (4 GiB from the wavefront's first stream) - those segments go the way of the unsynchronised ones
