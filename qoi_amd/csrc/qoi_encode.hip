@@ -855,6 +855,113 @@ __device__ __forceinline__ void pool_give(const EncParams& p, uint32_t id, uint3
         (void)__hip_atomic_fetch_and((gu64*)&p.pool_map[(size_t)(id >> 6) * kEncPoolMapStride], ~(1ull << (id & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ENTRY 2 (round 5): the entry state of a set of a FLAGGED image (flat content: the look-back window of ENTRY 1 does not determine
+// the colour table) by decoupled look-back over the SETS of the image - no summary pass over the pixels, no scans, one launch:
+//   * the set first walks its own pixels for "the last edge pixel per hash slot" and its last edge (what enc_slab_summary computed
+//     for every slab in a pass of its own: every pixel read from HBM twice) and publishes that as 65 eight-byte granules
+//     (slot k: word | valid << 32, granule 64: last edge + 1), state LOCAL;
+//   * then it looks back over the sets in front of it, four at a time: a slot takes the nearest valid LOCAL word, or whatever an
+//     INCLUSIVE granule says (the table as it stands behind that set); the last edge likewise.  Every granule carries its state and
+//     the call's epoch ("the data is the flag", qoi_dev.h): nothing to zero between calls, no fences, a reader may see a set's
+//     granules half LOCAL, half INCLUSIVE - each slot resolves on its own;
+//   * it publishes its own INCLUSIVE granules and encodes - the second walk over its pixels finds them in the L2 / Infinity Cache.
+// Sets are handed out in start order (tickets) or by workgroup index (tree calls) exactly as the placement look-back wants them.
+constexpr u64 kG2Local = 1ull << 62, kG2Incl = 2ull << 62;
+__device__ __forceinline__ u64 g2_tag(const EncParams& p) { return (u64)(p.epoch & 0x1FFFFFFFu) << 33; }
+__device__ __forceinline__ bool g2_ready(const EncParams& p, u64 g) { return ((g >> 33) & 0x1FFFFFFFull) == (u64)(p.epoch & 0x1FFFFFFFu) && (g >> 62) != 0ull; }
+
+template <int CH, class LDS>
+__device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t* __restrict__ pix, uint32_t n, uint32_t lo, uint32_t hi,
+                                               u64* __restrict__ rec_img, uint32_t set, uint32_t lane, LDS& L, uint32_t tbase, int& last_edge) {
+    // ---- own summary: last edge pixel per slot, last edge -------------------------------------------------------------
+    const uint32_t sent = lane + 1u;                           // cannot hash to its own slot (warm_entry_state)
+    L.table[lane] = sent;
+    __builtin_amdgcn_wave_barrier();
+    int le_loc = -1;
+    const uint32_t ngroups = (hi - lo + kGroupPx - 1u) / kGroupPx;
+    uint32_t cx[kGroupSteps], cv[kGroupSteps], nx[kGroupSteps], nv[kGroupSteps];
+    auto fetch = [&](uint32_t g, uint32_t (&x)[kGroupSteps], uint32_t (&v)[kGroupSteps]) {
+        const uint32_t base = lo + g * kGroupPx;
+#pragma unroll
+        for (int t = 0; t < kGroupSteps; ++t) load_pair_guarded<CH>(pix, base + (uint32_t)t * 64u + lane, hi, x[t], v[t]);
+    };
+    auto walk = [&](uint32_t g, const uint32_t (&x)[kGroupSteps], const uint32_t (&v)[kGroupSteps]) {
+        const uint32_t base = lo + g * kGroupPx;
+#pragma unroll
+        for (int t = 0; t < kGroupSteps; ++t) {
+            const bool inb = base + (uint32_t)t * 64u + lane < hi;
+            const u64 E = __ballot(inb && x[t] != v[t]);
+            if (E) {
+                le_loc = (int)(base + (uint32_t)t * 64u) + msb64(E);
+                (void)probe_swap(tbase | slot_byte_offset(x[t]), x[t], E);        // lanes in ascending order: the later pixel stays (PROBE 1)
+            }
+        }
+    };
+    fetch(0u, cx, cv);
+    for (uint32_t g = 0; g < ngroups; g += 2u) {
+        if (g + 1u < ngroups) fetch(g + 1u, nx, nv);
+        walk(g, cx, cv);
+        if (g + 1u >= ngroups) break;
+        if (g + 2u < ngroups) fetch(g + 2u, cx, cv);
+        walk(g + 1u, nx, nv);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t loc_w = L.table[lane];
+    const bool loc_valid = loc_w != sent;
+    u64* const mine = rec_img + (size_t)set * 65u;
+    const u64 tag = g2_tag(p);
+    granule_store(&mine[lane], (u64)(loc_valid ? loc_w : 0u) | ((u64)(loc_valid ? 1u : 0u) << 32) | tag | kG2Local);
+    if (lane == 0) granule_store(&mine[64], (u64)(uint32_t)(le_loc + 1) | tag | kG2Local);
+    // ---- the sets in front: nearest valid word per slot, nearest edge --------------------------------------------------
+    uint32_t ent_w = 0u; bool ent_valid = false, slot_done = loc_valid;      // (a slot this set wrote needs no entry word for the inclusive table - but the ENCODE does: see below)
+    int le_ent = -1; bool le_done = false;
+    // the encoder needs the entry word of EVERY slot (an edge pixel is compared with what its slot held BEFORE the set), so all 64 are looked up
+    slot_done = false;
+    uint32_t spins = 0;
+    for (int j0 = (int)set - 1; j0 >= 0 && (lanes_where(!slot_done) != 0ull || !le_done); j0 -= 4) {
+        for (;;) {
+            u64 gw[4], gl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 - k;
+                gw[k] = j >= 0 ? granule_load(&rec_img[(size_t)j * 65u + lane]) : (tag | kG2Incl);       // in front of set 0: the zeroed table, no edge (qoi.h:393)
+                gl[k] = j >= 0 ? granule_load(&rec_img[(size_t)j * 65u + 64u]) : (tag | kG2Incl);
+            }
+            bool all = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) all = all && g2_ready(p, gw[k]) && g2_ready(p, gl[k]);
+            if (lanes_where(!all) == 0ull) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool incl = (gw[k] >> 62) == 2ull, v = ((gw[k] >> 32) & 1ull) != 0ull;
+                    if (!slot_done && (incl || v)) { ent_w = v ? (uint32_t)gw[k] : 0u; ent_valid = v; slot_done = true; }
+                    const bool incl_l = (gl[k] >> 62) == 2ull; const int lv = (int)(uint32_t)gl[k] - 1;
+                    if (!le_done && (incl_l || lv >= 0)) { le_ent = lv; le_done = true; }
+                }
+                break;
+            }
+            if (++spins > p.spin_bound || ((spins & 63u) == 63u && __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (lane == 0) atomicOr(p.err, 1u);
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    le_ent = __builtin_amdgcn_readfirstlane(le_ent);
+    // ---- the table as it stands behind this set, for the sets that follow ----------------------------------------------
+    {
+        const bool v = loc_valid || ent_valid;
+        const int le_inc = le_loc >= 0 ? le_loc : le_ent;
+        granule_store(&mine[lane], (u64)(loc_valid ? loc_w : (ent_valid ? ent_w : 0u)) | ((u64)(v ? 1u : 0u) << 32) | tag | kG2Incl);
+        if (lane == 0) granule_store(&mine[64], (u64)(uint32_t)(le_inc + 1) | tag | kG2Incl);
+    }
+    __builtin_amdgcn_wave_barrier();
+    L.table[lane] = ent_valid ? ent_w : 0u;                   // untouched slots are the zeroes of qoi.h:393
+    last_edge = le_ent;
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
 template <int CH, int PROBE, int ENTRY, bool MIXED, class LDS>
 __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, LDS& L) {
     const EncImage I = enc_image<MIXED>(p, img);
@@ -882,7 +989,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 #pragma unroll
             for (int k = 0; k < 8; ++k) load_pair_at<CH>(q, -64 * (k + 1), in.warm[k], in.warm_prev[k]);
         }
-    } else {
+    } else if (ENTRY == 0) {
         const uint32_t s = set * p.set_slabs;                  // first slab of the set: its entry state is the set's
         const size_t g = (size_t)I.slab_base + s;
         const size_t G = (size_t)I.grp_base + (s >> 6);
@@ -897,7 +1004,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     const bool gen_set = lo == 0u;
     uint32_t nint = gen_set ? 0u : (last_set ? ngroups - 1u : ngroups);
     uint32_t ax[kGroupSteps], av[kGroupSteps], bx[kGroupSteps], bv[kGroupSteps];
-    if (nint) load_group<CH>(pix, lo, lane, ax, av);
+    if (ENTRY != 2 && nint) load_group<CH>(pix, lo, lane, ax, av);
 
     // ---- entry state: colour table + distance to the last edge ---------------------------
     LaneConst C;
@@ -906,12 +1013,17 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     C.lane_run = lane + 128u;
     C.tbase = lds_addr(L.table);                               // 256-byte aligned
     asm volatile("" : "+v"(C.tbase));                          // keep in a VGPR
-    int last_edge;
+    int last_edge = -1;
     if (ENTRY == 1) {
         if (!warm_entry_state<CH, PROBE>(pix, lo, lane, L, C.tbase, in, last_edge)) {
             if (lane == 0) { atomicOr(&p.need_generic[img], 1u); atomicOr(p.any_generic, 1u); }
             return;
         }
+    } else if (ENTRY == 2) {
+        if (PROBE == 1) {
+            if (!g2_entry_state<CH>(p, pix, n, lo, hi, p.g2_rec + (size_t)I.set_base * 65u, set, lane, L, C.tbase, last_edge)) return;
+        }
+        if (nint) load_group<CH>(pix, lo, lane, ax, av);       // (from the L2 / Infinity Cache: the set's own walk has just read them)
     } else {
         const u64 lv = uniform64(in.tab_valid);
         L.table[lane] = ((lv >> lane) & 1ull) ? in.tab_loc : in.tab_far;
@@ -1358,6 +1470,19 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         p.only_flagged = 0;
         small = 0xFFFFFFFFu;
     }
+    const bool first_lookback = p.lookback != 0;
+    if constexpr (!MIXED && PROBE == 1) if (warm && first_lookback && p.g2_rec != nullptr) {
+        // The images the first pass gave up on (flat content), by state look-back over their sets (ENTRY 2, g2_entry_state): one launch
+        // that returns at once when nothing was flagged - no summary pass, no scans.
+        EncParams g = p;
+        g.status = p.status_gen; g.ticket = p.ticket_gen; g.tree1 = p.tree1_gen; g.tree2 = p.tree2_gen;
+        g.set_slabs = kEncGenSetSlabs; g.set_px = kEncGenSetSlabs * kEncSlabPx;
+        g.sets_per_image = (p.spi + kEncGenSetSlabs - 1u) / kEncGenSetSlabs;
+        g.n_units = ((g.sets_per_image + 3u) / 4u) * p.n_images;
+        hipLaunchKernelGGL((enc_sets<CH, PROBE, 2, MIXED>), dim3(g.n_units < small || g.lookback == 2 ? g.n_units : small), dim3(256), 0, st, g);
+        tm->mark(kT_enc_slabs_generic, st);
+        return;
+    }
     hipLaunchKernelGGL((enc_slab_summary<CH, kEncSteps, MIXED>), dim3(slab_blocks < small ? slab_blocks : small), dim3(256), 0, st, p);
     tm->mark(kT_enc_summary, st);
     hipLaunchKernelGGL(enc_scan_groups<MIXED>, dim3(total_groups), dim3(64), 0, st, p);
@@ -1365,7 +1490,6 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     hipLaunchKernelGGL(enc_scan_images<MIXED>, dim3(p.n_images), dim3(64), 0, st, p);
     tm->mark(kT_enc_scan_images, st);
     // The images the first pass gave up on (flat content) are encoded again from their first set ...
-    const bool first_lookback = p.lookback != 0;
     EncParams g = p;
     if (warm && first_lookback) {
         // ... by look-back as well, with records / tickets of their own (the first pass left some behind for these images) and

@@ -60,12 +60,13 @@ extern "C" const char* qoimi_version(void) { return "qoi_mi355x 0.1 gfx950"; }
 struct Arena {
     void* base = nullptr;
     size_t cap = 0;
+    unsigned gen = 0;              // allocations so far (what a caller that remembers "I zeroed this part" compares)
     int reserve(size_t bytes) {
         if (bytes <= cap) return QOIMI_OK;
         if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
         size_t want = bytes + bytes / 4 + (1u << 20);
         HIP_TRY(hipMalloc(&base, want));
-        cap = want;
+        cap = want; ++gen;
         return QOIMI_OK;
     }
     void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
@@ -104,6 +105,9 @@ struct qoimi_ctx {
     int enc_tree_ticket = 0;            // env QOIMI_ENC_TREE_TICKET=1: tree placement hands its units out by one ticket per workgroup (start order) instead of by workgroup index
     uint32_t test_spin_bound = 0;       // env QOIMI_TEST_SPIN_BOUND (tests): polls before a placement wait gives up
     bool worst_case_buffer = false;     // env QOIMI_ENCODE_WORST_CASE_BUFFER=1 (read once, at creation): qoi_encode returns the reference's worst-case allocation
+    int enc_g2 = 1;                     // env QOIMI_ENC_G2=0: flagged images (flat content) go through the summary passes instead of the state look-back (ENTRY 2)
+    uint32_t enc_epoch = 0;             // encode call number: the tag of the state look-back's granules
+    void* g2_zeroed_at = nullptr; size_t g2_zeroed_bytes = 0; unsigned g2_zeroed_gen = 0;     // where those granules were last zeroed
     int enc_adapt = 1;                  // env QOIMI_ENC_ADAPT=0: the set size ignores what the previous call's streams looked like
     uint32_t enc_hint_npx = 0;          // pixels per image of the batch call whose first stream length stands in host_word[12] (0: none)
     struct { const void* px; size_t ps; qoi_desc desc; int n; void* out; size_t os; int* len; void* st; bool valid = false; } last_enc;   // the last qoimi_encode_batch (qoimi_encode_status re-encodes it order-free if a wait gave up)
@@ -178,6 +182,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_SPREAD")) c->enc_spread = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_TREE_TICKET")) c->enc_tree_ticket = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_ADAPT")) c->enc_adapt = atoi(e) != 0;
+    if (const char* e = getenv("QOIMI_ENC_G2")) c->enc_g2 = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_TEST_SPIN_BOUND")) { const long v = atol(e); if (v >= 1) c->test_spin_bound = (uint32_t)v; }
     if (const char* e = getenv("QOIMI_ENCODE_WORST_CASE_BUFFER")) c->worst_case_buffer = atoi(e) != 0;
     c->host_word[12] = 0u;
@@ -392,6 +397,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         p.set_stride = r_max * kEncSlabWorst + 16u;
     }
 
+    size_t g2_bytes = 0;
     for (int pass = 0; pass < 2; ++pass) {      // pass 0 measures, pass 1 carves
         Carver w(pass ? c->enc_ws.base : nullptr);
         p.status = w.take<u64>(S); p.ticket = w.take<uint32_t>((size_t)n_images); p.err = w.take<uint32_t>(1);
@@ -406,14 +412,33 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         }
         p.pool_map = w.take<u64>(lookback ? (size_t)(p.pool_slots / 64u) * kEncPoolMapStride : 0);
         const size_t zero_bytes = w.off;
-        p.sum_tab = w.take<uint32_t>(T * 64); p.sum_valid = w.take<u64>(T); p.sum_le = w.take<int>(T);
-        p.ent_tab = w.take<uint32_t>(T * 64); p.ent_valid = w.take<u64>(T); p.ent_le = w.take<int>(T);
-        p.grp_tab = w.take<uint32_t>(G * 64); p.grp_valid = w.take<u64>(G); p.grp_le = w.take<int>(G);
-        p.gent_tab = w.take<uint32_t>(G * 64); p.gent_le = w.take<int>(G);
+        // flagged images (flat content): by state look-back over their sets (ENTRY 2: 520 bytes per set of eight slabs, tagged with the
+        // call's number instead of being zeroed) - or, for order-free calls and the order-independent probe, by the summary passes
+        // (per slab 2 x (256 B table + 8 B valid + 4 B position): 4.3 GB for the 1024-frame 4K shard)
+        const bool g2 = lookback && p.probe_xchg && p.warm && c->enc_g2;
+        p.g2_rec = w.take<u64>(g2 ? S_gen * 65u : 0);
+        g2_bytes = g2 ? S_gen * 65u * sizeof(u64) : 0;
+        if (!g2) p.g2_rec = nullptr;
+        const size_t Tt = g2 ? 0 : T, Gt = g2 ? 0 : G;
+        p.sum_tab = w.take<uint32_t>(Tt * 64); p.sum_valid = w.take<u64>(Tt); p.sum_le = w.take<int>(Tt);
+        p.ent_tab = w.take<uint32_t>(Tt * 64); p.ent_valid = w.take<u64>(Tt); p.ent_le = w.take<int>(Tt);
+        p.grp_tab = w.take<uint32_t>(Gt * 64); p.grp_valid = w.take<u64>(Gt); p.grp_le = w.take<int>(Gt);
+        p.gent_tab = w.take<uint32_t>(Gt * 64); p.gent_le = w.take<int>(Gt);
         p.set_size = w.take<uint32_t>(lookback ? 0 : S); p.set_off = w.take<uint32_t>(lookback ? 0 : S);
         p.scratch = w.take<uint8_t>(lookback ? ((size_t)p.pool_slots + 1u) * p.set_stride : S * p.set_stride);
         if (!pass) { int rc = c->enc_ws.reserve(w.off + 256); if (rc) return rc; }
-        else HIP_TRY(hipMemsetAsync(c->enc_ws.base, 0, zero_bytes, st));   // look-back records, tickets, flags, pool map
+        else {
+            HIP_TRY(hipMemsetAsync(c->enc_ws.base, 0, zero_bytes, st));   // look-back records, tickets, flags, pool map
+            // the state look-back's granules are told apart by the call's number; zeroed only when they come to lie somewhere new
+            // (another arena, another shape of call) or the number wraps
+            c->enc_epoch = (c->enc_epoch + 1u) & 0x1FFFFFFFu;
+            if (g2_bytes && (c->g2_zeroed_at != (void*)p.g2_rec || c->g2_zeroed_bytes != g2_bytes || c->g2_zeroed_gen != c->enc_ws.gen || c->enc_epoch == 0u)) {
+                HIP_TRY(hipMemsetAsync(p.g2_rec, 0, g2_bytes, st));
+                c->g2_zeroed_at = (void*)p.g2_rec; c->g2_zeroed_bytes = g2_bytes; c->g2_zeroed_gen = c->enc_ws.gen;
+                if (c->enc_epoch == 0u) c->enc_epoch = 1u;
+            }
+            p.epoch = c->enc_epoch;
+        }
     }
     p.out = (uint8_t*)d_streams; p.out_stride = stream_stride; p.out_len = d_stream_len;
     c->last_enc_err = p.err;

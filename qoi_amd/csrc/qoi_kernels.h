@@ -95,6 +95,9 @@ struct EncParams {
     u64* status_gen;     // [n_images * ceil(spi / kEncGenSetSlabs)]                                     -- zeroed before every launch
     uint32_t* ticket_gen;    // [n_images]                                                             -- zeroed before every launch
     u64* tree1_gen; u64* tree2_gen;   // lookback == 2: the generic pass's group / block totals                -- zeroed before every launch
+    u64* g2_rec;         // ENTRY 2 (flagged images by state look-back over their sets): [n_images * ceil(spi / kEncGenSetSlabs)][65] granules tagged
+                         // with `epoch` - never zeroed between calls; nullptr: the summary passes (enc_slab_summary + scans + ENTRY 0)
+    uint32_t epoch;      // the context's encode call number (29 bits are compared)
     uint32_t* set_size;  // [n_images*sets_per_image]  order-free mode
     uint32_t* set_off;   // [n_images*sets_per_image]  order-free mode
     // output

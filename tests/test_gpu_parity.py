@@ -479,6 +479,13 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_LOOKBACK": "1"},  # the four wavefronts of a workgroup take their tickets from ONE image (the default: from consecutive images)
     {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "1"},
     {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_PERSIST": "3", "QOIMI_ENC_LOOKBACK": "1"},  # ... in the grid-stride loop
+    {"QOIMI_ENC_G2": "0"},                                # flagged (flat) images through the summary passes (enc_slab_summary + scans + ENTRY 0) instead of the state look-back
+    {"QOIMI_ENC_G2": "0", "QOIMI_ENC_LOOKBACK": "1"},
+    {"QOIMI_ENC_LOOKBACK": "1"},                          # look-back placement (forced for four images): flat images by state look-back with tickets
+    {"QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "1"},
+    {"QOIMI_ENC_TREE_TICKET": "1"},                       # tree placement with its units by one ticket per workgroup
+    {"QOIMI_DEC_RUN_DESC": "0"},                          # every long run written lane by lane
+    {"QOIMI_DEC_RUN_DESC": "1"},                          # run descriptors for flat images only
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
@@ -712,7 +719,8 @@ def test_decode_repair_loop_is_bounded(api, oracle, rounds):
 
 @pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_WARM": "0"}, {"QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_SET_SLABS": "4"},
                                  {"QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_LOOKBACK": "2"}, {"QOIMI_ENC_LOOKBACK": "1"},
-                                 {"QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "4"}])
+                                 {"QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "4"}, {"QOIMI_ENC_G2": "0"}, {"QOIMI_ENC_G2": "0", "QOIMI_ENC_LOOKBACK": "2"},
+                                 {"QOIMI_ENC_TREE_TICKET": "1", "QOIMI_ENC_LOOKBACK": "2"}])
 def test_flat_frames_byte_identical(api, oracle, env):
     """Flat UI frames go through the generic entry-state path (per-slab summaries + scans).  Frame 60 of this sweep was
     encoded three bytes too long by every path until round 2: a 64-bit lane mask lost its upper half (sign extension of
