@@ -408,6 +408,7 @@ def main() -> None:
     prof = ctx.get_profile(stream)
     ctx.set_profiling(False)
     ctx.encode_status(stream)
+    ws_main = ctx.workspace_bytes()                 # what the headline batch needed (the side legs below may grow the arenas further)
     launches = args.steps * passes
 
     # bit-exact round trip (qoibench.c:408-417) on the whole batch, and four of its streams against the reference codec
@@ -683,6 +684,9 @@ def main() -> None:
         ws = ctx.workspace_bytes()
         free_b, total_b = torch.cuda.mem_get_info(dev)
         out["device_memory"] = {"encode_workspace_bytes": ws["encode"], "decode_workspace_bytes": ws["decode"], "dropin_staging_bytes": ws["staging"],
+                                "headline_batch": {"encode_workspace_bytes": ws_main["encode"], "decode_workspace_bytes": ws_main["decode"], "stream_bytes": int(stream_bytes),
+                                                   "decode_workspace_over_stream_bytes": round(ws_main["decode"] / max(1.0, stream_bytes), 3) if not args.encode_only else None,
+                                                   "note": "decode: 4 bytes of chunk records per stream byte reserved (one record per byte is the worst case) + ~0.27 of per-segment state"},
                                 "bench_buffers_bytes": int(pixels.numel() + streams.numel() + decoded.numel()),
                                 "peak_device_bytes": int(total_b - free_b), "device_total_bytes": int(total_b),
                                 "note": "peak_device_bytes = device total - free at the end of the run (all processes on the device; the library's arenas and torch's caching allocator only grow)"}

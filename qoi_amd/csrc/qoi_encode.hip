@@ -358,6 +358,16 @@ __device__ __forceinline__ uint32_t probe_swap_all(uint32_t addr, uint32_t px) {
     asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2" : "=&v"(seen) : "v"(addr), "v"(px) : "memory");
     return seen;
 }
+// The same for callers that do not look at what comes back (the entry-state replays): every exchange returns into the SAME register,
+// which stays live from the first exchange to probe_wait() behind the last.  (With the result thrown away the compiler is free to
+// hand its register to something else right behind the asm block - it does not know that the instruction writes it LATER, when the
+// LDS answers - and whatever then lives there is overwritten: round 5's first state look-back lost half of an address that way.)
+__device__ __forceinline__ void probe_swap_into(uint32_t& chain, uint32_t addr, uint32_t px, u64 edges) {
+    asm volatile("s_mov_b64 exec, %3\n\t"
+                 "ds_wrxchg_rtn_b32 %0, %1, %2\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(chain) : "v"(addr), "v"(px), "s"(edges) : "memory");
+}
 __device__ __forceinline__ void probe_wait(uint32_t& seen) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(seen) : : "memory"); }
 
 // w = (seen == px ? idx : we) in the lanes of `edges`, unchanged elsewhere.  Waits for the probe's LDS result first.
@@ -698,6 +708,7 @@ __device__ __forceinline__ bool warm_entry_state(const uint8_t* __restrict__ pix
     last_edge = -1;
     if (lo == 0u) { L.table[lane] = 0u; return true; }       // qoi.h:393: zeroed table, no edge yet
     const uint32_t sent = lane + 1u;
+    uint32_t chain = 0u;                                      // what the exchanges return (probe_swap_into)
     L.table[lane] = sent;
     __builtin_amdgcn_wave_barrier();
     // ---- the 512 pixels right before the set, oldest first: later edge pixels simply overwrite earlier ones
@@ -710,9 +721,10 @@ __device__ __forceinline__ bool warm_entry_state(const uint8_t* __restrict__ pix
         const u64 E = __ballot(px != pvw);
         if (E) {
             last_edge = base + msb64(E);
-            (void)probe_swap((__builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false) & 0xFCu) | tbase, px, E);
+            probe_swap_into(chain, (__builtin_amdgcn_udot4(px, 0x2C1C140Cu, 0u, false) & 0xFCu) | tbase, px, E);
         }
     }
+    probe_wait(chain);
     __builtin_amdgcn_wave_barrier();
     u64 filled = __ballot(L.table[lane] != sent);
     bool full = filled == ~0ull, at_start = (int)lo - 64 * kWarmBatch <= 0;
@@ -740,7 +752,7 @@ __device__ __forceinline__ bool warm_entry_state(const uint8_t* __restrict__ pix
             const uint32_t so = slot_byte_offset(px);
             const uint32_t cur = *(const lds_u32*)(tbase | so);
             const u64 want = __ballot(edge && cur == (so >> 2) + 1u);
-            if (want) (void)probe_swap(tbase | so, px, want);            // same slot twice in a step: the later pixel wins
+            if (want) { probe_swap_into(chain, tbase | so, px, want); probe_wait(chain); }      // same slot twice in a step: the later pixel wins
             __builtin_amdgcn_wave_barrier();
             filled = __ballot(L.table[lane] != sent);
             full = filled == ~0ull;
@@ -885,15 +897,17 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
 #pragma unroll
         for (int t = 0; t < kGroupSteps; ++t) load_pair_guarded<CH>(pix, base + (uint32_t)t * 64u + lane, hi, x[t], v[t]);
     };
+    uint32_t chain = 0u;
     auto walk = [&](uint32_t g, const uint32_t (&x)[kGroupSteps], const uint32_t (&v)[kGroupSteps]) {
         const uint32_t base = lo + g * kGroupPx;
+        // (what the exchanges return is of no interest - but see probe_swap_into)
 #pragma unroll
         for (int t = 0; t < kGroupSteps; ++t) {
             const bool inb = base + (uint32_t)t * 64u + lane < hi;
             const u64 E = __ballot(inb && x[t] != v[t]);
             if (E) {
                 le_loc = (int)(base + (uint32_t)t * 64u) + msb64(E);
-                (void)probe_swap(tbase | slot_byte_offset(x[t]), x[t], E);        // lanes in ascending order: the later pixel stays (PROBE 1)
+                probe_swap_into(chain, tbase | slot_byte_offset(x[t]), x[t], E);  // lanes in ascending order: the later pixel stays (PROBE 1)
             }
         }
     };
@@ -905,6 +919,7 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
         if (g + 2u < ngroups) fetch(g + 2u, cx, cv);
         walk(g + 1u, nx, nv);
     }
+    probe_wait(chain);
     __builtin_amdgcn_wave_barrier();
     const uint32_t loc_w = L.table[lane];
     const bool loc_valid = loc_w != sent;

@@ -64,7 +64,10 @@ struct Arena {
     int reserve(size_t bytes) {
         if (bytes <= cap) return QOIMI_OK;
         if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 4 + (1u << 20);
+        // (a quarter more than asked for, so that calls of slowly growing batches do not reallocate every time - but no more than 256 MiB:
+        // the decode arena of the 1024-frame 4K shard is 45 GB, its margin was another 11)
+        const size_t slack = bytes / 4 < ((size_t)256 << 20) ? bytes / 4 : ((size_t)256 << 20);
+        size_t want = bytes + slack + (1u << 20);
         HIP_TRY(hipMalloc(&base, want));
         cap = want; ++gen;
         return QOIMI_OK;
