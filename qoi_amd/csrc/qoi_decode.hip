@@ -1847,20 +1847,23 @@ struct BurstWriter : LaneWriter<OCH, RING_, GROUP_> {
 // P4 on records: genuine decode of every active segment + exit-state check (lane = segment), see dec_segments.
 // 16 KiB of colour tables + the 4 KiB pixel ring = 20 KiB: eight wavefronts per CU.
 // FLAT (round 5): the segments of "flat" images (dec_image_is_flat: UI frames, constant frames - their stream is a fraction of a
-// byte per pixel, nearly all of it QOI_OP_RUN) run as a second launch of this kernel that does NOT write their long runs: P4 wrote a
+// byte per pixel, nearly all of it QOI_OP_RUN) run as a second launch of this kernel that writes almost no pixels itself: P4 wrote a
 // run lane by lane in 16-byte pieces, 64 lanes 0.3-30 KB apart (34 GB in 19 ms on 1024 UI frames, a third of what the memory system
-// gives coalesced writes).  Consecutive records that leave the pixel as it is - QOI_OP_RUN after QOI_OP_RUN: a run is cut every 62
-// pixels, qoi.h:417 - are merged into ONE run; its head (up to a 4-pixel boundary) and tail go through the ring as before, the
-// aligned middle becomes a 16-byte run descriptor (start pixel, length, pixel) in the segment's descriptor region, and dec_expand_runs
-// writes all descriptors of the launch afterwards with whole wavefronts, 1 KiB per store instruction.  Segments that left
-// descriptors queue up (run_queue) for it.
+// gives coalesced writes).  Here a lane keeps a SPAN - the pixels since its pixel value last changed: a chunk that names a pixel and
+// every QOI_OP_RUN behind it (a run is cut every 62 pixels, qoi.h:417; the UI tile's first pixel and the 95 repeats behind it are one
+// span).  A span that ends with eight pixels or more becomes a 16-byte descriptor (first pixel, pixels, value) in the segment's
+// descriptor region and dec_expand_runs writes all descriptors of the launch afterwards with whole wavefronts, 1 KiB per store
+// instruction; shorter ones (a flat image holds few: an eighth of its pixels at most are chunks) are stored by the lane.  No pixel ring.
+// Segments that left descriptors queue up (run_queue) for the expander.
+// (First form of the round: only the 4-pixel aligned middle of a run of twelve or more as a descriptor, head and tail through the
+// ring, the ring written out in front of every run - six scattered stores of 4-16 bytes per UI tile row: 8 ms per 1024 frames.)
 template <int OCH, bool FLAT>
 __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
 #ifndef QOIMI_SEGREC_GROUP
 #define QOIMI_SEGREC_GROUP 16
 #endif
     typedef BurstWriter<OCH, 2 * QOIMI_SEGREC_GROUP, QOIMI_SEGREC_GROUP> Writer;
-    constexpr uint32_t kTabDw = 64u * 64u, kOutDw = Writer::kRing * 64u;
+    constexpr uint32_t kTabDw = 64u * 64u, kOutDw = FLAT ? 64u : Writer::kRing * 64u;        // (FLAT: no pixel ring)
     constexpr uint32_t kDrainEvery = Writer::kGroup / 2u;      // steps between drains: they add <= 2 pixels each to what a drain leaves (< one group)
 #ifndef QOIMI_SEGREC_PAD_DW
 #define QOIMI_SEGREC_PAD_DW 0
@@ -1883,7 +1886,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     // (the other images, desc_all: a QOI_OP_RUN of twelve pixels or more leaves a descriptor too - one per chunk, nothing pending between
     // steps - in the segment's slot of the symbolic summaries, which are dead once the entry states stand: kSummaryDescs of them)
     uint4* const my_desc = FLAT ? p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap : reinterpret_cast<uint4*>(p.summary + (size_t)(have ? q : 0u) * 65u);
-    uint32_t n_desc = 0u, run_start = 0u, run_len = 0u;       // run_len != 0: a run is pending - W.ppos is behind it, the ring is empty
+    uint32_t n_desc = 0u, span_start = px_first, span_len = 0u;     // FLAT: the pixels since the value last changed: [span_start, span_start + span_len), all of them px
     RecSource S; S.init(p, blockIdx.x, lane, have && px_first < limit ? p.rec_gran[q] : 0u);
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);
 #ifndef QOIMI_P4_DEPTH
@@ -1917,17 +1920,12 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     constexpr uint32_t kLongRun = 12;
     // only a wavefront that holds a segment which may reach the image's pixel limit pays for the clipping (see dec_segments)
     const bool clip_lane = have && (j + 1u >= im.n_active || p.px_off[q + 1u] >= limit);
-    // ends the lane's pending run: the 4-pixel aligned part [run_start, run_start + aligned) becomes a descriptor, the rest goes
-    // through the ring (W.ppos already stands behind the whole run; px still is the run's pixel)
-    auto flush_run = [&]() {
-        const uint32_t aligned = run_len & ~3u, tail = run_len & 3u;
-        const uint32_t end = W.ppos;
-        if (aligned != 0u && n_desc < p.desc_cap) { my_desc[n_desc] = make_uint4(run_start, aligned, px, 0u); ++n_desc; }
-        else for (uint32_t i = run_start; i < run_start + aligned; i += 4u) W.store4(i, px, px, px, px);     // (no room: never - at most every second record ends a run)
-        W.ppos = W.fpos = run_start + aligned;
-        for (uint32_t k = 0; k < tail; ++k) W.put(px);
-        W.ppos = end; run_len = 0u;
-        (void)end;
+    // FLAT: the lane's span ends (its pixels have the value v): a descriptor for the expander, or - a few pixels - stored here
+    constexpr uint32_t kMinSpan = 8;
+    auto close_span = [&](uint32_t v) {
+        if (span_len >= kMinSpan && n_desc < p.desc_cap) { my_desc[n_desc] = make_uint4(span_start, span_len, v, 0u); ++n_desc; }
+        else for (uint32_t i = 0; i < span_len; ++i) W.store_one(span_start + i, v);       // (no room: never - a span of eight takes two records at least)
+        span_len = 0u;
     };
     auto run = [&](auto clip_tag) {
         constexpr bool CLIP = decltype(clip_tag)::value;
@@ -1937,7 +1935,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
         auto block = [&](auto dtag, const uint32_t blk) {
             constexpr uint32_t d = decltype(dtag)::value;
             const u32x4 c0 = ring[2u * d], c1 = ring[2u * d + 1u];      // the loads issued kDepth - 1 blocks (of eight steps) ago
-            W.drain_block();                                    // a static number of stores (BurstWriter)
+            if (!FLAT) W.drain_block();                         // a static number of stores (BurstWriter)
             const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
             // Which steps of the block have a QOI_OP_RGB / QOI_OP_RGBA record, and which a run of three pixels or more, in some lane:
             // sixteen compares up front, SCALAR tests at the steps.  (A branch on a vector compare made in the step holds the
@@ -1968,25 +1966,10 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
             }
 #pragma unroll
             for (uint32_t u = 0; u < 8u; ++u) {
-                if (kDrainEvery < 8u && u == 4u) W.drain_block();
+                if (!FLAT && kDrainEvery < 8u && u == 4u) W.drain_block();
                 const uint32_t rec = rc[u];
                 uint32_t rem = (rec >> 24) & 63u;                                 // 0: null record
-                if (FLAT) {
-                    // a pending run: a record that leaves the pixel as it is (QOI_OP_RUN, a null record) adds its pixels to it and is
-                    // through - its table store would put the pixel where it already stands (qoi_decode_core.h: the null record) -
-                    // any other record ends it: descriptor out, tail (< 4 pixels) into the ring, then the record as usual
-                    const bool pending = run_len != 0u;
-                    if (lanes_where(pending) != 0ull) {
-                        const bool pure = (rec & 0xC0FFFFFFu) == 0u;
-                        if (lanes_where(pending && !pure) != 0ull) { if (pending && !pure) flush_run(); }
-                        if (pending && pure) {
-                            uint32_t add = rem;
-                            if (CLIP) add = min(add, limit - W.ppos);     // over-long run clipped (Appendix B item 8)
-                            run_len += add; W.ppos += add; W.fpos = W.ppos;
-                            rem = 0u;
-                        }
-                    }
-                }
+                const uint32_t px_before = px;
                 // two complete bodies (see dec_summarize_rec: a step costs its instruction count): the common one knows nothing of
                 // QOI_OP_RGB / QOI_OP_RGBA
                 if (__builtin_expect(hm[u] != 0ull, 0)) {                        // QOI_OP_RGB keeps the alpha; QOI_OP_RGBA = stash record + alpha record (qoi.h:548-557)
@@ -2024,21 +2007,21 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                     *(lds_u32*)(((h << 8) & 0x3F00u) | tab_base) = px;       // qoi.h:577
                 }
                 if (CLIP) rem = min(rem, limit - W.ppos);                 // over-long run clipped (Appendix B item 8)
+                if (FLAT) {
+                    // a record that leaves the pixel as it is (QOI_OP_RUN, a null record) lengthens the span; one that names a pixel ends it
+                    // and opens the next (a stash half yields no pixel: rem is 0)
+                    const bool names = (rec & 0xC0FFFFFFu) != 0u && rem != 0u;
+                    if (lanes_where(names && span_len != 0u) != 0ull) { if (names && span_len != 0u) close_span(px_before); }
+                    if (names) span_start = W.ppos;
+                    span_len += rem; W.ppos += rem;
+                    continue;
+                }
                 const uint32_t n2 = min(rem, 2u);
                 W.put2n(px, n2);
                 if (__builtin_expect(lm[u] != 0ull, 0)) {                  // QOI_OP_RUN of three or more (qoi.h:573-575) in some lane
                     rem -= n2;
                     if (rem) {
-                        if (FLAT) {
-                            if (rem >= kLongRun) {
-                                // the run leaves the ring here: up to a 4-pixel boundary through it, the ring out, the rest pending
-                                while ((W.ppos & 3u) != 0u && rem) { W.put(px); --rem; }
-                                W.finish();
-                                run_start = W.ppos; run_len = rem;
-                                W.ppos += rem; W.fpos = W.ppos;
-                                rem = 0u;
-                            }
-                        } else if (rem >= kLongRun) {
+                        if (rem >= kLongRun) {
                             if (p.desc_all) {
                                 // sprites, screenshots with photographs in them: the run's head up to a 4-pixel boundary through the ring, the ring
                                 // out, the aligned part as a descriptor for dec_expand_runs (the lane wrote it in 16-byte pieces of its own: fifteen
@@ -2068,7 +2051,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
         }
     };
     if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
-    if (FLAT) { if (run_len != 0u) flush_run(); }
+    if (FLAT) { if (span_len != 0u) close_span(px); W.fpos = W.ppos; }
     if (FLAT || p.desc_all) {
         // segments with descriptors queue up for dec_expand_runs: one returning atomic per wavefront that has any
         const bool some = have && n_desc != 0u;
@@ -2133,14 +2116,29 @@ __global__ __launch_bounds__(256) void dec_expand_runs(DecParams p) {
             for (uint32_t i = 0; i < m; ++i) {
                 const uint32_t start = read_lane_dyn(cur.x, i), len = read_lane_dyn(cur.y, i), px = read_lane_dyn(cur.z, i);
                 if (OCH == 4) {
-                    uint4* __restrict__ o = reinterpret_cast<uint4*>(out + (size_t)start * 4u);          // start is a multiple of 4 pixels: 16-byte aligned
+                    // pixels up to the first 16-byte boundary and behind the last one as dwords (one store instruction for both ends),
+                    // the aligned middle 16 bytes per lane
+                    const uint32_t head = min(len, (4u - (start & 3u)) & 3u), mid = (len - head) >> 2, tail = (len - head) & 3u;
+                    uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out) + start;
+                    if (lane < head + tail) o32[lane < head ? lane : head + (mid << 2) + (lane - head)] = px;
+                    uint4* __restrict__ o = reinterpret_cast<uint4*>(o32 + head);
                     const uint4 w4 = make_uint4(px, px, px, px);
-                    for (uint32_t k = lane; k < (len >> 2); k += 64u) o[k] = w4;
+                    for (uint32_t k = lane; k < mid; k += 64u) o[k] = w4;
                 } else {
-                    uint32_t* __restrict__ o = reinterpret_cast<uint32_t*>(out + (size_t)start * 3u);      // 12-byte groups of four pixels
-                    const uint32_t a = px & 0xFFFFFFu;
-                    const uint32_t w0 = a | (a << 24), w1 = (a >> 8) | (a << 16), w2 = (a >> 16) | (a << 8);
-                    for (uint32_t k = lane; k < (len >> 2); k += 64u) { o[3u * k] = w0; o[3u * k + 1u] = w1; o[3u * k + 2u] = w2; }
+                    // 3-byte pixels: bytes up to the first dword boundary and behind the last one singly, the middle as dwords of the
+                    // repeating r,g,b pattern (the dword k dwords in starts (head + k) % 3 bytes into a pixel)
+                    const uint32_t b0 = start * 3u, nb = len * 3u;
+                    const uint32_t head = min(nb, (4u - (b0 & 3u)) & 3u), mid = (nb - head) >> 2, tail = (nb - head) & 3u;
+                    const uint32_t c0 = px & 0xFFu, c1 = (px >> 8) & 0xFFu, c2 = (px >> 16) & 0xFFu;
+                    auto byte_at = [&](uint32_t ph) { return ph == 0u ? c0 : (ph == 1u ? c1 : c2); };
+                    uint8_t* __restrict__ o8 = out + b0;
+                    if (lane < head + tail) {
+                        const uint32_t at = lane < head ? lane : head + (mid << 2) + (lane - head);
+                        o8[at] = (uint8_t)byte_at(at % 3u);
+                    }
+                    uint32_t* __restrict__ o = reinterpret_cast<uint32_t*>(o8 + head);
+                    const uint32_t w0 = c0 | (c1 << 8) | (c2 << 16) | (c0 << 24), w1 = c1 | (c2 << 8) | (c0 << 16) | (c1 << 24), w2 = c2 | (c0 << 8) | (c1 << 16) | (c2 << 24);
+                    for (uint32_t k = lane; k < mid; k += 64u) { const uint32_t ph = (head + k) % 3u; o[k] = ph == 0u ? w0 : (ph == 1u ? w1 : w2); }
                 }
             }
             cur = nxt;

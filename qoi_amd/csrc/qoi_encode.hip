@@ -1491,8 +1491,8 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         // that returns at once when nothing was flagged - no summary pass, no scans.
         EncParams g = p;
         g.status = p.status_gen; g.ticket = p.ticket_gen; g.tree1 = p.tree1_gen; g.tree2 = p.tree2_gen;
-        g.set_slabs = kEncGenSetSlabs; g.set_px = kEncGenSetSlabs * kEncSlabPx;
-        g.sets_per_image = (p.spi + kEncGenSetSlabs - 1u) / kEncGenSetSlabs;
+        g.set_slabs = p.gen_slabs; g.set_px = p.gen_slabs * kEncSlabPx;
+        g.sets_per_image = (p.spi + p.gen_slabs - 1u) / p.gen_slabs;
         g.n_units = ((g.sets_per_image + 3u) / 4u) * p.n_images;
         hipLaunchKernelGGL((enc_sets<CH, PROBE, 2, MIXED>), dim3(g.n_units < small || g.lookback == 2 ? g.n_units : small), dim3(256), 0, st, g);
         tm->mark(kT_enc_slabs_generic, st);
@@ -1511,8 +1511,8 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         // kEncGenSetSlabs slabs per set: flat content is a few bytes per slab, eight slabs per look-back instead of R.  (Round 3 parked
         // these sets order-free in per-set scratch slots - the worst-case slots of EVERY set of the batch, 42.5 GB for 1024 4K frames.)
         g.status = p.status_gen; g.ticket = p.ticket_gen; g.tree1 = p.tree1_gen; g.tree2 = p.tree2_gen;
-        g.set_slabs = kEncGenSetSlabs; g.set_px = kEncGenSetSlabs * kEncSlabPx;
-        g.sets_per_image = (p.spi + kEncGenSetSlabs - 1u) / kEncGenSetSlabs;
+        g.set_slabs = p.gen_slabs; g.set_px = p.gen_slabs * kEncSlabPx;
+        g.sets_per_image = (p.spi + p.gen_slabs - 1u) / p.gen_slabs;
         g.n_units = ((g.sets_per_image + 3u) / 4u) * p.n_images;
     } else if (warm) {
         g.lookback = 0; p.lookback = 0;                      // an order-free call: the flagged images are parked and placed with the others

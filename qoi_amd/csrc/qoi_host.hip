@@ -108,6 +108,7 @@ struct qoimi_ctx {
     int enc_tree_ticket = 0;            // env QOIMI_ENC_TREE_TICKET=1: tree placement hands its units out by one ticket per workgroup (start order) instead of by workgroup index
     uint32_t test_spin_bound = 0;       // env QOIMI_TEST_SPIN_BOUND (tests): polls before a placement wait gives up
     bool worst_case_buffer = false;     // env QOIMI_ENCODE_WORST_CASE_BUFFER=1 (read once, at creation): qoi_encode returns the reference's worst-case allocation
+    int enc_gen_slabs = (int)kEncGenSetSlabs;   // env QOIMI_ENC_GEN_SLABS (1..8): slabs per set of the pass over flagged images
     int enc_g2 = 1;                     // env QOIMI_ENC_G2=0: flagged images (flat content) go through the summary passes instead of the state look-back (ENTRY 2)
     uint32_t enc_epoch = 0;             // encode call number: the tag of the state look-back's granules
     void* g2_zeroed_at = nullptr; size_t g2_zeroed_bytes = 0; unsigned g2_zeroed_gen = 0;     // where those granules were last zeroed
@@ -186,6 +187,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_TREE_TICKET")) c->enc_tree_ticket = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_ADAPT")) c->enc_adapt = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_G2")) c->enc_g2 = atoi(e) != 0;
+    if (const char* e = getenv("QOIMI_ENC_GEN_SLABS")) { const int v = atoi(e); if (v >= 1 && v <= (int)kEncMaxSetSlabs) c->enc_gen_slabs = v; }
     if (const char* e = getenv("QOIMI_TEST_SPIN_BOUND")) { const long v = atol(e); if (v >= 1) c->test_spin_bound = (uint32_t)v; }
     if (const char* e = getenv("QOIMI_ENCODE_WORST_CASE_BUFFER")) c->worst_case_buffer = atoi(e) != 0;
     c->host_word[12] = 0u;
@@ -392,11 +394,12 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     // from their first spill to their copy-out - a pool of kEncPoolSlots slots (more than the wavefronts in flight; fewer for calls
     // of fewer sets), handed out on the device (pool_take).  The 1024-frame 4K shard: 0.34 GB instead of 42.5 GB.
     p.pool = lookback ? 1 : 0;
-    const size_t S_gen = (size_t)p.n_images * ((p.spi + kEncGenSetSlabs - 1u) / kEncGenSetSlabs);
+    p.gen_slabs = (uint32_t)c->enc_gen_slabs;
+    const size_t S_gen = (size_t)p.n_images * ((p.spi + p.gen_slabs - 1u) / p.gen_slabs);
     if (lookback) {
         size_t slots = (S + 63u) & ~(size_t)63u;
         p.pool_slots = (uint32_t)(slots < kEncPoolSlots ? slots : kEncPoolSlots);
-        const uint32_t r_max = p.set_slabs > kEncGenSetSlabs ? p.set_slabs : kEncGenSetSlabs;     // the generic pass draws on the same pool
+        const uint32_t r_max = p.set_slabs > p.gen_slabs ? p.set_slabs : p.gen_slabs;     // the generic pass draws on the same pool
         p.set_stride = r_max * kEncSlabWorst + 16u;
     }
 
@@ -528,7 +531,7 @@ extern "C" int qoimi_encode_images(qoimi_ctx* c, const void* d_pixels, const siz
             EncParams p; memset(&p, 0, sizeof p);
             p.pixels = (const uint8_t*)d_pixels; p.out = (uint8_t*)d_streams; p.n_images = n; p.channels = (uint8_t)ch;
             p.set_slabs = r; p.set_px = r * kEncSlabPx; p.set_stride = r * kEncSlabWorst + 16u;
-            p.probe_xchg = c->xchg_ordered ? 1 : 0; p.use_ticket = 0; p.warm = c->enc_warm ? 1 : 0; p.lookback = 0; p.pool = 0; p.spin_bound = 1u << 22;
+            p.probe_xchg = c->xchg_ordered ? 1 : 0; p.use_ticket = 0; p.warm = c->enc_warm ? 1 : 0; p.lookback = 0; p.pool = 0; p.spin_bound = 1u << 22; p.gen_slabs = kEncGenSetSlabs;
             const size_t T = (size_t)slabs, G = (size_t)groups, S = (size_t)sets;
             Carver w(pass ? (uint8_t*)c->enc_ws.base + ws_off : nullptr);
             if (!pass) w.base = nullptr;
