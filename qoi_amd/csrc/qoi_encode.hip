@@ -884,7 +884,7 @@ __device__ __forceinline__ bool g2_ready(const EncParams& p, u64 g) { return ((g
 
 template <int CH, class LDS>
 __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t* __restrict__ pix, uint32_t n, uint32_t lo, uint32_t hi,
-                                               u64* __restrict__ rec_img, uint32_t set, uint32_t lane, LDS& L, uint32_t tbase, int& last_edge) {
+                                               u64* __restrict__ rec_img, uint32_t set, uint32_t lane, LDS& L, uint32_t tbase, int& last_edge, bool& no_edges) {
     // ---- own summary: last edge pixel per slot, last edge -------------------------------------------------------------
     const uint32_t sent = lane + 1u;                           // cannot hash to its own slot (warm_entry_state)
     L.table[lane] = sent;
@@ -973,6 +973,7 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
     __builtin_amdgcn_wave_barrier();
     L.table[lane] = ent_valid ? ent_w : 0u;                   // untouched slots are the zeroes of qoi.h:393
     last_edge = le_ent;
+    no_edges = le_loc < 0;
     __builtin_amdgcn_wave_barrier();
     return true;
 }
@@ -1029,6 +1030,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     C.tbase = lds_addr(L.table);                               // 256-byte aligned
     asm volatile("" : "+v"(C.tbase));                          // keep in a VGPR
     int last_edge = -1;
+    bool run_only = false;                                     // ENTRY 2: the set holds no edge at all - its bytes are run bytes, known without a second walk
     if (ENTRY == 1) {
         if (!warm_entry_state<CH, PROBE>(pix, lo, lane, L, C.tbase, in, last_edge)) {
             if (lane == 0) { atomicOr(&p.need_generic[img], 1u); atomicOr(p.any_generic, 1u); }
@@ -1036,9 +1038,9 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         }
     } else if (ENTRY == 2) {
         if (PROBE == 1) {
-            if (!g2_entry_state<CH>(p, pix, n, lo, hi, p.g2_rec + (size_t)I.set_base * 65u, set, lane, L, C.tbase, last_edge)) return;
+            if (!g2_entry_state<CH>(p, pix, n, lo, hi, p.g2_rec + (size_t)I.set_base * 65u, set, lane, L, C.tbase, last_edge, run_only)) return;
         }
-        if (nint) load_group<CH>(pix, lo, lane, ax, av);       // (from the L2 / Infinity Cache: the set's own walk has just read them)
+        if (nint && !run_only) load_group<CH>(pix, lo, lane, ax, av);       // (from the L2 / Infinity Cache: the set's own walk has just read them)
     } else {
         const u64 lv = uniform64(in.tab_valid);
         L.table[lane] = ((lv >> lane) & 1ull) ? in.tab_loc : in.tab_far;
@@ -1081,6 +1083,24 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     };
 
     uint32_t g = 0;
+    if (ENTRY == 2 && run_only) {
+        // Every pixel of the set repeats the pixel in front of it (constant frames, letterbox bars, blank pages): pixel i, d pixels behind
+        // the last edge, carries 0xFD where d is a multiple of 62 (qoi.h:417-421) and nothing else - but the set's last pixel, which
+        // closes its run if the image ends with it or the pixel behind it is an edge (qoi.h:425-428).  No second walk over the pixels.
+        const uint32_t d0 = lo - (uint32_t)last_edge;                      // distance of the set's first pixel (last_edge = -1: the start value in front of pixel 0)
+        const uint32_t d1 = d0 + (hi - lo) - 1u;                           // ... of its last one
+        const uint32_t k = d1 / 62u - (d0 - 1u) / 62u;                     // multiples of 62 in [d0, d1]
+        bool closes = last_set;
+        if (!last_set) closes = load_px<CH>(pix, hi) != load_px<CH>(pix, hi - 1u);
+        closes = closes && (d1 % 62u) != 0u;
+        lds_u8* const st8 = (lds_u8*)(uintptr_t)sbase;
+        for (uint32_t i = lane; i < k; i += 64u) st8[i] = (uint8_t)0xFDu;
+        if (lane == 0 && closes) st8[k] = (uint8_t)(0xC0u | ((d1 - 1u) % 62u));
+        vbase = sbase + k + (closes ? 1u : 0u);
+        __builtin_amdgcn_wave_barrier();
+        g = ngroups; nint = 0u;
+        ask_early();
+    }
     if (nint) {
         u64 E;
         { uint32_t p0, v0; unpack_pair<CH>(ax[0], av[0], p0, v0); E = __ballot(p0 != v0); }

@@ -618,8 +618,8 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
     if (B == 0 && c->dec_run_desc && c->dec_flat_seg) {
         // A call of FLAT images only (run descriptors): a lane's walk over its segment no longer writes the segment's pixels, it costs
         // its chunks alone - larger segments mean fewer entry states (780 bytes per segment whatever its size), fewer chances to miss
-        // (a round per miss) and the same work.  The largest size that still fills the 98 K lanes dec_segments_rec holds at a time four
-        // times over (B = 4096 on 1024 UI frames: 165 K lanes, P3 11.9 ms and P4 10.7 against 7.7 and 8.0 at B = 1024, profiles/r05_s2_*).
+        // (a round per miss) and the same work.  The largest size that still gives 128 K lanes (1024 UI frames, 292 MB of streams: 512 /
+        // 1024 / 2048 bytes = 10 / 5 / 3 rounds in 22.0 / 18.9 / 19.1 ms, profiles/r05_s6_dec_span.txt; 4096: P3 and P4 run short of lanes).
         bool all_flat = true;
         uint64_t bytes = 0;
         for (int i = 0; i < n_images && all_flat; ++i) {
@@ -628,7 +628,7 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
         }
         if (all_flat)
             for (uint32_t cand = 4096u; cand >= 256u; cand >>= 1)
-                if (bytes / cand >= 393216u) { B = cand; break; }
+                if (bytes / cand >= 131072u) { B = cand; break; }
     }
     if (B == 0) {
         // One lane decodes one segment.  Two costs pull in opposite directions (constants measured on MI355X):
