@@ -5,7 +5,8 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/${SESSION:-sess}
 mkdir -p "$OUT"
-export TMPDIR=/tmp PYTHONUNBUFFERED=1
+export TMPDIR=/tmp PYTHONUNBUFFERED=1 HSA_ENABLE_COREDUMP=0
+ulimit -c 0
 (rocm-smi --showproductname 2>/dev/null | head -8; nproc; free -g | head -2) > "$OUT/env.log" 2>&1
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "rc=$?" >> "$OUT/smoke.log"; tail -2 "$OUT/smoke.log"
 echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > "$OUT/pytest.log" 2>&1; echo "rc=$?" >> "$OUT/pytest.log"; tail -4 "$OUT/pytest.log"
