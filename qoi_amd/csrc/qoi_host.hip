@@ -695,9 +695,9 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     memset(&p, 0, sizeof p);
     p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
-    p.rec_rows = rec_region_dwords(B) / 4u;
+    p.rec_rows = rec_rows_of(B);
     p.flat_segs = (uint32_t)flat_total;
-    p.desc_cap = rec_region_dwords(B) / 2u + 2u;            // a run ends with the record behind it: every second record at most
+    p.desc_cap = rec_max_records(B) / 2u + 2u;              // a run ends with the record behind it: every second record at most
     // descriptors for the long runs of the other images as well - not for calls of a few images without a flat one (one more launch
     // on a path that counts them)
     p.desc_all = (c->dec_run_desc >= 2 && (n_images > 4 || flat_total != 0)) ? 1u : 0u;
@@ -821,7 +821,9 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     const uint32_t B = choose_seg_bytes(c, sizes, descs, n_images);
     // The chunk records take four bytes per stream byte (worst case) while a call is in flight.  Calls whose streams would
     // need more than dec_rec_cap are decoded as consecutive sub-batches of whole images through the same workspace.
-    const uint64_t cap_stream = (uint64_t)(c->dec_rec_cap / 4u) - (uint64_t)(c->dec_rec_cap / 4u) / 64u;
+    // (16-bit records: 3.2 stored bytes per stream byte at the worst, not 4)
+    const uint64_t cap_stream = QOIMI_REC16 ? (uint64_t)(c->dec_rec_cap / 16u) * 5u - (uint64_t)(c->dec_rec_cap / 16u) * 5u / 32u
+                                            : (uint64_t)(c->dec_rec_cap / 4u) - (uint64_t)(c->dec_rec_cap / 4u) / 64u;
     long long acc[4] = {0, 0, 0, 0};
     for (int first = 0; first < n_images;) {
         uint64_t bytes = 0;
