@@ -1681,7 +1681,11 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     // skip the store by writing back the word they read (see dec_summarize)
     const bool skip_runs = REFINE && j != 0u;
     // read-ahead state of the plain form: address and word of the next step's table read, address and word of the last table write
+#if QOIMI_REC16
+    uint32_t ra_cur = and_or_b32(s_lut16[ring[0].x & 0xFFu], 0x3F00u, tc_base), t_cur = 0u, wa_prev = ~0u, wv_prev = 0u;      // (the first record's template: only its slot bits count)
+#else
     uint32_t ra_cur = and_or_b32(ring[0].x, 0x3F00u, tc_base), t_cur = 0u, wa_prev = ~0u, wv_prev = 0u;
+#endif
     if (plain) t_cur = *(const lds_u32*)ra_cur;
     // One loop over the blocks, unrolled kDepth times (the ring is indexed statically: registers); a block of eight steps is
     // taken in the plain form or in the general one.  A block that holds a half of a QOI_OP_RGBA in any lane (class 3, or class 2
