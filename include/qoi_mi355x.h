@@ -136,9 +136,13 @@ int qoimi_encode_images(qoimi_ctx *ctx, const void *d_pixels, const size_t *pixe
  * QOIMI_ENC_PROBE=0 in the environment selects the order-independent probe from the start (about 1.5 x the encode time). */
 long long qoimi_encode_suspect_calls(qoimi_ctx *ctx);
 
-/* Synchronise `stream` and return QOIMI_E_INTERNAL if the last qoimi_encode_batch on this
- * context tripped its device-side liveness bound (never expected), or - once - after a repeat of
- * the LDS-order self-test failed (see qoimi_encode_suspect_calls); QOIMI_OK otherwise. */
+/* Synchronise `stream`.  If a placement wait of the last qoimi_encode_batch on this context gave up (never observed: a set waits for
+ * sets that are resident or done - with tickets by construction, for calls of fewer than 8 images by the order the dispatcher starts
+ * workgroups in, which launches of other streams could in principle disturb; such waits are bounded and end each other) the call is
+ * encoded again here, order-free, from the caller's buffers - which the caller must therefore not have released or overwritten before
+ * asking.  QOIMI_E_INTERNAL if that failed too, or - once - after a repeat of the LDS-order self-test failed (see
+ * qoimi_encode_suspect_calls); QOIMI_OK otherwise.  A caller that only synchronises its stream never learns of a wait that gave up:
+ * call this before reading the streams. */
 int qoimi_encode_status(qoimi_ctx *ctx, void *stream);
 
 /* Decode n_images streams that live in device memory.

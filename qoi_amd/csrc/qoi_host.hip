@@ -121,7 +121,8 @@ struct qoimi_ctx {
     std::string enc_debug_dump;         // env QOIMI_ENC_DEBUG_DUMP: file that receives the entry-state arrays of every encode call
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
-    int dec_p3_plain = 1, dec_inner = 4, dec_inner1 = 3;   // env QOIMI_P3_PLAIN, QOIMI_DEC_INNER, QOIMI_DEC_INNER1 (read once, at creation)
+    int dec_p3_plain = 1, dec_inner = 8, dec_inner1 = 3;   // env QOIMI_P3_PLAIN, QOIMI_DEC_INNER, QOIMI_DEC_INNER1 (read once, at creation)
+                                                           // (dec_inner 4 / 8 / 16 on 1024 UI frames: 3 / 2 / 2 rounds in 19.4 / 18.6 / 23.2 ms, profiles/r05_s9_dec_uiflat_inner.txt)
     int dec_l2_wgs = 1;          // dec_chain_state_l2m: 0 never, 1 for calls of up to four images of 128 groups or more, 2 for every call of up to four images (env QOIMI_DEC_L2M, tests)
     int dec_flat_seg = 1;        // 0: calls of flat images take the segment size of the general cost model (env QOIMI_DEC_FLAT_SEG, A/B)
     int dec_run_desc = 2;        // env QOIMI_DEC_RUN_DESC - 0: every long run is written lane by lane; 1: run descriptors for flat images; 2: and a descriptor per long QOI_OP_RUN chunk of the other images

@@ -753,6 +753,29 @@ def test_flat_frames_byte_identical(api, oracle, env):
                 os.environ[k] = v
 
 
+def test_state_lookback_granules_across_calls_and_shapes(api, oracle):
+    """The state look-back's granules (enc_sets<ENTRY 2>) are told apart by the call's number and zeroed only where they come to lie
+    somewhere new: one context, flat images, shapes and batch sizes alternating from call to call (tree and look-back placement, the
+    arena growing in between) - every stream the reference's, call after call."""
+    import torch
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    c = api.Context(0)
+    plan = [(640, 360, 2), (1024, 600, 9), (640, 360, 2), (640, 360, 2), (1024, 600, 9), (1920, 1080, 3), (1024, 600, 9), (1024, 600, 9), (37, 23, 1), (1024, 600, 12)]
+    kinds = ["uiflat", "constant", "sprite_alpha", "uiflat", "photo"]
+    for call, (w, h, n) in enumerate(plan):
+        b = DeviceBatch(c, w, h, 4, n)
+        frames = [synth.frame_rgba(kinds[(call + i) % len(kinds)], w, h, 700 + 13 * call + i) for i in range(n)]
+        if call % 3 == 2:                                  # a letterboxed frame: opens with rows of the start value, ends in a long run
+            frames[0] = frames[0].copy(); frames[0][: h // 3] = (0, 0, 0, 255); frames[0][-(h // 4):] = (9, 9, 9, 255)
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        lens = b.encode()
+        for i, f in enumerate(frames):
+            assert b.stream_bytes(i, lens[i]) == oracle.encode(f, w, h, 4), (call, i, w, h, n)
+    c.close()
+
+
 @pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_SPREAD": "0"}])
 def test_random_sweep_of_contents_and_shapes(api, oracle, env):
     """A seeded sweep over every synthetic content kind at shapes from a few pixels to several 64-slab groups, 3 and 4 channels:

@@ -74,6 +74,10 @@ def test_gpu_rows_on_a_512_png(tmp_path):
     assert rc == 0
     rows = {k: [l for l in lines if l.startswith(k)] for k in ("qoi-mi355x:", "qoi-dev:", "qoi-ref:")}
     assert all(len(v) == 2 + 2 for v in rows.values()), {k: len(v) for k, v in rows.items()}     # two images, directory total, grand total
+    # the directory in ONE qoimi_encode_images / qoimi_decode_batch call (a 4-channel and a 3-channel image of different shapes): in the two totals
+    batch = [l for l in lines if l.startswith("qoi-batch:")]
+    assert len(batch) == 2 and batch[0].split()[-2:] == rows["qoi-ref:"][2].split()[-2:], (batch, rows["qoi-ref:"])
+    assert float(batch[0].split()[3]) > 0 and float(batch[0].split()[4]) > 0
     for a, b, c in zip(rows["qoi-mi355x:"], rows["qoi-dev:"], rows["qoi-ref:"]):
         assert a.split()[-2:] == c.split()[-2:] == b.split()[-2:], (a, b, c)      # size kb and rate: byte-identical streams
         for r in (a, b, c):

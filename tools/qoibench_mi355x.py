@@ -19,6 +19,8 @@ Rows:
     qoi-dev:     the same kernels on device-resident buffers (qoimi_encode_batch / qoimi_decode_batch)
     qoi-ref:     only with --ref-lib PATH [--ref-prefix P]: a CPU build of the reference's qoi_encode/qoi_decode
                  (any shared object exporting `<P>qoi_encode` / `<P>qoi_decode`) timed beside, one host core
+    qoi-batch:   (totals only) ALL images of a directory in ONE qoimi_encode_images call and ONE qoimi_decode_batch call,
+                 device-resident - whatever their shapes and channel counts; per-image means like the other rows; --nobatch: off
 
 --synth K writes K synthetic .png files of every content class into the directory first (there are no test images
 in the reference tree).  The tool itself contains no CPU codec and needs the MI355X for its own rows.
@@ -40,7 +42,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import png_io  # noqa: E402
 
-ROWS = ("qoi-mi355x:", "qoi-dev:   ", "qoi-ref:   ")
+ROWS = ("qoi-mi355x:", "qoi-dev:   ", "qoi-ref:   ", "qoi-batch: ")
 
 
 class Result:
@@ -174,6 +176,51 @@ def benchmark_image(path: str, opt, ref, gpu) -> Result:
     return res
 
 
+def benchmark_batch(images, streams, opt, gpu) -> list:
+    """The directory's images in one qoimi_encode_images call and one qoimi_decode_batch call (device-resident):
+    [stream bytes, encode ns, decode ns] for the whole directory.  `streams`: what the drop-in qoi_encode wrote for each image -
+    the batch call must write the same bytes."""
+    api, ctx, torch = gpu
+    descs = [api.QoiDesc(w, h, ch, api.QOI_SRGB) for (_, w, h, ch) in images]
+    pix_off, str_off = [], []
+    po = so = 0
+    for (px, w, h, ch) in images:
+        pix_off.append(po); str_off.append(so)
+        po += (px.size + 255) // 256 * 256; so += (api.encode_bound(w, h, ch) + 255) // 256 * 256
+    d_pix = torch.empty(po, dtype=torch.uint8, device="cuda")
+    d_str = torch.empty(so, dtype=torch.uint8, device="cuda")
+    d_len = torch.zeros(len(images), dtype=torch.int32, device="cuda")
+    for (px, _, _, _), o in zip(images, pix_off):
+        d_pix[o:o + px.size].copy_(torch.from_numpy(px.reshape(-1)))
+    st = torch.cuda.current_stream().cuda_stream
+
+    def enc():
+        ctx.encode_images(d_pix.data_ptr(), pix_off, descs, d_str.data_ptr(), str_off, d_len.data_ptr(), st)
+        ctx.encode_status(st)
+    enc()
+    lens = [int(x) for x in d_len.cpu().numpy()]
+    if not opt.noverify:
+        for i, want in enumerate(streams):
+            if d_str[str_off[i]:str_off[i] + lens[i]].cpu().numpy().tobytes() != want:
+                raise SystemExit(f"batch stream {i} differs from the drop-in's")
+    # decode: the streams at a common stride, all of them to 4 channels (qoibench.c decodes with channels = 4)
+    sstride = (max(lens) + 8 + 255) // 256 * 256
+    pstride = (max(w * h for (_, w, h, _) in images) * 4 + 255) // 256 * 256
+    d_in = torch.zeros(len(images) * sstride, dtype=torch.uint8, device="cuda")
+    for i in range(len(images)):
+        d_in[i * sstride:i * sstride + lens[i]].copy_(d_str[str_off[i]:str_off[i] + lens[i]])
+    d_out = torch.empty(len(images) * pstride, dtype=torch.uint8, device="cuda")
+
+    def dec():
+        ctx.decode_batch(d_in.data_ptr(), sstride, lens, descs, 4, d_out.data_ptr(), pstride, st)
+    row = [sum(lens), 0, 0]
+    if not opt.nodecode:
+        row[2] = bench_fn(opt.nowarmup, opt.runs, dec)
+    if not opt.noencode:
+        row[1] = bench_fn(opt.nowarmup, opt.runs, enc)
+    return row
+
+
 def benchmark_directory(path: str, grand: Result, opt, ref, gpu, rows, out):
     entries = sorted(os.listdir(path))
     if not opt.norecurse:                                            # qoibench.c:497-511
@@ -183,6 +230,7 @@ def benchmark_directory(path: str, grand: Result, opt, ref, gpu, rows, out):
                 benchmark_directory(sub, grand, opt, ref, gpu, rows, out)
     dirtotal = Result()
     has_shown_head = False
+    batch_images, batch_streams = [], []
     for e in entries:
         if not e.endswith(".png"):
             continue
@@ -194,9 +242,15 @@ def benchmark_directory(path: str, grand: Result, opt, ref, gpu, rows, out):
         if not opt.onlytotals:
             w, h, _ = png_io.png_info(open(f, "rb").read())
             out(f"## {f} size: {w}x{h}")
-            out(print_result(res, rows))
+            out(print_result(res, [r for r in rows if r != 3]))
         dirtotal.add(res)
+        if gpu and 3 in rows:
+            px, w, h, ch = load_image(f)
+            batch_images.append((px, w, h, ch))
+            batch_streams.append(gpu[0].qoi_encode(px, gpu[0].QoiDesc(w, h, ch, gpu[0].QOI_SRGB)))
     if dirtotal.count > 0:
+        if batch_images:
+            dirtotal.libs[3] = benchmark_batch(batch_images, batch_streams, opt, gpu)
         out(f"## Total for {path}")
         out(print_result(dirtotal, rows))
         grand.add(dirtotal)
@@ -218,6 +272,7 @@ def main(argv=None, out=print, ref=None, use_gpu=True) -> int:
     ap.add_argument("directory")
     for f in ("nowarmup", "noverify", "noencode", "nodecode", "norecurse", "onlytotals"):
         ap.add_argument("--" + f, action="store_true")
+    ap.add_argument("--nobatch", action="store_true", help="no qoi-batch row (a directory's images in one call)")
     ap.add_argument("--synth", type=int, default=0)
     ap.add_argument("--ref-lib", default="", help="shared object with a CPU build of the reference ABI: adds the qoi-ref row")
     ap.add_argument("--ref-prefix", default="", help="symbol prefix in --ref-lib (e.g. ref_)")
@@ -237,6 +292,8 @@ def main(argv=None, out=print, ref=None, use_gpu=True) -> int:
         rows = (0, 1)
     if ref:
         rows = rows + (2,)
+    if use_gpu and not opt.nobatch:
+        rows = rows + (3,)
     grand = Result()
     benchmark_directory(opt.directory, grand, opt, ref, gpu, rows, out)
     if grand.count > 0:
