@@ -891,33 +891,47 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
     __builtin_amdgcn_wave_barrier();
     int le_loc = -1;
     const uint32_t ngroups = (hi - lo + kGroupPx - 1u) / kGroupPx;
-    uint32_t cx[kGroupSteps], cv[kGroupSteps], nx[kGroupSteps], nv[kGroupSteps];
-    auto fetch = [&](uint32_t g, uint32_t (&x)[kGroupSteps], uint32_t (&v)[kGroupSteps]) {
+    // One load per pixel: the pixel in front of a lane's is its neighbour's (a DPP move; lane 0 takes lane 63 of the step before).  (The
+    // first form asked for every pixel AND the one before it, bounds-checked, as the encoding groups do: 34 GB of constant frames in
+    // 12.2 ms = 2.8 TB/s, profiles/r05_s6_enc_state_lookback_tune.txt.)  3-channel pixels as one unaligned dword where a byte
+    // behind the pixel still belongs to the image.
+    auto load_one = [&](uint32_t i) -> uint32_t {
+        if constexpr (CH == 4) return load_px<4>(pix, i);
+        else {
+            if (i + 1u < n) { struct __attribute__((packed, aligned(1))) U1 { uint32_t x; }; return (reinterpret_cast<const U1*>(pix + (size_t)i * 3u)->x & 0x00FFFFFFu) | 0xFF000000u; }
+            return load_px<3>(pix, i);
+        }
+    };
+    uint32_t cx[kGroupSteps], nx[kGroupSteps];
+    auto fetch = [&](uint32_t g, uint32_t (&x)[kGroupSteps]) {
         const uint32_t base = lo + g * kGroupPx;
 #pragma unroll
-        for (int t = 0; t < kGroupSteps; ++t) load_pair_guarded<CH>(pix, base + (uint32_t)t * 64u + lane, hi, x[t], v[t]);
+        for (int t = 0; t < kGroupSteps; ++t) { const uint32_t i = base + (uint32_t)t * 64u + lane; x[t] = i < hi ? load_one(i) : 0u; }
     };
     uint32_t chain = 0u;
-    auto walk = [&](uint32_t g, const uint32_t (&x)[kGroupSteps], const uint32_t (&v)[kGroupSteps]) {
+    uint32_t carry = lo > 0u ? load_one(lo - 1u) : kInitPx;     // the pixel in front of the set (qoi.h:396-399 in front of the image)
+    auto walk = [&](uint32_t g, const uint32_t (&x)[kGroupSteps]) {
         const uint32_t base = lo + g * kGroupPx;
         // (what the exchanges return is of no interest - but see probe_swap_into)
 #pragma unroll
         for (int t = 0; t < kGroupSteps; ++t) {
             const bool inb = base + (uint32_t)t * 64u + lane < hi;
-            const u64 E = __ballot(inb && x[t] != v[t]);
+            const uint32_t prev = from_lane_below(x[t], carry);
+            const u64 E = __ballot(inb && x[t] != prev);
+            carry = read_lane(x[t], 63);
             if (E) {
                 le_loc = (int)(base + (uint32_t)t * 64u) + msb64(E);
                 probe_swap_into(chain, tbase | slot_byte_offset(x[t]), x[t], E);  // lanes in ascending order: the later pixel stays (PROBE 1)
             }
         }
     };
-    fetch(0u, cx, cv);
+    fetch(0u, cx);
     for (uint32_t g = 0; g < ngroups; g += 2u) {
-        if (g + 1u < ngroups) fetch(g + 1u, nx, nv);
-        walk(g, cx, cv);
+        if (g + 1u < ngroups) fetch(g + 1u, nx);
+        walk(g, cx);
         if (g + 1u >= ngroups) break;
-        if (g + 2u < ngroups) fetch(g + 2u, cx, cv);
-        walk(g + 1u, nx, nv);
+        if (g + 2u < ngroups) fetch(g + 2u, cx);
+        walk(g + 1u, nx);
     }
     probe_wait(chain);
     __builtin_amdgcn_wave_barrier();
