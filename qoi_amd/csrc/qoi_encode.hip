@@ -690,6 +690,17 @@ struct SetIn {
     int le_loc, le_far;          // ENTRY 0: last edge before the set: group-local / image-level
 };
 
+// PIPE (round 5 experiment, env QOIMI_ENC_PIPE=1 with QOIMI_ENC_PERSIST): a wavefront that encodes set after set asks for the NEXT set's
+// first loads - its look-back window and its first group of pixels, and the ticket that names it - when its current set's groups are
+// through, in front of that set's placement: they travel while the wavefront waits for its place and copies its bytes out.  (With
+// start-order tickets a wavefront may hold two sets at once: whatever a set waits for was taken EARLIER than either of its holder's two.)
+struct SetPre {
+    uint32_t warm[8], warm_prev[8];
+    uint32_t img, set;
+    bool have_ticket;      // (img, set) is this wavefront's next set: its ticket is taken
+    bool valid;            // ... and its loads are on their way in the arrays above
+};
+
 // ENTRY 1: a set finds its entry state itself.  The colour table before pixel `lo` is "the last edge pixel
 // per hash slot" (qoi.h:430-436), so the wavefront walks BACKWARDS over the pixels before its set, 64 at a
 // time, and fills every slot that is still empty with the latest edge pixel that hashes there, until all 64
@@ -992,8 +1003,9 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
     return true;
 }
 
-template <int CH, int PROBE, int ENTRY, bool MIXED, class LDS>
-__device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, LDS& L) {
+template <int CH, int PROBE, int ENTRY, bool MIXED, bool PIPE = false, class LDS>
+__device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, LDS& L,
+                                           SetPre* pre = nullptr, bool use_pre = false, bool has_next = false, uint32_t next_img = 0u) {
     const EncImage I = enc_image<MIXED>(p, img);
     const uint8_t* __restrict__ pix = p.pixels + I.pixel_off;
     const uint32_t n = I.npx;
@@ -1013,7 +1025,17 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     // dozen instructions - costs the older wavefronts next to nothing (1024 x 4K photographs: 12.56 -> 12.40 ms, profiles/r04_s3_*).
     __builtin_amdgcn_s_setprio(2);
     SetIn in;
-    if (ENTRY == 1) {
+    if (PIPE) {
+        // The registers a set's first loads land in are the SAME whether this set asks for them here or the set before it did (SetPre):
+        // one definition on either path, nothing to copy at the join (a copy of a value that is still on its way waits for it).
+        if (!use_pre && lo != 0u) {
+            const uint8_t* __restrict__ q = pix + (size_t)(lo + lane) * (size_t)CH;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) load_pair_at<CH>(q, -64 * (k + 1), pre->warm[k], pre->warm_prev[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { in.warm[k] = pre->warm[k]; in.warm_prev[k] = pre->warm_prev[k]; }
+    } else if (ENTRY == 1) {
         if (lo != 0u) {                                        // (a set begins on a slab boundary: lo >= 1024, all of these lie inside the image)
             const uint8_t* __restrict__ q = pix + (size_t)(lo + lane) * (size_t)CH;
 #pragma unroll
@@ -1034,6 +1056,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     const bool gen_set = lo == 0u;
     uint32_t nint = gen_set ? 0u : (last_set ? ngroups - 1u : ngroups);
     uint32_t ax[kGroupSteps], av[kGroupSteps], bx[kGroupSteps], bv[kGroupSteps];
+    // (PIPE asks ahead for the look-back window only - what a set needs FIRST; its first group goes out here and travels during the replay
+    // of the window.  With the group asked for ahead as well the kernel needs 89 registers: spills, or five wavefronts per SIMD.)
     if (ENTRY != 2 && nint) load_group<CH>(pix, lo, lane, ax, av);
 
     // ---- entry state: colour table + distance to the last edge ---------------------------
@@ -1162,6 +1186,25 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     const uint32_t set_bytes = spilled + spos;
     PHASE_MARK(2);
 
+    if (PIPE) {
+        // the NEXT set of this wavefront: its ticket and its first loads go out here, in front of this set's placement
+        if (has_next && __hip_atomic_load((gu32*)&p.need_generic[next_img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&p.ticket[next_img], 1u);
+            const uint32_t nset = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            const uint32_t nlo = nset * p.set_px;
+            pre->img = next_img; pre->set = nset; pre->have_ticket = true;
+            // (loads only for sets that begin inside the image with a whole first group in front of its end: the others - an image's
+            // first and last set, tickets beyond its sets - do their own loads, or nothing, when their turn comes)
+            if (nset < p.sets_per_image && nlo != 0u && nlo + kGroupPx < p.npx) {
+                const uint8_t* __restrict__ npix = p.pixels + (size_t)next_img * p.pixel_stride;
+                const uint8_t* __restrict__ q = npix + (size_t)(nlo + lane) * (size_t)CH;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) load_pair_at<CH>(q, -64 * (k + 1), pre->warm[k], pre->warm_prev[k]);
+                pre->valid = true;
+            }
+        }
+    }
     if (!p.lookback) {
         // ---- order-free mode: park the set's bytes in its scratch slot, E4 (enc_offsets + enc_compact) places them ----
         (void)spill_stage<PROBE>(L, slot, spilled, spos, true, lane);
@@ -1296,7 +1339,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
 // the ENTRY 0 passes with only_flagged set: small grid-stride grids that return at once when nothing was
 // flagged.  A workgroup serves unit u = (image u % n_images, four consecutive sets u / n_images) so that the
 // sets in flight spread over all images.
-template <int CH, int PROBE, int ENTRY, bool MIXED>
+template <int CH, int PROBE, int ENTRY, bool MIXED, bool PIPE = false>
 // (the generic 3-channel form - flat 3-channel images only - takes a register more than six wavefronts per SIMD leave it: five)
 // (and so do the forms for differently shaped images, whose geometry comes from a table)
 __global__ __launch_bounds__(256, PROBE == 1 ? ((CH == 3 && ENTRY == 0) || MIXED ? QOIMI_ENC_WAVES_PER_SIMD - 1 : QOIMI_ENC_WAVES_PER_SIMD) : 4) void enc_sets(EncParams p) {
@@ -1304,9 +1347,30 @@ __global__ __launch_bounds__(256, PROBE == 1 ? ((CH == 3 && ENTRY == 0) || MIXED
     __shared__ uint32_t s_unit;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
+    SetPre pre;
+    pre.have_ticket = false; pre.valid = false;
 #pragma unroll 1
     for (uint32_t unit0 = blockIdx.x; unit0 < p.n_units; unit0 += gridDim.x) {
         uint32_t unit = unit0;
+        if (PIPE) {
+            // (look-back placement with tickets and SPREAD, one shape: what the launcher selects this form for)
+            const uint32_t img = (unit * 4u + wave) % p.n_images;
+            const bool mine = pre.have_ticket, loaded = pre.valid;         // taken / asked for by this wavefront's previous set
+            pre.have_ticket = false; pre.valid = false;
+            uint32_t set;
+            if (mine) set = pre.set;
+            else {
+                if (__hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(&p.ticket[img], 1u);
+                set = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            }
+            const uint32_t unit2 = unit0 + gridDim.x;
+            if (set < p.sets_per_image && __hip_atomic_load((gu32*)&p.need_generic[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                encode_set<CH, PROBE, ENTRY, MIXED, true>(p, img, set, lane, s_lds[wave], &pre, loaded, unit2 < p.n_units, (unit2 * 4u + wave) % p.n_images);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         if (p.lookback == 2 && p.use_ticket) {
             // Tree placement waits for LOWER-numbered sets of the same launch.  Units handed out by workgroup index would make that a bet
             // on in-order dispatch (every XCD dispatches its share on its own: two launches from different streams could wait on each
@@ -1512,6 +1576,15 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         p.only_flagged = 0;
         // (p.persist: test knob - at most that many workgroups, each taking unit after unit in the kernel's grid-stride loop)
         // (tree placement takes its sets by workgroup index and waits for lower-numbered ones: one workgroup per unit, no grid-stride loop)
+        bool piped = false;
+        if constexpr (!MIXED && PROBE == 1) {
+            // experiment (QOIMI_ENC_PIPE=1 with QOIMI_ENC_PERSIST=N): each wavefront's next set asked for in front of its current set's placement
+            if (p.pipe && p.persist && p.n_units > p.persist && p.lookback == 1 && p.use_ticket && p.spread) {
+                hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, MIXED, true>), dim3(p.persist), dim3(256), 0, st, p);
+                piped = true;
+            }
+        }
+        if (!piped)
         hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, MIXED>), dim3(p.persist && p.n_units > p.persist && p.lookback != 2 ? p.persist : p.n_units), dim3(256), 0, st, p);
         tm->mark(kT_enc_slabs, st);
         p.only_flagged = 1;

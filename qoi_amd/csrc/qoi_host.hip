@@ -116,6 +116,7 @@ struct qoimi_ctx {
     uint32_t enc_hint_npx = 0;          // pixels per image of the batch call whose first stream length stands in host_word[12] (0: none)
     struct { const void* px; size_t ps; qoi_desc desc; int n; void* out; size_t os; int* len; void* st; bool valid = false; } last_enc;   // the last qoimi_encode_batch (qoimi_encode_status re-encodes it order-free if a wait gave up)
     int enc_spread = 1;                 // env QOIMI_ENC_SPREAD: the wavefronts of a workgroup take their tickets from consecutive images (0: all four from one image)
+    int enc_pipe = 0;                   // env QOIMI_ENC_PIPE=1 (experiment, with QOIMI_ENC_PERSIST): next set's loads ahead of the current set's placement
     int enc_persist = 0;                // env QOIMI_ENC_PERSIST: workgroups of the first encode pass (0: one per unit)
     int enc_lookback = -1;              // 1: sets place their bytes themselves (decoupled look-back); 2: the same by the tree of byte counts; 0: order-free (scratch slots + enc_offsets + enc_compact); -1: by the call's shape
     std::string enc_debug_dump;         // env QOIMI_ENC_DEBUG_DUMP: file that receives the entry-state arrays of every encode call
@@ -193,6 +194,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENCODE_WORST_CASE_BUFFER")) c->worst_case_buffer = atoi(e) != 0;
     c->host_word[12] = 0u;
     if (const char* e = getenv("QOIMI_ENC_PERSIST")) { const int v = atoi(e); if (v >= 0) c->enc_persist = v; }
+    if (const char* e = getenv("QOIMI_ENC_PIPE")) c->enc_pipe = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
     if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
     if (const char* e = getenv("QOIMI_P3_PLAIN")) c->dec_p3_plain = atoi(e);
@@ -335,6 +337,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.use_ticket = c->enc_ticket ? 1 : 0;
     p.warm = c->enc_warm ? 1 : 0;
     p.persist = (uint32_t)c->enc_persist;
+    p.pipe = (uint32_t)c->enc_pipe;
     p.spread = (uint32_t)c->enc_spread;
     // Slabs per set and placement - functions of the call's shape only; QOIMI_ENC_SET_SLABS / QOIMI_ENC_LOOKBACK force them; every
     // combination gives the same bytes.

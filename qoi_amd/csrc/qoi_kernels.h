@@ -74,6 +74,7 @@ struct EncParams {
     uint32_t spread;         // 1 (default): the wavefronts of a workgroup serve consecutive images (env QOIMI_ENC_SPREAD=0: all four take tickets of one image)
     uint32_t gen_slabs;      // slabs per set of the pass over flagged images (kEncGenSetSlabs; env QOIMI_ENC_GEN_SLABS)
     uint32_t spin_bound;     // polls a placement wait makes before it gives up (err bit 0): 2^22 with tickets (start order), 2^15 for the tree by workgroup index
+    uint32_t pipe;           // 1 (env QOIMI_ENC_PIPE, with persist): a wavefront asks for its next set's first loads in front of its current set's placement
     uint32_t persist;        // 0: one workgroup per unit; else the first pass runs at most this many workgroups (env QOIMI_ENC_PERSIST, a test knob)
     // workspace
     uint32_t* sum_tab;   u64* sum_valid;  int* sum_le;     // E1 out        [n_images*spi]

@@ -479,6 +479,8 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_LOOKBACK": "1"},  # the four wavefronts of a workgroup take their tickets from ONE image (the default: from consecutive images)
     {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "1"},
     {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_PERSIST": "3", "QOIMI_ENC_LOOKBACK": "1"},  # ... in the grid-stride loop
+    {"QOIMI_ENC_PIPE": "1", "QOIMI_ENC_PERSIST": "3", "QOIMI_ENC_LOOKBACK": "1"},   # experiment: a wavefront asks for its next set's look-back window in front of its current set's placement
+    {"QOIMI_ENC_PIPE": "1", "QOIMI_ENC_PERSIST": "1", "QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "1"},
     {"QOIMI_ENC_G2": "0"},                                # flagged (flat) images through the summary passes (enc_slab_summary + scans + ENTRY 0) instead of the state look-back
     {"QOIMI_ENC_G2": "0", "QOIMI_ENC_LOOKBACK": "1"},
     {"QOIMI_ENC_LOOKBACK": "1"},                          # look-back placement (forced for four images): flat images by state look-back with tickets
