@@ -583,6 +583,9 @@ __device__ __forceinline__ void encode_step(LDS& L, const LaneConst& C, uint32_t
         }
     }
     // ---- common case: chunk lengths 1 and 2 only.  offset = #chunks below + #LUMA chunks below ----
+#ifdef QOIMI_ENC_SKIP_EMPTY_TAIL
+    if (any != 0ull)                                           // (experiment: the long-chunk body above has staged everything in content dense in QOI_OP_RGB / QOI_OP_RGBA)
+#endif
     {
         const u64 two = __ballot(word_is_two(w)) & any;
         const uint32_t off = count_below_from(two, count_below_from(any, vbase));
