@@ -75,3 +75,49 @@ def test_encoder_keeps_its_pixel_prefetch(ch):
     waits = [int(m.group(1)) for l in dis[name[0]] for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m]
     deep = [w for w in waits if w >= 3]
     assert len(deep) >= 16, (len(waits), sorted(set(waits)))          # two groups of eight steps in the pipelined loop
+
+
+def _written_vgprs(line: str):
+    """VGPR numbers an instruction line writes (its first operand where the mnemonic has a destination) - good enough for the check below."""
+    import re
+    m = re.match(r"^(\S+)\s+(.*)$", line)
+    if not m:
+        return set()
+    op, rest = m.group(1), m.group(2)
+    if op.startswith(("s_", "ds_write", "ds_or_b", "buffer_store", "global_store", "flat_store", "scratch_store", "v_cmp", "v_cmpx", "v_nop", "v_readlane", "v_readfirstlane")) \
+            or op in ("ds_wrxchg_rtn_b32",):
+        return set()
+    first = rest.split(",")[0].strip()
+    r = re.match(r"^v(\d+)$", first)
+    if r:
+        return {int(r.group(1))}
+    r = re.match(r"^v\[(\d+):(\d+)\]$", first)
+    if r:
+        return set(range(int(r.group(1)), int(r.group(2)) + 1))
+    return set()
+
+
+def test_exchange_results_are_not_overwritten_in_flight():
+    """`ds_wrxchg_rtn_b32` sits in asm blocks: the compiler does not know that the instruction writes its result LATER, when the LDS
+    answers, and is free to hand the result register to something else behind the block if the C++ side drops the value (round 5: the
+    state look-back's first build lost half of an address that way - a memory fault on the GPU, 152 parity tests green before it).
+    Held statically: in every kernel of the built library, between an exchange and the next `s_waitcnt` that waits for LDS results
+    no instruction may write the exchange's result register (another exchange into the same register excepted: LDS results return in order)."""
+    import re
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(LIB) and os.path.exists(objdump)):
+        pytest.skip("needs the built library and llvm-objdump")
+    dis = KR.disassembly(LIB, objdump)
+    seen = 0
+    for name, lines in dis.items():
+        for i, l in enumerate(lines):
+            m = re.match(r"^ds_wrxchg_rtn_b32\s+v(\d+),", l)
+            if not m:
+                continue
+            seen += 1
+            dest = int(m.group(1))
+            for l2 in lines[i + 1:i + 400]:
+                if re.match(r"^s_waitcnt\b.*lgkmcnt\(0\)", l2) or l2.startswith(("s_endpgm", "s_branch", "s_cbranch", "s_setpc")):
+                    break                                     # waited for (or control leaves the straight line: not followed)
+                assert dest not in _written_vgprs(l2), (name, l, l2)
+    assert seen >= 20, seen                                   # the encoder's probes and replays are there at all
