@@ -77,8 +77,8 @@ def measured_traffic(kernel_prefix: str, scale: float = 1.0):
     except OSError:
         return None, None
     for name, k in doc["kernels"].items():
-        # the exact instantiation, template arguments included (files of earlier rounds name it without the round-5 argument)
-        if name in (kernel_prefix, kernel_prefix.replace(", false>", ">")) and "FETCH_SIZE_KB" in k and "WRITE_SIZE_KB" in k:
+        # the exact instantiation, template arguments included (files of earlier sessions name it without the round-5 arguments)
+        if name in (kernel_prefix, kernel_prefix.replace(", false, false>", ", false>"), kernel_prefix.replace(", false, false>", ">")) and "FETCH_SIZE_KB" in k and "WRITE_SIZE_KB" in k:
             nbytes = (k["FETCH_SIZE_KB"] * doc["read_correction"] + k["WRITE_SIZE_KB"]) * 1024.0 * scale
             note = "" if scale == 1.0 else f", x {scale:g}: the PMC passes ran {doc.get('frames', '?')} frames per launch"
             return nbytes, (f"profiles/{os.path.basename(TRAFFIC_FILE)} (an earlier session's PMC passes, build {doc.get('commit', 'not recorded')}; "
@@ -627,7 +627,7 @@ def main() -> None:
                 f_prof = float(json.load(open(TRAFFIC_FILE)).get("frames", F))
             except (OSError, ValueError):
                 f_prof = float(F)
-            traffic, traffic_src = measured_traffic("qoimi::enc_sets<4, 1, 1, false>", frames_per_launch / f_prof)
+            traffic, traffic_src = measured_traffic("qoimi::enc_sets<4, 1, 1, false, false>", frames_per_launch / f_prof)
         roof = lambda kernel, nbytes, ms, **kw: dict({"bound": "hbm", "kernel": kernel, "achieved": round(gbs(nbytes, ms), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                       "frac": round(gbs(nbytes, ms) / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 4)}, **kw)
         out = {

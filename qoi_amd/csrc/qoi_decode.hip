@@ -1092,7 +1092,9 @@ struct PipeReaderT {
     // DESC form.  wave_base: the stream of the wavefront's first segment; wave_bytes: from there to the end of the 16-byte granule
     // that holds the last byte of the last stream a lane of the wavefront reads (both wave-uniform); lane_ok: the lane reads at all.
     // Returns false for a lane whose stream the descriptor does not reach.
-    __device__ __forceinline__ bool init_desc(uint32_t ring_addr, const uint8_t* wave_base, unsigned long long wave_bytes, const uint8_t* stream, uint32_t pos0, bool lane_ok) {
+    // lane_end: one past the 16-byte granule that holds the last byte the lane may read (its stream's end).
+    __device__ __forceinline__ bool init_desc(uint32_t ring_addr, const uint8_t* wave_base, unsigned long long wave_bytes, const uint8_t* stream, uint32_t pos0, bool lane_ok,
+                                              const uint8_t* lane_end) {
         ring = ring_addr;
         const unsigned long long nrec = wave_bytes < 0xFFFFFFE0ull ? wave_bytes : 0xFFFFFFE0ull;
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)wave_base, 0, (int)(uint32_t)nrec, 0x00020000);
@@ -1100,7 +1102,9 @@ struct PipeReaderT {
         const uint8_t* p = stream + pos0;
         const uint8_t* a = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)31);
         const unsigned long long d = (unsigned long long)(a - wave_base);
-        const bool reach = lane_ok && a >= wave_base && d < nrec;          // (what lies behind nrec reads as zeros: behind every stream of the wavefront)
+        // the lane's WHOLE read extent must lie inside the descriptor: a stream that begins just below a capped descriptor's end would
+        // read zeros behind it (zeros parse as QOI_OP_INDEX chunks, the lane would "synchronise" on them) - it takes MODE 1 instead
+        const bool reach = lane_ok && a >= wave_base && lane_end >= a && d + (unsigned long long)(lane_end - a) <= nrec;
         boff = reach ? (uint32_t)d : idle;
         aoff = pos0 - (uint32_t)(p - a);
         u32x4 v[RD / 4u];
@@ -1263,8 +1267,11 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         const int first = __builtin_ctzll(hv);
         const uintptr_t first_stream = ((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)reinterpret_cast<uintptr_t>(my_stream), first)) |
                                        ((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(reinterpret_cast<uintptr_t>(my_stream) >> 32), first) << 32);
-        const bool reach = R.init_desc(lds_addr_of(&s_ring[wave][lane]), reinterpret_cast<const uint8_t*>(first_stream), (unsigned long long)(last_end - first_stream),
-                                       my_stream, t0, have);
+        // (base: the first stream aligned DOWN to 32 bytes - the lanes' 32-byte aligned requests then never start in front of it, whatever
+        // the alignment of the caller's streams)
+        const uintptr_t wave_base = first_stream & ~(uintptr_t)31;
+        const bool reach = R.init_desc(lds_addr_of(&s_ring[wave][lane]), reinterpret_cast<const uint8_t*>(wave_base), (unsigned long long)(last_end - wave_base),
+                                       my_stream, t0, have, reinterpret_cast<const uint8_t*>(my_end));
         ParseState s; parse_init(s, t0);
         if (from_start) { s.p1 = s.p2 = s.p3 = s.p4 = t0; }
         uint32_t m = t0;
