@@ -1605,7 +1605,12 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         g.set_slabs = p.gen_slabs; g.set_px = p.gen_slabs * kEncSlabPx;
         g.sets_per_image = (p.spi + p.gen_slabs - 1u) / p.gen_slabs;
         g.n_units = ((g.sets_per_image + 3u) / 4u) * p.n_images;
-        hipLaunchKernelGGL((enc_sets<CH, PROBE, 2, MIXED>), dim3(g.n_units < small || g.lookback == 2 ? g.n_units : small), dim3(256), 0, st, g);
+        // (grid: 1/32 of the units when the call is not expected to hold flagged images - the launch then finds nothing and costs what its
+        // grid is - and 1/p.gen_grid_div of them when the context's previous batch did: a loop over few long-lived workgroups is the slow
+        // way to run this kernel, EXPERIMENTS.md)
+        uint32_t grid2 = small;
+        if (p.gen_grid_div) { const uint32_t want = g.n_units / p.gen_grid_div; if (want > grid2) grid2 = want; }
+        hipLaunchKernelGGL((enc_sets<CH, PROBE, 2, MIXED>), dim3(g.n_units < grid2 || g.lookback == 2 ? g.n_units : grid2), dim3(256), 0, st, g);
         tm->mark(kT_enc_slabs_generic, st);
         return;
     }

@@ -109,6 +109,7 @@ struct qoimi_ctx {
     uint32_t test_spin_bound = 0;       // env QOIMI_TEST_SPIN_BOUND (tests): polls before a placement wait gives up
     bool worst_case_buffer = false;     // env QOIMI_ENCODE_WORST_CASE_BUFFER=1 (read once, at creation): qoi_encode returns the reference's worst-case allocation
     int enc_gen_slabs = (int)kEncGenSetSlabs;   // env QOIMI_ENC_GEN_SLABS (1..8): slabs per set of the pass over flagged images
+    int enc_gen_grid_div = 4;           // env QOIMI_ENC_GEN_GRID_HOT: the pass over flagged images runs with 1/N of its units when the previous batch held flagged images
     int enc_g2 = 1;                     // env QOIMI_ENC_G2=0: flagged images (flat content) go through the summary passes instead of the state look-back (ENTRY 2)
     uint32_t enc_epoch = 0;             // encode call number: the tag of the state look-back's granules
     void* g2_zeroed_at = nullptr; size_t g2_zeroed_bytes = 0; unsigned g2_zeroed_gen = 0;     // where those granules were last zeroed
@@ -189,6 +190,8 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_TREE_TICKET")) c->enc_tree_ticket = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_ADAPT")) c->enc_adapt = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_G2")) c->enc_g2 = atoi(e) != 0;
+    if (const char* e = getenv("QOIMI_ENC_GEN_GRID_HOT")) { const int v = atoi(e); if (v >= 1) c->enc_gen_grid_div = v; }
+    c->host_word[13] = 0u;
     if (const char* e = getenv("QOIMI_ENC_GEN_SLABS")) { const int v = atoi(e); if (v >= 1 && v <= (int)kEncMaxSetSlabs) c->enc_gen_slabs = v; }
     if (const char* e = getenv("QOIMI_TEST_SPIN_BOUND")) { const long v = atol(e); if (v >= 1) c->test_spin_bound = (uint32_t)v; }
     if (const char* e = getenv("QOIMI_ENCODE_WORST_CASE_BUFFER")) c->worst_case_buffer = atoi(e) != 0;
@@ -399,6 +402,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     // of fewer sets), handed out on the device (pool_take).  The 1024-frame 4K shard: 0.34 GB instead of 42.5 GB.
     p.pool = lookback ? 1 : 0;
     p.gen_slabs = (uint32_t)c->enc_gen_slabs;
+    p.gen_grid_div = (c->enc_adapt && n_images >= 8 && c->host_word[13] != 0u) ? (uint32_t)c->enc_gen_grid_div : 0u;
     const size_t S_gen = (size_t)p.n_images * ((p.spi + p.gen_slabs - 1u) / p.gen_slabs);
     if (lookback) {
         size_t slots = (S + 63u) & ~(size_t)63u;
@@ -460,6 +464,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     c->timer.mark(kT_enc_total, st);
     if (c->enc_adapt && place == 1) {                       // what this batch's streams look like, for the next call's set size (see above)
         if (hipMemcpyAsync(&c->host_word[12], d_stream_len, sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess) c->enc_hint_npx = p.npx;
+        (void)hipMemcpyAsync(&c->host_word[13], p.any_generic, sizeof(uint32_t), hipMemcpyDeviceToHost, st);    // ... and whether it held flagged (flat) images: the grid of the next call's pass over them
     }
     c->last_enc.px = d_pixels; c->last_enc.ps = pixel_stride; c->last_enc.desc = *desc; c->last_enc.n = n_images;
     c->last_enc.out = d_streams; c->last_enc.os = stream_stride; c->last_enc.len = d_stream_len; c->last_enc.st = stream; c->last_enc.valid = true;

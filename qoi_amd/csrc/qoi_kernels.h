@@ -72,6 +72,7 @@ struct EncParams {
     uint8_t only_flagged;    // set by the launcher: this pass handles images with need_generic[img] != 0 only
     uint32_t n_units;        // set by the launcher: (image, four consecutive sets) work units
     uint32_t spread;         // 1 (default): the wavefronts of a workgroup serve consecutive images (env QOIMI_ENC_SPREAD=0: all four take tickets of one image)
+    uint32_t gen_grid_div;   // 0: the pass over flagged images runs with the small grid; N: with 1/N of its units (the previous batch of the context held flagged images)
     uint32_t gen_slabs;      // slabs per set of the pass over flagged images (kEncGenSetSlabs; env QOIMI_ENC_GEN_SLABS)
     uint32_t spin_bound;     // polls a placement wait makes before it gives up (err bit 0): 2^22 with tickets (start order), 2^15 for the tree by workgroup index
     uint32_t pipe;           // 1 (env QOIMI_ENC_PIPE, with persist): a wavefront asks for its next set's first loads in front of its current set's placement
