@@ -109,7 +109,7 @@ struct qoimi_ctx {
     uint32_t test_spin_bound = 0;       // env QOIMI_TEST_SPIN_BOUND (tests): polls before a placement wait gives up
     bool worst_case_buffer = false;     // env QOIMI_ENCODE_WORST_CASE_BUFFER=1 (read once, at creation): qoi_encode returns the reference's worst-case allocation
     int enc_gen_slabs = (int)kEncGenSetSlabs;   // env QOIMI_ENC_GEN_SLABS (1..8): slabs per set of the pass over flagged images
-    int enc_gen_grid_div = 4;           // env QOIMI_ENC_GEN_GRID_HOT: the pass over flagged images runs with 1/N of its units when the previous batch held flagged images
+    int enc_gen_grid_div = 1;           // (32 / 4 / 1: uiflat 21.3 / 21.2 / 20.4 ms, sprite_alpha 11.0 / 11.1 / 10.1 per 512, profiles/r05_s14_enc_grid.txt) env QOIMI_ENC_GEN_GRID_HOT: the pass over flagged images runs with 1/N of its units when the previous batch held flagged images
     int enc_g2 = 1;                     // env QOIMI_ENC_G2=0: flagged images (flat content) go through the summary passes instead of the state look-back (ENTRY 2)
     uint32_t enc_epoch = 0;             // encode call number: the tag of the state look-back's granules
     void* g2_zeroed_at = nullptr; size_t g2_zeroed_bytes = 0; unsigned g2_zeroed_gen = 0;     // where those granules were last zeroed

@@ -23,7 +23,7 @@ px = torch.empty(ps, dtype=torch.uint8, device="cuda")
 st = torch.empty(ss, dtype=torch.uint8, device="cuda")
 out = torch.empty(ps, dtype=torch.uint8, device="cuda")
 lens = torch.zeros(16, dtype=torch.int32, device="cuda")
-ctx.synth_frames(synth.KIND_ID["photo"], synth.DEFAULT_SEED, 0, 1, w, h, px.data_ptr(), ps, stream)
+ctx.synth_frames(synth.KIND_ID[os.environ.get("KIND", "photo")], synth.DEFAULT_SEED, 0, 1, w, h, px.data_ptr(), ps, stream)
 ctx.encode_batch(px.data_ptr(), ps, desc, 1, st.data_ptr(), ss, lens.data_ptr(), stream)
 ctx.encode_status(stream)
 n = [int(lens[0].item())]
