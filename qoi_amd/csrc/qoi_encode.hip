@@ -887,7 +887,7 @@ __device__ __forceinline__ void pool_give(const EncParams& p, uint32_t id, uint3
 //   * the set first walks its own pixels for "the last edge pixel per hash slot" and its last edge (what enc_slab_summary computed
 //     for every slab in a pass of its own: every pixel read from HBM twice) and publishes that as 65 eight-byte granules
 //     (slot k: word | valid << 32, granule 64: last edge + 1), state LOCAL;
-//   * then it looks back over the sets in front of it, four at a time: a slot takes the nearest valid LOCAL word, or whatever an
+//   * then it looks back over the sets in front of it, eight at a time: a slot takes the nearest valid LOCAL word, or whatever an
 //     INCLUSIVE granule says (the table as it stands behind that set); the last edge likewise.  Every granule carries its state and
 //     the call's epoch ("the data is the flag", qoi_dev.h): nothing to zero between calls, no fences, a reader may see a set's
 //     granules half LOCAL, half INCLUSIVE - each slot resolves on its own;
@@ -954,29 +954,34 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
     const bool loc_valid = loc_w != sent;
     u64* const mine = rec_img + (size_t)set * 65u;
     const u64 tag = g2_tag(p);
-    granule_store(&mine[lane], (u64)(loc_valid ? loc_w : 0u) | ((u64)(loc_valid ? 1u : 0u) << 32) | tag | kG2Local);
-    if (lane == 0) granule_store(&mine[64], (u64)(uint32_t)(le_loc + 1) | tag | kG2Local);
+    // (a set that wrote ALL 64 slots itself - most sets of photograph-like content - leaves a table that owes nothing to the sets in front
+    // of it: its first publication is INCLUSIVE already, and the look-backs of the sets behind it end there)
+    const bool self_incl = lanes_where(loc_valid) == ~0ull && le_loc >= 0;
+    const u64 first_state = self_incl ? kG2Incl : kG2Local;
+    granule_store(&mine[lane], (u64)(loc_valid ? loc_w : 0u) | ((u64)(loc_valid ? 1u : 0u) << 32) | tag | first_state);
+    if (lane == 0) granule_store(&mine[64], (u64)(uint32_t)(le_loc + 1) | tag | first_state);
     // ---- the sets in front: nearest valid word per slot, nearest edge --------------------------------------------------
     uint32_t ent_w = 0u; bool ent_valid = false, slot_done = loc_valid;      // (a slot this set wrote needs no entry word for the inclusive table - but the ENCODE does: see below)
     int le_ent = -1; bool le_done = false;
     // the encoder needs the entry word of EVERY slot (an edge pixel is compared with what its slot held BEFORE the set), so all 64 are looked up
     slot_done = false;
     uint32_t spins = 0;
-    for (int j0 = (int)set - 1; j0 >= 0 && (lanes_where(!slot_done) != 0ull || !le_done); j0 -= 4) {
+    constexpr int kWin = 8;                                    // sets looked at per poll (one frame alone: every set of the image is in flight, the walk back is long)
+    for (int j0 = (int)set - 1; j0 >= 0 && (lanes_where(!slot_done) != 0ull || !le_done); j0 -= kWin) {
         for (;;) {
-            u64 gw[4], gl[4];
+            u64 gw[kWin], gl[kWin];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < kWin; ++k) {
                 const int j = j0 - k;
                 gw[k] = j >= 0 ? granule_load(&rec_img[(size_t)j * 65u + lane]) : (tag | kG2Incl);       // in front of set 0: the zeroed table, no edge (qoi.h:393)
                 gl[k] = j >= 0 ? granule_load(&rec_img[(size_t)j * 65u + 64u]) : (tag | kG2Incl);
             }
             bool all = true;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) all = all && g2_ready(p, gw[k]) && g2_ready(p, gl[k]);
+            for (int k = 0; k < kWin; ++k) all = all && g2_ready(p, gw[k]) && g2_ready(p, gl[k]);
             if (lanes_where(!all) == 0ull) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < kWin; ++k) {
                     const bool incl = (gw[k] >> 62) == 2ull, v = ((gw[k] >> 32) & 1ull) != 0ull;
                     if (!slot_done && (incl || v)) { ent_w = v ? (uint32_t)gw[k] : 0u; ent_valid = v; slot_done = true; }
                     const bool incl_l = (gl[k] >> 62) == 2ull; const int lv = (int)(uint32_t)gl[k] - 1;
@@ -1039,7 +1044,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) { in.warm[k] = pre->warm[k]; in.warm_prev[k] = pre->warm_prev[k]; }
-    } else if (ENTRY == 1) {
+    } else if (ENTRY == 1 || ENTRY == 3) {
         if (lo != 0u) {                                        // (a set begins on a slab boundary: lo >= 1024, all of these lie inside the image)
             const uint8_t* __restrict__ q = pix + (size_t)(lo + lane) * (size_t)CH;
 #pragma unroll
@@ -1073,10 +1078,21 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     asm volatile("" : "+v"(C.tbase));                          // keep in a VGPR
     int last_edge = -1;
     bool run_only = false;                                     // ENTRY 2: the set holds no edge at all - its bytes are run bytes, known without a second walk
+    bool fell_back = false;                                    // ENTRY 3: the look-back window did not do, the set took the state look-back
     if (ENTRY == 1) {
         if (!warm_entry_state<CH, PROBE>(pix, lo, lane, L, C.tbase, in, last_edge)) {
             if (lane == 0) { atomicOr(&p.need_generic[img], 1u); atomicOr(p.any_generic, 1u); }
             return;
+        }
+    } else if (ENTRY == 3) {
+        // ONE pass for every kind of content (experiment, QOIMI_ENC_UNI=1): a set whose look-back window determines its entry state takes it
+        // from there as ever and leaves the table as it stands BEHIND it as INCLUSIVE granules; a set whose window does not (flat stretches)
+        // walks its own pixels, publishes, looks back over the sets in front of it (g2_entry_state) - no image is flagged, no second launch.
+        if (!warm_entry_state<CH, PROBE>(pix, lo, lane, L, C.tbase, in, last_edge)) {
+            if (PROBE == 1) {
+                if (!g2_entry_state<CH>(p, pix, n, lo, hi, p.g2_rec + (size_t)I.set_base * 65u, set, lane, L, C.tbase, last_edge, run_only)) return;
+            }
+            fell_back = true;
         }
     } else if (ENTRY == 2) {
         if (PROBE == 1) {
@@ -1125,7 +1141,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     };
 
     uint32_t g = 0;
-    if (ENTRY == 2 && run_only) {
+    if ((ENTRY == 2 || ENTRY == 3) && run_only) {
         // Every pixel of the set repeats the pixel in front of it (constant frames, letterbox bars, blank pages): pixel i, d pixels behind
         // the last edge, carries 0xFD where d is a multiple of 62 (qoi.h:417-421) and nothing else - but the set's last pixel, which
         // closes its run if the image ends with it or the pixel behind it is an edge (qoi.h:425-428).  No second walk over the pixels.
@@ -1190,6 +1206,17 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     const uint32_t set_bytes = spilled + spos;
     PHASE_MARK(2);
 
+    if (ENTRY == 3 && PROBE == 1 && !fell_back) {
+        // the table as it stands behind this set, for a set further on whose look-back window will not do: every slot is known here (the
+        // window filled all 64, or the image's start is in reach), the last edge follows from the distance counter
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t tw = L.table[lane];
+        const int le_end = (int)hi + 63 - (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)ccp);
+        u64* const mine = p.g2_rec + ((size_t)I.set_base + set) * 65u;
+        const u64 tag = g2_tag(p);
+        granule_store(&mine[lane], (u64)tw | (1ull << 32) | tag | kG2Incl);
+        if (lane == 0) granule_store(&mine[64], (u64)(uint32_t)(le_end + 1) | tag | kG2Incl);
+    }
     if (PIPE) {
         // the NEXT set of this wavefront: its ticket and its first loads go out here, in front of this set's placement
         if (has_next && __hip_atomic_load((gu32*)&p.need_generic[next_img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
@@ -1582,8 +1609,14 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         // (tree placement takes its sets by workgroup index and waits for lower-numbered ones: one workgroup per unit, no grid-stride loop)
         bool piped = false;
         if constexpr (!MIXED && PROBE == 1) {
+            if (p.uni && p.lookback != 0 && p.g2_rec != nullptr) {          // one pass, a set falls back to the state look-back by itself
+                hipLaunchKernelGGL((enc_sets<CH, PROBE, 3, MIXED>), dim3(p.n_units), dim3(256), 0, st, p);
+                piped = true;
+            }
+        }
+        if constexpr (!MIXED && PROBE == 1) {
             // experiment (QOIMI_ENC_PIPE=1 with QOIMI_ENC_PERSIST=N): each wavefront's next set asked for in front of its current set's placement
-            if (p.pipe && p.persist && p.n_units > p.persist && p.lookback == 1 && p.use_ticket && p.spread) {
+            if (!piped && p.pipe && p.persist && p.n_units > p.persist && p.lookback == 1 && p.use_ticket && p.spread) {
                 hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, MIXED, true>), dim3(p.persist), dim3(256), 0, st, p);
                 piped = true;
             }
@@ -1597,6 +1630,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         small = 0xFFFFFFFFu;
     }
     const bool first_lookback = p.lookback != 0;
+    if constexpr (!MIXED && PROBE == 1) if (warm && first_lookback && p.g2_rec != nullptr && p.uni) return;       // ENTRY 3 did it all
     if constexpr (!MIXED && PROBE == 1) if (warm && first_lookback && p.g2_rec != nullptr) {
         // The images the first pass gave up on (flat content), by state look-back over their sets (ENTRY 2, g2_entry_state): one launch
         // that returns at once when nothing was flagged - no summary pass, no scans.

@@ -110,6 +110,7 @@ struct qoimi_ctx {
     bool worst_case_buffer = false;     // env QOIMI_ENCODE_WORST_CASE_BUFFER=1 (read once, at creation): qoi_encode returns the reference's worst-case allocation
     int enc_gen_slabs = (int)kEncGenSetSlabs;   // env QOIMI_ENC_GEN_SLABS (1..8): slabs per set of the pass over flagged images
     int enc_gen_grid_div = 1;           // (32 / 4 / 1: uiflat 21.3 / 21.2 / 20.4 ms, sprite_alpha 11.0 / 11.1 / 10.1 per 512, profiles/r05_s14_enc_grid.txt) env QOIMI_ENC_GEN_GRID_HOT: the pass over flagged images runs with 1/N of its units when the previous batch held flagged images
+    int enc_uni = 0;                    // env QOIMI_ENC_UNI=1 (experiment): one encode pass, sets fall back to the state look-back one by one
     int enc_g2 = 1;                     // env QOIMI_ENC_G2=0: flagged images (flat content) go through the summary passes instead of the state look-back (ENTRY 2)
     uint32_t enc_epoch = 0;             // encode call number: the tag of the state look-back's granules
     void* g2_zeroed_at = nullptr; size_t g2_zeroed_bytes = 0; unsigned g2_zeroed_gen = 0;     // where those granules were last zeroed
@@ -190,6 +191,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_TREE_TICKET")) c->enc_tree_ticket = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_ADAPT")) c->enc_adapt = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_G2")) c->enc_g2 = atoi(e) != 0;
+    if (const char* e = getenv("QOIMI_ENC_UNI")) c->enc_uni = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_GEN_GRID_HOT")) { const int v = atoi(e); if (v >= 1) c->enc_gen_grid_div = v; }
     c->host_word[13] = 0u;
     if (const char* e = getenv("QOIMI_ENC_GEN_SLABS")) { const int v = atoi(e); if (v >= 1 && v <= (int)kEncMaxSetSlabs) c->enc_gen_slabs = v; }
@@ -430,8 +432,10 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         // call's number instead of being zeroed) - or, for order-free calls and the order-independent probe, by the summary passes
         // (per slab 2 x (256 B table + 8 B valid + 4 B position): 4.3 GB for the 1024-frame 4K shard)
         const bool g2 = lookback && p.probe_xchg && p.warm && c->enc_g2;
-        p.g2_rec = w.take<u64>(g2 ? S_gen * 65u : 0);
-        g2_bytes = g2 ? S_gen * 65u * sizeof(u64) : 0;
+        p.uni = (g2 && c->enc_uni) ? 1u : 0u;
+        const size_t g2_sets = p.uni ? S : S_gen;              // (one pass: a record per set of that pass)
+        p.g2_rec = w.take<u64>(g2 ? g2_sets * 65u : 0);
+        g2_bytes = g2 ? g2_sets * 65u * sizeof(u64) : 0;
         if (!g2) p.g2_rec = nullptr;
         const size_t Tt = g2 ? 0 : T, Gt = g2 ? 0 : G;
         p.sum_tab = w.take<uint32_t>(Tt * 64); p.sum_valid = w.take<u64>(Tt); p.sum_le = w.take<int>(Tt);

@@ -75,6 +75,7 @@ struct EncParams {
     uint32_t gen_grid_div;   // 0: the pass over flagged images runs with the small grid; N: with 1/N of its units (the previous batch of the context held flagged images)
     uint32_t gen_slabs;      // slabs per set of the pass over flagged images (kEncGenSetSlabs; env QOIMI_ENC_GEN_SLABS)
     uint32_t spin_bound;     // polls a placement wait makes before it gives up (err bit 0): 2^22 with tickets (start order), 2^15 for the tree by workgroup index
+    uint32_t uni;            // 1 (env QOIMI_ENC_UNI): one pass (enc_sets<ENTRY 3>) - sets whose look-back window does not do take the state look-back themselves; g2_rec holds a record per set of the FIRST pass
     uint32_t pipe;           // 1 (env QOIMI_ENC_PIPE, with persist): a wavefront asks for its next set's first loads in front of its current set's placement
     uint32_t persist;        // 0: one workgroup per unit; else the first pass runs at most this many workgroups (env QOIMI_ENC_PERSIST, a test knob)
     // workspace

@@ -481,6 +481,9 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_PERSIST": "3", "QOIMI_ENC_LOOKBACK": "1"},  # ... in the grid-stride loop
     {"QOIMI_ENC_PIPE": "1", "QOIMI_ENC_PERSIST": "3", "QOIMI_ENC_LOOKBACK": "1"},   # experiment: a wavefront asks for its next set's look-back window in front of its current set's placement
     {"QOIMI_ENC_PIPE": "1", "QOIMI_ENC_PERSIST": "1", "QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "1"},
+    {"QOIMI_ENC_UNI": "1"},                               # experiment: ONE encode pass, a set whose look-back window does not do takes the state look-back by itself
+    {"QOIMI_ENC_UNI": "1", "QOIMI_ENC_LOOKBACK": "1"},
+    {"QOIMI_ENC_UNI": "1", "QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "1"},
     {"QOIMI_ENC_G2": "0"},                                # flagged (flat) images through the summary passes (enc_slab_summary + scans + ENTRY 0) instead of the state look-back
     {"QOIMI_ENC_G2": "0", "QOIMI_ENC_LOOKBACK": "1"},
     {"QOIMI_ENC_LOOKBACK": "1"},                          # look-back placement (forced for four images): flat images by state look-back with tickets
@@ -722,7 +725,7 @@ def test_decode_repair_loop_is_bounded(api, oracle, rounds):
 @pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_WARM": "0"}, {"QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_SET_SLABS": "4"},
                                  {"QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_LOOKBACK": "2"}, {"QOIMI_ENC_LOOKBACK": "1"},
                                  {"QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "4"}, {"QOIMI_ENC_G2": "0"}, {"QOIMI_ENC_G2": "0", "QOIMI_ENC_LOOKBACK": "2"},
-                                 {"QOIMI_ENC_TREE_TICKET": "1", "QOIMI_ENC_LOOKBACK": "2"}])
+                                 {"QOIMI_ENC_TREE_TICKET": "1", "QOIMI_ENC_LOOKBACK": "2"}, {"QOIMI_ENC_UNI": "1"}, {"QOIMI_ENC_UNI": "1", "QOIMI_ENC_LOOKBACK": "2"}])
 def test_flat_frames_byte_identical(api, oracle, env):
     """Flat UI frames go through the generic entry-state path (per-slab summaries + scans).  Frame 60 of this sweep was
     encoded three bytes too long by every path until round 2: a 64-bit lane mask lost its upper half (sign extension of
