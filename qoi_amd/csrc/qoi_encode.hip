@@ -1012,6 +1012,13 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
     return true;
 }
 
+
+// The first set of a call that finds a flat stretch in front of it says so to the HOST: the call's number into a pinned word, read (without
+// a wait) when the context's next call is set up - a hint, no more: whichever pass that call takes, its streams are the same bytes.
+__device__ __forceinline__ void leave_hint(const EncParams& p) {
+    if (p.host_hint) __hip_atomic_store(p.host_hint, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int CH, int PROBE, int ENTRY, bool MIXED, bool PIPE = false, class LDS>
 __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uint32_t set, uint32_t lane, LDS& L,
                                            SetPre* pre = nullptr, bool use_pre = false, bool has_next = false, uint32_t next_img = 0u) {
@@ -1081,7 +1088,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     bool fell_back = false;                                    // ENTRY 3: the look-back window did not do, the set took the state look-back
     if (ENTRY == 1) {
         if (!warm_entry_state<CH, PROBE>(pix, lo, lane, L, C.tbase, in, last_edge)) {
-            if (lane == 0) { atomicOr(&p.need_generic[img], 1u); atomicOr(p.any_generic, 1u); }
+            if (lane == 0) { atomicOr(&p.need_generic[img], 1u); if (atomicOr(p.any_generic, 1u) == 0u) leave_hint(p); }
             return;
         }
     } else if (ENTRY == 3) {
@@ -1093,6 +1100,7 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
                 if (!g2_entry_state<CH>(p, pix, n, lo, hi, p.g2_rec + (size_t)I.set_base * 65u, set, lane, L, C.tbase, last_edge, run_only)) return;
             }
             fell_back = true;
+            if (lane == 0 && __hip_atomic_load(p.any_generic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && atomicOr(p.any_generic, 1u) == 0u) leave_hint(p);
         }
     } else if (ENTRY == 2) {
         if (PROBE == 1) {

@@ -75,7 +75,7 @@ struct EncParams {
     uint32_t gen_grid_div;   // 0: the pass over flagged images runs with the small grid; N: with 1/N of its units (the previous batch of the context held flagged images)
     uint32_t gen_slabs;      // slabs per set of the pass over flagged images (kEncGenSetSlabs; env QOIMI_ENC_GEN_SLABS)
     uint32_t spin_bound;     // polls a placement wait makes before it gives up (err bit 0): 2^22 with tickets (start order), 2^15 for the tree by workgroup index
-    uint32_t uni;            // 1 (env QOIMI_ENC_UNI): one pass (enc_sets<ENTRY 3>) - sets whose look-back window does not do take the state look-back themselves; g2_rec holds a record per set of the FIRST pass
+    uint32_t uni;            // 1 (env QOIMI_ENC_UNI=1, or a small call behind one that held flat stretches): one pass (enc_sets<ENTRY 3>) - sets whose look-back window does not do take the state look-back themselves; g2_rec holds a record per set of the FIRST pass
     uint32_t pipe;           // 1 (env QOIMI_ENC_PIPE, with persist): a wavefront asks for its next set's first loads in front of its current set's placement
     uint32_t persist;        // 0: one workgroup per unit; else the first pass runs at most this many workgroups (env QOIMI_ENC_PERSIST, a test knob)
     // workspace
@@ -90,6 +90,7 @@ struct EncParams {
     uint32_t* err;       // liveness-bound flag               -- zeroed before every launch
     uint32_t* need_generic;  // [n_images] image needs the E1/E2 path  -- zeroed before every launch
     uint32_t* any_generic;   // [1]                                    -- zeroed before every launch
+    uint32_t* host_hint;     // pinned HOST word (may be null): the first set of a call whose look-back window does not do leaves the call's number there - the next small call's choice of pass
     uint8_t* scratch;    // order-free mode: [n_images*sets_per_image][set_stride] parked sets; look-back mode (pool = 1): [pool_slots + 1][set_stride],
                          // the spilled pieces of the sets that hold a slot (the last slot is the emergency slot of an exhausted pool: err bit 1)
     u64* pool_map;       // [pool_slots / 64 * kEncPoolMapStride] look-back mode: bit set = slot taken      -- zeroed before every launch

@@ -27,4 +27,4 @@ for _ in range(reps):
     c.decode_batch(st.data_ptr(), ss, sizes, [desc] * F, 4, out.data_ptr(), ps, s)
 prof = c.get_profile(s)
 print(os.path.basename(os.path.dirname(api.LIB_PATH)), {k: round(v[0] / reps, 3) for k, v in prof.items() if v[1] and v[0] / reps > 0.02},
-      'rounds', c.decode_stats()['rounds'], 'equal', bool(torch.equal(out, px)))
+      'rounds', c.decode_stats()['rounds'], 'equal', bool(torch.equal(out, px)), 'workspace GB', round(c.workspace_bytes()['decode'] / 1e9, 2), 'streams GB', round(sum(sizes) / 1e9, 2))
