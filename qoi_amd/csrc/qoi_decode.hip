@@ -2029,10 +2029,11 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     const uint32_t limit = im.npx;
     const uint32_t px_first = have ? p.px_off[q] : 0u;
     // FLAT: the lane's run descriptors (8 bytes each: start pixel, pixels) and the run in the making
-    // (the other images, desc_all: a QOI_OP_RUN of twelve pixels or more leaves a descriptor too - one per chunk, nothing pending between
-    // steps - in the segment's slot of the symbolic summaries, which are dead once the entry states stand: kSummaryDescs of them)
+    // (the other images, desc_all: QOI_OP_RUNs of twelve pixels or more, and the runs that follow them directly, leave a descriptor too -
+    // in the segment's slot of the symbolic summaries, which are dead once the entry states stand: kSummaryDescs of them)
     uint4* const my_desc = FLAT ? p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap : reinterpret_cast<uint4*>(p.summary + (size_t)(have ? q : 0u) * 65u);
     uint32_t n_desc = 0u, span_start = px_first, span_len = 0u;     // FLAT: the pixels since the value last changed: [span_start, span_start + span_len), all of them px
+    uint32_t span_px = 0u;                                          // the other images: the span of long runs in the making holds this pixel
     RecSource S; S.init(p, blockIdx.x, lane, have && px_first < limit ? p.rec_gran[q] : 0u);
 #if QOIMI_REC16
     __shared__ uint32_t s_lut16[256];
@@ -2188,16 +2189,21 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                     if (rem) {
                         if (rem >= kLongRun) {
                             if (p.desc_all) {
-                                // sprites, screenshots with photographs in them: the run's head up to a 4-pixel boundary through the ring, the ring
-                                // out, the aligned part as a descriptor for dec_expand_runs (the lane wrote it in 16-byte pieces of its own: fifteen
-                                // stores for a run of 62 while the other 63 lanes wait), the tail through the ring
-                                while ((W.ppos & 3u) != 0u && rem) { W.put(px); --rem; }
-                                const uint32_t aligned = rem & ~3u;
-                                if (aligned != 0u && n_desc < kSummaryDescs) {
+                                // sprites, screenshots with photographs in them: the whole run (the two pixels above taken back) becomes a span for
+                                // dec_expand_runs, and the QOI_OP_RUNs that follow it directly lengthen the span - three additions per chunk of 62
+                                // pixels.  (First form, a descriptor per chunk with head and tail through the ring: a transparent band of 77 000
+                                // pixels was 1239 x (align, ring out, descriptor, tail) in one lane while 63 waited - dec_segments_rec 16.4 ms per
+                                // 256 sprite frames against 4.8 for photographs, profiles/r05_s18_dec_kernels.txt.)  A span is written down when
+                                // the next one opens or the segment ends; the ring goes out once per span.
+                                if (span_len != 0u && W.fpos + n2 == W.ppos && span_start + span_len + n2 == W.ppos && span_px == px) {
+                                    W.ppos += rem; span_len += rem + n2; W.fpos = W.ppos; rem = 0u;
+                                } else if (n_desc + 1u < kSummaryDescs) {
+                                    if (span_len != 0u) { my_desc[n_desc] = make_uint4(span_start, span_len, span_px, 0u); ++n_desc; }
+                                    W.ppos -= n2;
                                     W.finish();
-                                    my_desc[n_desc] = make_uint4(W.ppos, aligned, px, 0u); ++n_desc;
-                                    W.ppos += aligned; W.fpos = W.ppos; rem -= aligned;
-                                } else if (rem >= 4u) W.splat(px, rem);
+                                    span_start = W.ppos; span_len = rem + n2; span_px = px;
+                                    W.ppos += span_len; W.fpos = W.ppos; rem = 0u;
+                                } else W.splat(px, rem);
                             } else W.splat(px, rem);
                         }
                         while (rem) { W.put(px); --rem; }
@@ -2221,6 +2227,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     };
     if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
     if (FLAT) { if (span_len != 0u) close_span(px); W.fpos = W.ppos; }
+    else if (span_len != 0u) { my_desc[n_desc] = make_uint4(span_start, span_len, span_px, 0u); ++n_desc; }       // (a place was kept for it)
     if (FLAT || p.desc_all) {
         // segments with descriptors queue up for dec_expand_runs: one returning atomic per wavefront that has any
         const bool some = have && n_desc != 0u;

@@ -1014,7 +1014,9 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
 
 
 // The first set of a call that finds a flat stretch in front of it says so to the HOST: the call's number into a pinned word, read (without
-// a wait) when the context's next call is set up - a hint, no more: whichever pass that call takes, its streams are the same bytes.
+// a wait) when the context's next calls are set up - a hint, no more: whichever pass a call takes, its streams are the same bytes.  The word
+// behind it holds the number of the last call whose first set has STARTED: the host may be hundreds of calls ahead of the device, "no flat
+// stretch lately" means lately on the device.
 __device__ __forceinline__ void leave_hint(const EncParams& p) {
     if (p.host_hint) __hip_atomic_store(p.host_hint, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1030,6 +1032,8 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     const bool last_set = hi == n;
     const uint32_t ngroups = (hi - lo + kGroupPx - 1u) / kGroupPx;
     const size_t sg = (size_t)I.set_base + set;                // global index of the set
+    if ((ENTRY == 1 || ENTRY == 3) && p.host_hint && sg == 0 && lane == 0)      // how far the device has come: leave_hint
+        __hip_atomic_store(p.host_hint + 1, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef QOIMI_ENC_PHASES
     unsigned long long t_mark = __builtin_readcyclecounter();
     if (lane == 0) atomicAdd(&g_enc_phase[5], 1ull);

@@ -112,7 +112,6 @@ struct qoimi_ctx {
     int enc_gen_grid_div = 1;           // (32 / 4 / 1: uiflat 21.3 / 21.2 / 20.4 ms, sprite_alpha 11.0 / 11.1 / 10.1 per 512, profiles/r05_s14_enc_grid.txt) env QOIMI_ENC_GEN_GRID_HOT: the pass over flagged images runs with 1/N of its units when the previous batch held flagged images
     int enc_uni = -1;                   // one encode pass, sets whose look-back window does not do take the state look-back one by one.  -1: for calls of a few
                                         // images (tree placement) behind a call that met flat stretches (host_word[14]); env QOIMI_ENC_UNI=1 always / 0 never
-    uint32_t enc_prev_epoch = 0;        // number of the context's previous encode call (what host_word[14] is compared with)
     int enc_g2 = 1;                     // env QOIMI_ENC_G2=0: flagged images (flat content) go through the summary passes instead of the state look-back (ENTRY 2)
     uint32_t enc_epoch = 0;             // encode call number: the tag of the state look-back's granules
     void* g2_zeroed_at = nullptr; size_t g2_zeroed_bytes = 0; unsigned g2_zeroed_gen = 0;     // where those granules were last zeroed
@@ -195,7 +194,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_ADAPT")) c->enc_adapt = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_G2")) c->enc_g2 = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_UNI")) c->enc_uni = atoi(e) != 0;
-    c->host_word[14] = 0u;
+    c->host_word[14] = 0u; c->host_word[15] = 0u;
     if (const char* e = getenv("QOIMI_ENC_GEN_GRID_HOT")) { const int v = atoi(e); if (v >= 1) c->enc_gen_grid_div = v; }
     c->host_word[13] = 0u;
     if (const char* e = getenv("QOIMI_ENC_GEN_SLABS")) { const int v = atoi(e); if (v >= 1 && v <= (int)kEncMaxSetSlabs) c->enc_gen_slabs = v; }
@@ -418,10 +417,10 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     }
 
     size_t g2_bytes = 0;
-    // one of the context's last 64 calls met flat stretches (the calls of a pipeline are set up long before their predecessors have run,
-    // the word lags; read once: the device may be writing)
-    const uint32_t hint = *(volatile uint32_t*)&c->host_word[14];
-    const bool hot = hint != 0u && ((c->enc_prev_epoch - hint) & 0x1FFFFFFFu) < 64u;
+    // one of the last eight small calls the DEVICE has started met flat stretches (host_word[14]: number of the last call that did,
+    // [15]: of the last call started; the calls of a pipeline are set up long before their predecessors run - read once: the device may be writing)
+    const uint32_t hint = *(volatile uint32_t*)&c->host_word[14], started = *(volatile uint32_t*)&c->host_word[15];
+    const bool hot = hint != 0u && (((started - hint) & 0x1FFFFFFFu) < 8u || ((hint - started) & 0x1FFFFFFFu) < 8u);
     for (int pass = 0; pass < 2; ++pass) {      // pass 0 measures, pass 1 carves
         Carver w(pass ? c->enc_ws.base : nullptr);
         p.status = w.take<u64>(S); p.ticket = w.take<uint32_t>((size_t)n_images); p.err = w.take<uint32_t>(1);
@@ -443,8 +442,8 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         // One pass or two: a frame of photographic content is 2 us faster through the two-pass kernel, which never needs its second pass
         // (35.3 against 37.1 us per 4K frame); a frame with flat stretches saves the second launch and the first pass's wasted walk with
         // the one-pass kernel (4K: constant 110 -> 93 us, UI 156 -> 111, soft-alpha sprite 126 -> 69; profiles/r05_s16_single_uni.txt).
-        // Calls of a few images take the one pass when one of the context's last 64 calls met a flat stretch: its first such set left the
-        // call's number in a pinned word (leave_hint).  Batches keep two passes (1024 photographs 13.4 against 12.3 ms in one pass).
+        // Calls of a few images take the one pass when one of the last eight such calls the device has started met a flat stretch: its first
+        // such set left the call's number in a pinned word (leave_hint).  Batches keep two passes (1024 photographs 13.4 against 12.3 ms in one pass).
         p.uni = (g2 && (c->enc_uni > 0 || (c->enc_uni < 0 && c->enc_adapt && place == 2 && hot))) ? 1u : 0u;
         p.host_hint = place == 2 ? &c->host_word[14] : nullptr;
         const size_t g2_sets = p.uni ? S : S_gen;              // (one pass: a record per set of that pass)
@@ -470,7 +469,6 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
                 if (c->enc_epoch == 0u) c->enc_epoch = 1u;
             }
             p.epoch = c->enc_epoch;
-            c->enc_prev_epoch = p.epoch;
         }
     }
     p.out = (uint8_t*)d_streams; p.out_stride = stream_stride; p.out_len = d_stream_len;

@@ -783,29 +783,29 @@ def test_state_lookback_granules_across_calls_and_shapes(api, oracle):
 
 def test_small_calls_take_one_pass_behind_a_call_that_met_flat_stretches(api, oracle):
     """Calls of a few images (tree placement): the first set of a call whose look-back window does not determine its entry state leaves
-    the call's number in a pinned host word, and while that number is one of the context's last 64 the small calls run the one-pass kernel
-    (no second launch over flagged images); 64 calls of photographs later the two passes are back.  Which kernel ran shows in the profile;
-    the streams are the reference's either way."""
+    the call's number in a pinned host word, the first set of every such call the number of the call that has started in the word behind
+    it; while the two are less than eight calls apart the small calls run the one-pass kernel (no second launch over flagged images),
+    eight calls of photographs later the two passes are back.  Which kernel ran shows in the profile; the streams are the reference's
+    either way."""
     from gpu_util import DeviceBatch
     from qoi_amd import synth
     c = api.Context(0)
     w, h = 1280, 720
-    seq = ["photo", "uiflat", "uiflat", "constant"] + ["photo"] * 70 + ["sprite_alpha", "sprite_alpha"]
+    seq = ["photo", "uiflat", "uiflat", "constant"] + ["photo"] * 12 + ["sprite_alpha", "sprite_alpha"]
     second_pass = []
     for call, kind in enumerate(seq):
         b = DeviceBatch(c, w, h, 4, 1)
-        f = synth.frame_rgba(kind, w, h, 4100 + (call if call < 8 or call >= 70 else 8))
+        f = synth.frame_rgba(kind, w, h, 4100 + call)
         b.upload(0, f)
         c.set_profiling(True)
         lens = b.encode()
         prof = c.get_profile(b.stream)
         c.set_profiling(False)
-        if call < 8 or call >= 70:
-            assert b.stream_bytes(0, lens[0]) == oracle.encode(f, w, h, 4), (call, kind)
+        assert b.stream_bytes(0, lens[0]) == oracle.encode(f, w, h, 4), (call, kind)
         second_pass.append(prof.get("enc_slabs_generic", (0.0, 0))[1] > 0)          # (two passes: the second launch is there even where it finds nothing to do)
-    # photo, uiflat: two passes (nothing known yet); from there one pass up to the 64th call behind the constant frame (call 3); the first sprite finds two passes again
-    want = [True, True] + [False] * 2 + [False] * 64 + [True] * 6 + [True, False]
-    assert second_pass == want, [i for i, (a, b_) in enumerate(zip(second_pass, want)) if a != b_]
+    # photo, uiflat: two passes (nothing known yet); one pass up to the eighth call behind the constant frame (call 3); the first sprite finds two passes again
+    want = [True, True] + [False] * 2 + [False] * 8 + [True] * 4 + [True, False]
+    assert second_pass == want, second_pass
     c.close()
 
 
