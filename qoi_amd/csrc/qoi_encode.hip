@@ -924,34 +924,53 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
         for (int t = 0; t < kGroupSteps; ++t) { const uint32_t i = base + (uint32_t)t * 64u + lane; x[t] = i < hi ? load_one(i) : 0u; }
     };
     uint32_t chain = 0u;
-    uint32_t carry = lo > 0u ? load_one(lo - 1u) : kInitPx;     // the pixel in front of the set (qoi.h:396-399 in front of the image)
-    auto walk = [&](uint32_t g, const uint32_t (&x)[kGroupSteps]) {
-        const uint32_t base = lo + g * kGroupPx;
-        // (what the exchanges return is of no interest - but see probe_swap_into)
+    // groups [g0, g1) of the set into the table at `tb`: the last edge pixel per slot, the last edge
+    auto scan = [&](uint32_t g0, uint32_t g1, uint32_t tb, int& le) {
+        const uint32_t first = lo + g0 * kGroupPx;
+        uint32_t carry = first > 0u ? load_one(first - 1u) : kInitPx;     // the pixel in front (qoi.h:396-399 in front of the image)
+        auto walk = [&](uint32_t g, const uint32_t (&x)[kGroupSteps]) {
+            const uint32_t base = lo + g * kGroupPx;
+            // (what the exchanges return is of no interest - but see probe_swap_into)
 #pragma unroll
-        for (int t = 0; t < kGroupSteps; ++t) {
-            const bool inb = base + (uint32_t)t * 64u + lane < hi;
-            const uint32_t prev = from_lane_below(x[t], carry);
-            const u64 E = __ballot(inb && x[t] != prev);
-            carry = read_lane(x[t], 63);
-            if (E) {
-                le_loc = (int)(base + (uint32_t)t * 64u) + msb64(E);
-                probe_swap_into(chain, tbase | slot_byte_offset(x[t]), x[t], E);  // lanes in ascending order: the later pixel stays (PROBE 1)
+            for (int t = 0; t < kGroupSteps; ++t) {
+                const bool inb = base + (uint32_t)t * 64u + lane < hi;
+                const uint32_t prev = from_lane_below(x[t], carry);
+                const u64 E = __ballot(inb && x[t] != prev);
+                carry = read_lane(x[t], 63);
+                if (E) {
+                    le = (int)(base + (uint32_t)t * 64u) + msb64(E);
+                    probe_swap_into(chain, tb | slot_byte_offset(x[t]), x[t], E);  // lanes in ascending order: the later pixel stays (PROBE 1)
+                }
             }
+        };
+        fetch(g0, cx);
+        for (uint32_t g = g0; g < g1; g += 2u) {
+            if (g + 1u < g1) fetch(g + 1u, nx);
+            walk(g, cx);
+            if (g + 1u >= g1) break;
+            if (g + 2u < g1) fetch(g + 2u, cx);
+            walk(g + 1u, nx);
         }
+        probe_wait(chain);
+        __builtin_amdgcn_wave_barrier();
     };
-    fetch(0u, cx);
-    for (uint32_t g = 0; g < ngroups; g += 2u) {
-        if (g + 1u < ngroups) fetch(g + 1u, nx);
-        walk(g, cx);
-        if (g + 1u >= ngroups) break;
-        if (g + 2u < ngroups) fetch(g + 2u, cx);
-        walk(g + 1u, nx);
+    // The set's LAST groups first: where they write all 64 slots and hold an edge (photographs, the inside of a sprite) they say everything
+    // about the table behind the set, and the groups in front of them are not walked at all (the state look-back read every flagged image
+    // twice - 512 soft-alpha sprites: 4 of its 9.7 ms).  Where they do not (flat stretches), the groups in front go into a table of their
+    // own - the staging buffer, idle until the encoding starts, 256 bytes behind the table and aligned like it - and fill the gaps.
+    const uint32_t g_tail = ngroups > kG2TailGroups ? ngroups - kG2TailGroups : 0u;
+    scan(g_tail, ngroups, tbase, le_loc);
+    uint32_t loc_w = L.table[lane];
+    bool loc_valid = loc_w != sent;
+    if (g_tail != 0u && !(lanes_where(loc_valid) == ~0ull && le_loc >= 0)) {
+        L.stage[lane] = sent;
+        __builtin_amdgcn_wave_barrier();
+        int le_head = -1;
+        scan(0u, g_tail, tbase + 256u, le_head);
+        const uint32_t head_w = L.stage[lane];
+        if (!loc_valid) { loc_w = head_w; loc_valid = head_w != sent; }
+        if (le_loc < 0) le_loc = le_head;
     }
-    probe_wait(chain);
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t loc_w = L.table[lane];
-    const bool loc_valid = loc_w != sent;
     u64* const mine = rec_img + (size_t)set * 65u;
     const u64 tag = g2_tag(p);
     // (a set that wrote ALL 64 slots itself - most sets of photograph-like content - leaves a table that owes nothing to the sets in front

@@ -36,6 +36,7 @@ constexpr uint32_t kEncPoolSlots = 8192;              // look-back mode: scratch
                                                       // wavefronts of enc_sets a chip holds at a time: a set keeps its slot from its first spill to its copy-out)
 constexpr uint32_t kEncPoolMapStride = 16;            // u64 words between two words of the pool's bitmap: one word per 128-byte line
 constexpr uint32_t kEncTreeMaxSets = 12288;          // automatic choice of the placement: an image of more sets than this is placed order-free, not by the tree
+constexpr uint32_t kG2TailGroups = 2;                 // state look-back: groups (of 512 pixels) at a set's end that are walked first
 constexpr uint32_t kEncGenSetSlabs = 8;               // slabs per set of the generic pass when it places by look-back (flat content: few bytes per slab)
 
 // Calls of differently shaped images (qoimi_encode_images): everything the kernels take from the call's one shape otherwise, per image.
