@@ -924,49 +924,56 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
         for (int t = 0; t < kGroupSteps; ++t) { const uint32_t i = base + (uint32_t)t * 64u + lane; x[t] = i < hi ? load_one(i) : 0u; }
     };
     uint32_t chain = 0u;
-    // groups [g0, g1) of the set into the table at `tb`: the last edge pixel per slot, the last edge
-    auto scan = [&](uint32_t g0, uint32_t g1, uint32_t tb, int& le) {
-        const uint32_t first = lo + g0 * kGroupPx;
-        uint32_t carry = first > 0u ? load_one(first - 1u) : kInitPx;     // the pixel in front (qoi.h:396-399 in front of the image)
-        auto walk = [&](uint32_t g, const uint32_t (&x)[kGroupSteps]) {
-            const uint32_t base = lo + g * kGroupPx;
-            // (what the exchanges return is of no interest - but see probe_swap_into)
+    // a group of the set into the table at `tb`: the last edge pixel per slot, the last edge
+    auto walk = [&](uint32_t g, const uint32_t (&x)[kGroupSteps], uint32_t tb, int& le, uint32_t& carry) {
+        const uint32_t base = lo + g * kGroupPx;
+        // (what the exchanges return is of no interest - but see probe_swap_into)
 #pragma unroll
-            for (int t = 0; t < kGroupSteps; ++t) {
-                const bool inb = base + (uint32_t)t * 64u + lane < hi;
-                const uint32_t prev = from_lane_below(x[t], carry);
-                const u64 E = __ballot(inb && x[t] != prev);
-                carry = read_lane(x[t], 63);
-                if (E) {
-                    le = (int)(base + (uint32_t)t * 64u) + msb64(E);
-                    probe_swap_into(chain, tb | slot_byte_offset(x[t]), x[t], E);  // lanes in ascending order: the later pixel stays (PROBE 1)
-                }
+        for (int t = 0; t < kGroupSteps; ++t) {
+            const bool inb = base + (uint32_t)t * 64u + lane < hi;
+            const uint32_t prev = from_lane_below(x[t], carry);
+            const u64 E = __ballot(inb && x[t] != prev);
+            carry = read_lane(x[t], 63);
+            if (E) {
+                le = (int)(base + (uint32_t)t * 64u) + msb64(E);
+                probe_swap_into(chain, tb | slot_byte_offset(x[t]), x[t], E);  // lanes in ascending order: the later pixel stays (PROBE 1)
             }
-        };
-        fetch(g0, cx);
-        for (uint32_t g = g0; g < g1; g += 2u) {
-            if (g + 1u < g1) fetch(g + 1u, nx);
-            walk(g, cx);
-            if (g + 1u >= g1) break;
-            if (g + 2u < g1) fetch(g + 2u, cx);
-            walk(g + 1u, nx);
         }
-        probe_wait(chain);
-        __builtin_amdgcn_wave_barrier();
     };
     // The set's LAST groups first: where they write all 64 slots and hold an edge (photographs, the inside of a sprite) they say everything
     // about the table behind the set, and the groups in front of them are not walked at all (the state look-back read every flagged image
     // twice - 512 soft-alpha sprites: 4 of its 9.7 ms).  Where they do not (flat stretches), the groups in front go into a table of their
-    // own - the staging buffer, idle until the encoding starts, 256 bytes behind the table and aligned like it - and fill the gaps.
+    // own - the staging buffer, idle until the encoding starts, 256 bytes behind the table and aligned like it - and fill the gaps; their
+    // first group is asked for before the tail has been looked at (512 pixels asked for in vain where the tail does: the walk of the groups
+    // in front starts without a load in its way - as a second pipeline of its own it cost 1024 constant frames 7.2 -> 7.8 ms,
+    // profiles/r05_s20_enc_tail_first.txt).
+    static_assert(kG2TailGroups == 2u, "the tail is the two register groups");
     const uint32_t g_tail = ngroups > kG2TailGroups ? ngroups - kG2TailGroups : 0u;
-    scan(g_tail, ngroups, tbase, le_loc);
+    const uint32_t tail_first = lo + g_tail * kGroupPx;
+    uint32_t carry_tail = tail_first > 0u ? load_one(tail_first - 1u) : kInitPx;     // the pixel in front (qoi.h:396-399 in front of the image)
+    uint32_t carry_head = lo > 0u ? load_one(lo - 1u) : kInitPx;
+    fetch(g_tail, cx);
+    if (g_tail + 1u < ngroups) fetch(g_tail + 1u, nx);
+    walk(g_tail, cx, tbase, le_loc, carry_tail);
+    if (g_tail != 0u) fetch(0u, cx);
+    if (g_tail + 1u < ngroups) walk(g_tail + 1u, nx, tbase, le_loc, carry_tail);
+    probe_wait(chain);
+    __builtin_amdgcn_wave_barrier();
     uint32_t loc_w = L.table[lane];
     bool loc_valid = loc_w != sent;
     if (g_tail != 0u && !(lanes_where(loc_valid) == ~0ull && le_loc >= 0)) {
         L.stage[lane] = sent;
         __builtin_amdgcn_wave_barrier();
         int le_head = -1;
-        scan(0u, g_tail, tbase + 256u, le_head);
+        for (uint32_t g = 0; g < g_tail; g += 2u) {
+            if (g + 1u < g_tail) fetch(g + 1u, nx);
+            walk(g, cx, tbase + 256u, le_head, carry_head);
+            if (g + 1u >= g_tail) break;
+            if (g + 2u < g_tail) fetch(g + 2u, cx);
+            walk(g + 1u, nx, tbase + 256u, le_head, carry_head);
+        }
+        probe_wait(chain);
+        __builtin_amdgcn_wave_barrier();
         const uint32_t head_w = L.stage[lane];
         if (!loc_valid) { loc_w = head_w; loc_valid = head_w != sent; }
         if (le_loc < 0) le_loc = le_head;
