@@ -108,7 +108,9 @@ struct qoimi_ctx {
     int enc_tree_ticket = 0;            // env QOIMI_ENC_TREE_TICKET=1: tree placement hands its units out by one ticket per workgroup (start order) instead of by workgroup index
     uint32_t test_spin_bound = 0;       // env QOIMI_TEST_SPIN_BOUND (tests): polls before a placement wait gives up
     bool worst_case_buffer = false;     // env QOIMI_ENCODE_WORST_CASE_BUFFER=1 (read once, at creation): qoi_encode returns the reference's worst-case allocation
-    int enc_gen_slabs = (int)kEncGenSetSlabs;   // env QOIMI_ENC_GEN_SLABS (1..8): slabs per set of the pass over flagged images
+    int enc_gen_slabs = 0;              // env QOIMI_ENC_GEN_SLABS (1..16): slabs per set of the pass over flagged images; 0: kEncGenSetSlabs, twice that for
+                                        // calls of 3 x 65536 slabs and more (8 / 12 / 16 slabs, 1024 frames: constant 7.69 / 7.34 / 6.75 ms, uiflat 20.62 / 20.49 / 20.34,
+                                        // 512 sprites 8.86 / 8.70 / 8.76 - profiles/r05_s22_enc_gen_slabs16.txt; a single frame has too few sets for that)
     int enc_gen_grid_div = 1;           // (32 / 4 / 1: uiflat 21.3 / 21.2 / 20.4 ms, sprite_alpha 11.0 / 11.1 / 10.1 per 512, profiles/r05_s14_enc_grid.txt) env QOIMI_ENC_GEN_GRID_HOT: the pass over flagged images runs with 1/N of its units when the previous batch held flagged images
     int enc_uni = -1;                   // one encode pass, sets whose look-back window does not do take the state look-back one by one.  -1: for calls of a few
                                         // images (tree placement) behind a call that met flat stretches (host_word[14]); env QOIMI_ENC_UNI=1 always / 0 never
@@ -406,7 +408,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     // from their first spill to their copy-out - a pool of kEncPoolSlots slots (more than the wavefronts in flight; fewer for calls
     // of fewer sets), handed out on the device (pool_take).  The 1024-frame 4K shard: 0.34 GB instead of 42.5 GB.
     p.pool = lookback ? 1 : 0;
-    p.gen_slabs = (uint32_t)c->enc_gen_slabs;
+    p.gen_slabs = c->enc_gen_slabs > 0 ? (uint32_t)c->enc_gen_slabs : ((size_t)n_images * p.spi >= 3u * 65536u ? 2u * kEncGenSetSlabs : kEncGenSetSlabs);
     p.gen_grid_div = (c->enc_adapt && n_images >= 8 && c->host_word[13] != 0u) ? (uint32_t)c->enc_gen_grid_div : 0u;
     const size_t S_gen = (size_t)p.n_images * ((p.spi + p.gen_slabs - 1u) / p.gen_slabs);
     if (lookback) {

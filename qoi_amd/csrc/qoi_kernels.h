@@ -30,7 +30,7 @@ struct KernelTimer {
 // ---- encode ------------------------------------------------------------------------
 constexpr int kEncSteps = 16;                         // 64-pixel steps per slab
 constexpr uint32_t kEncSlabPx = 64u * kEncSteps;      // pixels per slab: the unit of the generic entry-state passes
-constexpr uint32_t kEncMaxSetSlabs = 8;               // a wavefront encodes a SET of 1..8 consecutive slabs
+constexpr uint32_t kEncMaxSetSlabs = 16;              // a wavefront encodes a SET of 1..16 consecutive slabs
 constexpr uint32_t kEncSlabWorst = kEncSlabPx * 5u;   // most bytes a slab can produce (QOI_OP_RGBA everywhere)
 constexpr uint32_t kEncPoolSlots = 8192;              // look-back mode: scratch slots of the sets that spill, handed out by a bitmap (more than the 6144
                                                       // wavefronts of enc_sets a chip holds at a time: a set keeps its slot from its first spill to its copy-out)

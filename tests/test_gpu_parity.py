@@ -481,7 +481,9 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_SPREAD": "0", "QOIMI_ENC_PERSIST": "3", "QOIMI_ENC_LOOKBACK": "1"},  # ... in the grid-stride loop
     {"QOIMI_ENC_PIPE": "1", "QOIMI_ENC_PERSIST": "3", "QOIMI_ENC_LOOKBACK": "1"},   # experiment: a wavefront asks for its next set's look-back window in front of its current set's placement
     {"QOIMI_ENC_PIPE": "1", "QOIMI_ENC_PERSIST": "1", "QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "1"},
-    {"QOIMI_ENC_UNI": "1"},                               # experiment: ONE encode pass, a set whose look-back window does not do takes the state look-back by itself
+    {"QOIMI_ENC_GEN_SLABS": "16", "QOIMI_ENC_LOOKBACK": "1"},   # sixteen slabs per set in the pass over flagged images (what calls of 3 x 65536 slabs take)
+    {"QOIMI_ENC_GEN_SLABS": "3", "QOIMI_ENC_LOOKBACK": "1"},
+    {"QOIMI_ENC_UNI": "1"},                               # ONE encode pass, a set whose look-back window does not do takes the state look-back by itself
     {"QOIMI_ENC_UNI": "1", "QOIMI_ENC_LOOKBACK": "1"},
     {"QOIMI_ENC_UNI": "1", "QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "1"},
     {"QOIMI_ENC_G2": "0"},                                # flagged (flat) images through the summary passes (enc_slab_summary + scans + ENTRY 0) instead of the state look-back
