@@ -1118,7 +1118,9 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
     bool fell_back = false;                                    // ENTRY 3: the look-back window did not do, the set took the state look-back
     if (ENTRY == 1) {
         if (!warm_entry_state<CH, PROBE>(pix, lo, lane, L, C.tbase, in, last_edge)) {
-            if (lane == 0) { atomicOr(&p.need_generic[img], 1u); if (atomicOr(p.any_generic, 1u) == 0u) leave_hint(p); }
+            // (any_generic counts the flagged images: the host reads it behind the call - a batch of flagged images only tells the
+            // next call to run this pass with few workgroups, see qoimi_encode_batch)
+            if (lane == 0 && atomicOr(&p.need_generic[img], 1u) == 0u) { if (atomicAdd(p.any_generic, 1u) == 0u) leave_hint(p); }
             return;
         }
     } else if (ENTRY == 3) {
@@ -1645,6 +1647,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         p.only_flagged = 0;
         // (p.persist: test knob - at most that many workgroups, each taking unit after unit in the kernel's grid-stride loop)
         // (tree placement takes its sets by workgroup index and waits for lower-numbered ones: one workgroup per unit, no grid-stride loop)
+        if (p.persist == 0xFFFFFFFFu) p.persist = p.n_units / 16u > 2048u ? p.n_units / 16u : 2048u;   // (the previous batch held flagged images only: qoimi_encode_batch)
         bool piped = false;
         if constexpr (!MIXED && PROBE == 1) {
             if (p.uni && p.lookback != 0 && p.g2_rec != nullptr) {          // one pass, a set falls back to the state look-back by itself

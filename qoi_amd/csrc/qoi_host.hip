@@ -118,6 +118,7 @@ struct qoimi_ctx {
     uint32_t enc_epoch = 0;             // encode call number: the tag of the state look-back's granules
     void* g2_zeroed_at = nullptr; size_t g2_zeroed_bytes = 0; unsigned g2_zeroed_gen = 0;     // where those granules were last zeroed
     int enc_adapt = 1;                  // env QOIMI_ENC_ADAPT=0: the set size ignores what the previous call's streams looked like
+    uint32_t enc_hint_images = 0;       // images of the batch call whose count of flagged images stands in host_word[13]
     uint32_t enc_hint_npx = 0;          // pixels per image of the batch call whose first stream length stands in host_word[12] (0: none)
     struct { const void* px; size_t ps; qoi_desc desc; int n; void* out; size_t os; int* len; void* st; bool valid = false; } last_enc;   // the last qoimi_encode_batch (qoimi_encode_status re-encodes it order-free if a wait gave up)
     int enc_spread = 1;                 // env QOIMI_ENC_SPREAD: the wavefronts of a workgroup take their tickets from consecutive images (0: all four from one image)
@@ -347,6 +348,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.use_ticket = c->enc_ticket ? 1 : 0;
     p.warm = c->enc_warm ? 1 : 0;
     p.persist = (uint32_t)c->enc_persist;
+    bool all_flagged_before = false;
     p.pipe = (uint32_t)c->enc_pipe;
     p.spread = (uint32_t)c->enc_spread;
     // Slabs per set and placement - functions of the call's shape only; QOIMI_ENC_SET_SLABS / QOIMI_ENC_LOOKBACK force them; every
@@ -410,6 +412,12 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.pool = lookback ? 1 : 0;
     p.gen_slabs = c->enc_gen_slabs > 0 ? (uint32_t)c->enc_gen_slabs : ((size_t)n_images * p.spi >= 3u * 65536u ? 2u * kEncGenSetSlabs : kEncGenSetSlabs);
     p.gen_grid_div = (c->enc_adapt && n_images >= 8 && c->host_word[13] != 0u) ? (uint32_t)c->enc_gen_grid_div : 0u;
+    // The previous batch held flagged images ONLY (flat content: host_word[13] counts them): this call's first pass will most likely find
+    // an image's first flat stretch within microseconds and every other set of the image has nothing to do but to see the flag - one
+    // workgroup per four sets is 345 000 workgroups that start and end for 512 4K frames, 0.5 ms of dispatch.  A sixteenth of them, each
+    // looking at sixteen units, sees the same flags (photographs pay 7-9 % with several sets per wavefront: the hint is gone after one call).
+    all_flagged_before = c->enc_adapt && place == 1 && n_images >= 8 && c->enc_hint_images != 0u && c->host_word[13] >= c->enc_hint_images;
+    if (all_flagged_before && p.persist == 0u) p.persist = 0xFFFFFFFFu;            // resolved below, once the units are known
     const size_t S_gen = (size_t)p.n_images * ((p.spi + p.gen_slabs - 1u) / p.gen_slabs);
     if (lookback) {
         size_t slots = (S + 63u) & ~(size_t)63u;
@@ -483,7 +491,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     c->timer.mark(kT_enc_total, st);
     if (c->enc_adapt && place == 1) {                       // what this batch's streams look like, for the next call's set size (see above)
         if (hipMemcpyAsync(&c->host_word[12], d_stream_len, sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess) c->enc_hint_npx = p.npx;
-        (void)hipMemcpyAsync(&c->host_word[13], p.any_generic, sizeof(uint32_t), hipMemcpyDeviceToHost, st);    // ... and whether it held flagged (flat) images: the grid of the next call's pass over them
+        if (hipMemcpyAsync(&c->host_word[13], p.any_generic, sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess) c->enc_hint_images = (uint32_t)n_images;    // ... and how many flagged (flat) images it held: the grids of the next call's passes
     }
     c->last_enc.px = d_pixels; c->last_enc.ps = pixel_stride; c->last_enc.desc = *desc; c->last_enc.n = n_images;
     c->last_enc.out = d_streams; c->last_enc.os = stream_stride; c->last_enc.len = d_stream_len; c->last_enc.st = stream; c->last_enc.valid = true;

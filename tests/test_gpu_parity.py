@@ -783,6 +783,25 @@ def test_state_lookback_granules_across_calls_and_shapes(api, oracle):
     c.close()
 
 
+def test_batches_behind_a_batch_of_flagged_images_only(api, oracle):
+    """A look-back batch whose images were ALL sent to the pass over flagged images tells the context's next batch to run its first pass
+    with a sixteenth of the workgroups (each looks at sixteen units: they will most likely find flags only).  Flat batches in a row, then
+    photographs behind them (several sets per wavefront for once), then photographs again: every stream the reference's."""
+    from gpu_util import DeviceBatch
+    from qoi_amd import synth
+    c = api.Context(0)
+    w, h, n = 1024, 600, 9
+    for call, kind in enumerate(["uiflat", "uiflat", "constant", "photo", "photo", "sprite_alpha", "sprite_alpha", "uiflat"]):
+        b = DeviceBatch(c, w, h, 4, n)
+        frames = [synth.frame_rgba(kind, w, h, 5200 + 17 * call + i) for i in range(n)]
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        lens = b.encode()
+        for i, f in enumerate(frames):
+            assert b.stream_bytes(i, lens[i]) == oracle.encode(f, w, h, 4), (call, kind, i)
+    c.close()
+
+
 def test_small_calls_take_one_pass_behind_a_call_that_met_flat_stretches(api, oracle):
     """Calls of a few images (tree placement): the first set of a call whose look-back window does not determine its entry state leaves
     the call's number in a pinned host word, the first set of every such call the number of the call that has started in the word behind
