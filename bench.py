@@ -687,7 +687,7 @@ def main() -> None:
         out["device_memory"] = {"encode_workspace_bytes": ws["encode"], "decode_workspace_bytes": ws["decode"], "dropin_staging_bytes": ws["staging"],
                                 "headline_batch": {"encode_workspace_bytes": ws_main["encode"], "decode_workspace_bytes": ws_main["decode"], "stream_bytes": int(stream_bytes),
                                                    "decode_workspace_over_stream_bytes": round(ws_main["decode"] / max(1.0, stream_bytes), 3) if not args.encode_only else None,
-                                                   "note": "decode: 4 bytes of chunk records per stream byte reserved (one record per byte is the worst case) + ~0.27 of per-segment state"},
+                                                   "note": "decode: 4 bytes of chunk records per stream byte of a SUB-BATCH reserved (one record per byte is the worst case; the record arena is capped at 24 GiB, a call whose streams need more is decoded as consecutive sub-batches of whole images: QOIMI_DEC_REC_CAP_MB) + ~0.27 of per-segment state"},
                                 "bench_buffers_bytes": int(pixels.numel() + streams.numel() + decoded.numel()),
                                 "peak_device_bytes": int(total_b - free_b), "device_total_bytes": int(total_b),
                                 "note": "peak_device_bytes = device total - free at the end of the run (all processes on the device; the library's arenas and torch's caching allocator only grow)"}
