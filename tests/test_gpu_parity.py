@@ -1186,7 +1186,8 @@ def test_spilling_sets_share_a_scratch_pool(api, oracle):
     c.synth_frames(synth.KIND_ID["photo"], synth.DEFAULT_SEED, 0, n, w, h, b.pixels.data_ptr(), b.pixel_stride, b.stream)
     b.encode()
     ws = c.workspace_bytes()["encode"]
-    assert ws < 700 << 20, ws            # generic-path tables 0.13 GB + pool 0.34 GB (a worst-case slot per set: 1.3 GB more)
+    assert ws < 1000 << 20, ws           # state granules and records 0.13 GB + pool 0.67 GB (8193 slots of sixteen worst-case slabs: what a set of the pass
+                                         # over flagged images may spill in a call this large; a worst-case slot per set: 1.3 GB more)
     c.close()
 
 
