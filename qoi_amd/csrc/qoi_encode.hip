@@ -899,7 +899,8 @@ __device__ __forceinline__ bool g2_ready(const EncParams& p, u64 g) { return ((g
 
 template <int CH, class LDS>
 __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t* __restrict__ pix, uint32_t n, uint32_t lo, uint32_t hi,
-                                               u64* __restrict__ rec_img, uint32_t set, uint32_t lane, LDS& L, uint32_t tbase, int& last_edge, bool& no_edges) {
+                                               u64* __restrict__ rec_img, uint32_t set, uint32_t lane, LDS& L, uint32_t tbase, int& last_edge, bool& no_edges,
+                                               bool* front_walked = nullptr) {
     // ---- own summary: last edge pixel per slot, last edge -------------------------------------------------------------
     const uint32_t sent = lane + 1u;                           // cannot hash to its own slot (warm_entry_state)
     L.table[lane] = sent;
@@ -961,7 +962,9 @@ __device__ __forceinline__ bool g2_entry_state(const EncParams& p, const uint8_t
     __builtin_amdgcn_wave_barrier();
     uint32_t loc_w = L.table[lane];
     bool loc_valid = loc_w != sent;
-    if (g_tail != 0u && !(lanes_where(loc_valid) == ~0ull && le_loc >= 0)) {
+    const bool tail_does = lanes_where(loc_valid) == ~0ull && le_loc >= 0;
+    if (front_walked) *front_walked = !tail_does;              // (a set of flat stretches: what the first pass would have flagged its image for)
+    if (g_tail != 0u && !tail_does) {
         L.stage[lane] = sent;
         __builtin_amdgcn_wave_barrier();
         int le_head = -1;
@@ -1136,7 +1139,11 @@ __device__ __forceinline__ void encode_set(const EncParams& p, uint32_t img, uin
         }
     } else if (ENTRY == 2) {
         if (PROBE == 1) {
-            if (!g2_entry_state<CH>(p, pix, n, lo, hi, p.g2_rec + (size_t)I.set_base * 65u, set, lane, L, C.tbase, last_edge, run_only)) return;
+            bool front = false;
+            if (!g2_entry_state<CH>(p, pix, n, lo, hi, p.g2_rec + (size_t)I.set_base * 65u, set, lane, L, C.tbase, last_edge, run_only, &front)) return;
+            // every image of the call by state look-back (no first pass: the context's previous batch held flagged images only): the count
+            // of images with flat stretches is kept all the same - it decides how the NEXT batch runs
+            if (p.all_g2 && front && lane == 0 && atomicOr(&p.need_generic[img], 1u) == 0u) atomicAdd(p.any_generic, 1u);
         }
         if (nint && !run_only) load_group<CH>(pix, lo, lane, ax, av);       // (from the L2 / Infinity Cache: the set's own walk has just read them)
     } else {
@@ -1662,10 +1669,12 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
                 piped = true;
             }
         }
-        if (!piped)
+        // (p.all_g2: no first pass at all - the pass over flagged images takes every image; qoimi_encode_batch)
+        const bool skip_first = !MIXED && PROBE == 1 && p.all_g2 && p.lookback == 1 && p.g2_rec != nullptr && !p.uni;
+        if (!piped && !skip_first)
         hipLaunchKernelGGL((enc_sets<CH, PROBE, 1, MIXED>), dim3(p.persist && p.n_units > p.persist && p.lookback != 2 ? p.persist : p.n_units), dim3(256), 0, st, p);
         tm->mark(kT_enc_slabs, st);
-        p.only_flagged = 1;
+        p.only_flagged = skip_first ? 0 : 1;
     } else {
         p.only_flagged = 0;
         small = 0xFFFFFFFFu;
@@ -1685,6 +1694,7 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
         // way to run this kernel, EXPERIMENTS.md)
         uint32_t grid2 = small;
         if (p.gen_grid_div) { const uint32_t want = g.n_units / p.gen_grid_div; if (want > grid2) grid2 = want; }
+        if (!p.only_flagged) grid2 = g.n_units;
         hipLaunchKernelGGL((enc_sets<CH, PROBE, 2, MIXED>), dim3(g.n_units < grid2 || g.lookback == 2 ? g.n_units : grid2), dim3(256), 0, st, g);
         tm->mark(kT_enc_slabs_generic, st);
         return;

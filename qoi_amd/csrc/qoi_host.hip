@@ -114,6 +114,7 @@ struct qoimi_ctx {
     int enc_gen_grid_div = 1;           // (32 / 4 / 1: uiflat 21.3 / 21.2 / 20.4 ms, sprite_alpha 11.0 / 11.1 / 10.1 per 512, profiles/r05_s14_enc_grid.txt) env QOIMI_ENC_GEN_GRID_HOT: the pass over flagged images runs with 1/N of its units when the previous batch held flagged images
     int enc_uni = -1;                   // one encode pass, sets whose look-back window does not do take the state look-back one by one.  -1: for calls of a few
                                         // images (tree placement) behind a call that met flat stretches (host_word[14]); env QOIMI_ENC_UNI=1 always / 0 never
+    int enc_all_g2 = 1;                 // env QOIMI_ENC_ALL_G2=0: a batch behind a batch of flagged images only still runs its first pass (with a sixteenth of its workgroups)
     int enc_g2 = 1;                     // env QOIMI_ENC_G2=0: flagged images (flat content) go through the summary passes instead of the state look-back (ENTRY 2)
     uint32_t enc_epoch = 0;             // encode call number: the tag of the state look-back's granules
     void* g2_zeroed_at = nullptr; size_t g2_zeroed_bytes = 0; unsigned g2_zeroed_gen = 0;     // where those granules were last zeroed
@@ -196,6 +197,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_TREE_TICKET")) c->enc_tree_ticket = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_ADAPT")) c->enc_adapt = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_G2")) c->enc_g2 = atoi(e) != 0;
+    if (const char* e = getenv("QOIMI_ENC_ALL_G2")) c->enc_all_g2 = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_UNI")) c->enc_uni = atoi(e) != 0;
     c->host_word[14] = 0u; c->host_word[15] = 0u;
     if (const char* e = getenv("QOIMI_ENC_GEN_GRID_HOT")) { const int v = atoi(e); if (v >= 1) c->enc_gen_grid_div = v; }
@@ -418,6 +420,10 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     // looking at sixteen units, sees the same flags (photographs pay 7-9 % with several sets per wavefront: the hint is gone after one call).
     all_flagged_before = c->enc_adapt && place == 1 && n_images >= 8 && c->enc_hint_images != 0u && c->host_word[13] >= c->enc_hint_images;
     if (all_flagged_before && p.persist == 0u) p.persist = 0xFFFFFFFFu;            // resolved below, once the units are known
+    // ... or not at all (QOIMI_ENC_ALL_G2, default on): the pass over flagged images takes EVERY image of this call, and counts the images in
+    // which some set had to walk the groups in front of its tail - the same statistic, so a batch of photographs behind flat batches
+    // runs once through that pass (sixteen-slab sets, every set through the pool) and hands the next batch back to the two passes.
+    p.all_g2 = (all_flagged_before && c->enc_all_g2) ? 1u : 0u;
     const size_t S_gen = (size_t)p.n_images * ((p.spi + p.gen_slabs - 1u) / p.gen_slabs);
     if (lookback) {
         size_t slots = (S + 63u) & ~(size_t)63u;

@@ -77,6 +77,7 @@ struct EncParams {
     uint32_t gen_slabs;      // slabs per set of the pass over flagged images (kEncGenSetSlabs; env QOIMI_ENC_GEN_SLABS)
     uint32_t spin_bound;     // polls a placement wait makes before it gives up (err bit 0): 2^22 with tickets (start order), 2^15 for the tree by workgroup index
     uint32_t uni;            // 1 (env QOIMI_ENC_UNI=1, or a small call behind one that held flat stretches): one pass (enc_sets<ENTRY 3>) - sets whose look-back window does not do take the state look-back themselves; g2_rec holds a record per set of the FIRST pass
+    uint32_t all_g2;         // 1: no first pass, every image of the call goes through the pass over flagged images (the context's previous batch held flagged images only)
     uint32_t pipe;           // 1 (env QOIMI_ENC_PIPE, with persist): a wavefront asks for its next set's first loads in front of its current set's placement
     uint32_t persist;        // 0: one workgroup per unit; else the first pass runs at most this many workgroups (env QOIMI_ENC_PERSIST, a test knob)
     // workspace

@@ -26,5 +26,11 @@ c.set_profiling(True)
 for _ in range(reps):
     c.decode_batch(st.data_ptr(), ss, sizes, [desc] * F, 4, out.data_ptr(), ps, s)
 prof = c.get_profile(s)
+c.set_profiling(False)
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(reps):
+    c.decode_batch(st.data_ptr(), ss, sizes, [desc] * F, 4, out.data_ptr(), ps, s)
+torch.cuda.synchronize(); wall_ms = (time.perf_counter() - t0) / reps * 1e3
 print(os.path.basename(os.path.dirname(api.LIB_PATH)), {k: round(v[0] / reps, 3) for k, v in prof.items() if v[1] and v[0] / reps > 0.02},
-      'rounds', c.decode_stats()['rounds'], 'equal', bool(torch.equal(out, px)), 'workspace GB', round(c.workspace_bytes()['decode'] / 1e9, 2), 'streams GB', round(sum(sizes) / 1e9, 2))
+      'rounds', c.decode_stats()['rounds'], 'equal', bool(torch.equal(out, px)), 'wall ms', round(wall_ms, 2), 'workspace GB', round(c.workspace_bytes()['decode'] / 1e9, 2), 'streams GB', round(sum(sizes) / 1e9, 2))
