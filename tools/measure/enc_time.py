@@ -22,4 +22,10 @@ c.set_profiling(True)
 for _ in range(5):
     c.encode_batch(px.data_ptr(), ps, desc, F, st.data_ptr(), ss, lens.data_ptr(), s); c.encode_status(s)
 prof = c.get_profile(s)
-print(os.environ.get('QOIMI_ENC_SET_SLABS', '-'), os.path.basename(os.path.dirname(api.LIB_PATH)), {k: round(v[0] / 5, 3) for k, v in prof.items() if v[1] and v[0] / 5 > 0.02}, 'bytes/px', round(float(lens.sum()) / (F * npx), 4))
+c.set_profiling(False)
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3):
+    c.encode_batch(px.data_ptr(), ps, desc, F, st.data_ptr(), ss, lens.data_ptr(), s)
+torch.cuda.synchronize(); wall_ms = (time.perf_counter() - t0) / 3 * 1e3
+print(os.environ.get('QOIMI_ENC_SET_SLABS', '-'), os.path.basename(os.path.dirname(api.LIB_PATH)), {k: round(v[0] / 5, 3) for k, v in prof.items() if v[1] and v[0] / 5 > 0.02}, 'wall ms', round(wall_ms, 3), 'bytes/px', round(float(lens.sum()) / (F * npx), 4))
