@@ -481,6 +481,13 @@ def main() -> None:
             ctx.decode_batch(streams.data_ptr(), sstride, ksizes, descs, 4, decoded.data_ptr(), pstride, stream)   # warm-up
             enc_k = lambda: ctx.encode_batch(pixels.data_ptr(), pstride, desc, F, streams.data_ptr(), sstride, lens.data_ptr(), stream)
             dec_k = lambda: ctx.decode_batch(streams.data_ptr(), sstride, ksizes, descs, 4, decoded.data_ptr(), pstride, stream)
+            # the reference checks of the class before kept the host busy for seconds and the device idle: a class whose calls take a few
+            # milliseconds (constant: 6 + 8) would be timed while the clocks are still on their way up (one reduced run read its encode at
+            # 10.7-14.6 ms, profiles/r05_s32_*) - 0.3 s of the class's own calls first, as for the single frame
+            t_warm = time.perf_counter()
+            while time.perf_counter() - t_warm < 0.3:
+                enc_k(); dec_k()
+                torch.cuda.synchronize()
             te, td = timed(enc_k, 3), timed(dec_k, 3)
             dt = te + td
             kok = equal_batches(torch, decoded, pixels, F, pstride, npx * 4)
@@ -576,6 +583,10 @@ def main() -> None:
             s3 = [int(lens[0].item())]
             g3 = lambda: ctx.decode_batch(streams.data_ptr(), ss3, s3, [d3], 4, decoded.data_ptr(), ps3, stream)
             g3()
+            t_warm = time.perf_counter()
+            while time.perf_counter() - t_warm < 0.3:              # (clocks: see other_content)
+                e3(); g3()
+                torch.cuda.synchronize()
             dte, dtd = timed(e3, 5), timed(g3, 5)
             ok3 = bool(torch.equal(decoded[:ps3], pixels[:ps3]))
             cfg3 = {"workload": f"BASELINE configs[3]: one {w3}x{h3} RGBA image (photo, {n3 / 1e6:.0f} Mpx), encode + decode, device-resident, wall clock incl. launches",
