@@ -229,6 +229,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
 extern "C" void qoimi_ctx_destroy(qoimi_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
+    (void)hipDeviceSynchronize();       // calls still in flight write to the arenas and to the pinned words freed below
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     c->enc_ws.release(); c->dec_ws.release(); c->io_a.release(); c->io_b.release(); c->io_c.release();
     if (c->host_word) (void)hipHostFree(c->host_word);
