@@ -177,6 +177,13 @@ int qoimi_hash_streams(qoimi_ctx *ctx, const void *d_streams, size_t stream_stri
  * [2] staging buffers of the host-pointer entry points (qoi_encode / qoi_decode of the calling thread's context). */
 void qoimi_workspace_bytes(qoimi_ctx *ctx, size_t out[3]);
 
+/* Caps the chunk-record arena of this context's decode calls (bytes; at least 1 MiB): a call whose streams need more - four bytes
+ * per stream byte, the worst case - is decoded as consecutive sub-batches of whole images through the same arena, and `release`
+ * != 0 gives the arena grown so far back to the device.  Default: a sixth of the device's memory, 48 GiB at most (1024 4K
+ * photographs in one piece: 45 GB of workspace); 24 GiB decodes them as two sub-batches in 27 GB at +1 % of the time
+ * (DESIGN.md section 4).  The pixels are the same either way.  Returns QOIMI_OK or QOIMI_E_ARG. */
+int qoimi_set_decode_record_cap(qoimi_ctx *ctx, size_t bytes, int release);
+
 /* Counters of the last decode on this context: [0] speculation rounds, [1] segments
  * re-decoded after a failed check, [2] total segments, [3] segments whose entry position
  * needed the full five-phase parse (look-back synchronisation did not settle). */

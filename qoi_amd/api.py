@@ -34,7 +34,7 @@ EXPORTS = (
     "qoimi_ctx_create", "qoimi_ctx_destroy", "qoimi_last_error", "qoimi_encode_bound",
     "qoimi_encode_batch", "qoimi_encode_status", "qoimi_decode_batch", "qoimi_synth_frames",
     "qoimi_decode_stats", "qoimi_version", "qoimi_set_profiling", "qoimi_get_profile", "qoimi_kernel_name",
-    "qoimi_encode_suspect_calls", "qoimi_workspace_bytes", "qoimi_hash_streams", "qoimi_encode_images",
+    "qoimi_encode_suspect_calls", "qoimi_workspace_bytes", "qoimi_set_decode_record_cap", "qoimi_hash_streams", "qoimi_encode_images",
 )
 
 
@@ -101,6 +101,8 @@ def load_library() -> ctypes.CDLL:
     lib.qoimi_get_profile.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong), ci]
     lib.qoimi_kernel_name.restype = ctypes.c_char_p
     lib.qoimi_kernel_name.argtypes = [ci]
+    lib.qoimi_set_decode_record_cap.restype = ctypes.c_int
+    lib.qoimi_set_decode_record_cap.argtypes = [vp, sz, ctypes.c_int]
     lib.qoimi_workspace_bytes.restype = None
     lib.qoimi_workspace_bytes.argtypes = [vp, ctypes.POINTER(sz)]
     lib.qoimi_encode_suspect_calls.restype = ctypes.c_longlong
@@ -282,6 +284,10 @@ class Context:
         out = (ctypes.c_size_t * 3)()
         self._lib.qoimi_workspace_bytes(self._h, out)
         return {"encode": int(out[0]), "decode": int(out[1]), "staging": int(out[2])}
+
+    def set_decode_record_cap(self, nbytes: int, release: bool = False) -> None:
+        """Caps the chunk-record arena of decode calls (larger calls run as sub-batches of whole images); release=True frees the arena grown so far."""
+        self._check(self._lib.qoimi_set_decode_record_cap(self._h, int(nbytes), 1 if release else 0), "qoimi_set_decode_record_cap")
 
     def decode_stats(self) -> dict:
         out = (ctypes.c_longlong * 4)()

@@ -169,11 +169,13 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         return fail(QOIMI_E_NO_GPU, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     qoimi_ctx* c = new qoimi_ctx();
     c->device = device;
-    {   // record arena of a decode call: up to a twelfth of the device's memory (24 GiB on a 288 GB MI355X: the 1024-frame shard of
-        // BASELINE configs[4] as two sub-batches, 27.4 GB of workspace = 2.6 x its stream bytes at 36.8 ms; in one piece 45.1 GB = 4.3 x
-        // at 36.4 ms, in three 18.3 GB at 37.1: profiles/r05_s17_dec_cap.txt), never less than 1 GiB
-        size_t cap = (size_t)prop.totalGlobalMem / 12u;
-        if (cap > ((size_t)24 << 30)) cap = (size_t)24 << 30;
+    {   // record arena of a decode call: up to a sixth of the device's memory (48 GiB on a 288 GB MI355X: the 1024-frame shard of
+        // BASELINE configs[4] in one piece, 45.1 GB of workspace = 4.3 x its stream bytes at 36.4 ms), never less than 1 GiB.  A caller
+        // short of device memory caps it (QOIMI_DEC_REC_CAP_MB): 24 GiB = two sub-batches, 27.4 GB = 2.6 x the stream bytes at 36.8 ms
+        // (+1 %: every kernel's tail twice), 16 GiB = three, 18.3 GB at 37.1 ms (profiles/r05_s17_dec_cap.txt, r05_s27_dec_cap_wall.txt).
+        // The default was 24 GiB for sessions 24-34 of round 5: 172.8 Gpx/s (median of six runs on five boxes) against 176 in one piece.
+        size_t cap = (size_t)prop.totalGlobalMem / 6u;
+        if (cap > ((size_t)48 << 30)) cap = (size_t)48 << 30;
         if (cap < ((size_t)1 << 30)) cap = (size_t)1 << 30;
         c->dec_rec_cap = cap;
     }
@@ -235,6 +237,17 @@ extern "C" void qoimi_ctx_destroy(qoimi_ctx* c) {
     if (c->host_word) (void)hipHostFree(c->host_word);
     if (c->pin_buf) (void)hipHostFree(c->pin_buf);
     delete c;
+}
+
+extern "C" int qoimi_set_decode_record_cap(qoimi_ctx* c, size_t bytes, int release) {
+    if (!c || bytes < ((size_t)1 << 20)) return fail(QOIMI_E_ARG, "record cap: NULL context or less than 1 MiB");
+    c->dec_rec_cap = bytes;
+    if (release) {
+        DeviceGuard guard(c->device);
+        (void)hipDeviceSynchronize();
+        c->dec_ws.release();
+    }
+    return QOIMI_OK;
 }
 
 // Per-kernel timing with HIP events on the launch stream.  on=1 resets the accumulators.
