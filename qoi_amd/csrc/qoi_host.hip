@@ -424,7 +424,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     // Scratch.  Order-free: every set parks its bytes in a slot of its own until the placement passes run (few large images:
     // tens of megabytes).  Look-back: only sets that outgrow their LDS staging buffer (more than ~1.5 bytes per pixel) hold scratch,
     // from their first spill to their copy-out - a pool of kEncPoolSlots slots (more than the wavefronts in flight; fewer for calls
-    // of fewer sets), handed out on the device (pool_take).  The 1024-frame 4K shard: 0.34 GB instead of 42.5 GB.
+    // of fewer sets), handed out on the device (pool_take).  The 1024-frame 4K shard: 0.67 GB (slots of sixteen slabs) instead of 42.5 GB.
     p.pool = lookback ? 1 : 0;
     p.gen_slabs = c->enc_gen_slabs > 0 ? (uint32_t)c->enc_gen_slabs : ((size_t)n_images * p.spi >= 3u * 65536u ? 2u * kEncGenSetSlabs : kEncGenSetSlabs);
     p.gen_grid_div = (c->enc_adapt && n_images >= 8 && c->host_word[13] != 0u) ? (uint32_t)c->enc_gen_grid_div : 0u;
