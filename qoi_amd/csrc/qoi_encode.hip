@@ -1425,6 +1425,12 @@ __global__ __launch_bounds__(256, PROBE == 1 ? ((CH == 3 && ENTRY == 0) || MIXED
     __shared__ uint32_t s_unit;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (p.only_flagged && *p.any_generic == 0u) return;
+    // One frame: the hipMemsetAsync over the call's records, tickets, flags and pool map was a tenth of the call (2.9 us + a launch gap of
+    // 35).  A context keeps TWO such regions for calls of a few images and uses them in turn; the first launch of a call zeroes the other
+    // one in passing - a store per thread of its first few workgroups - and the next call finds it zeroed (qoimi_encode_batch checks that
+    // it is the very next call and lays its region out the same way; anything else pays the memset as before).
+    if ((ENTRY == 1 || ENTRY == 3) && p.zero_next != nullptr)
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < p.zero_next_dwords; i += gridDim.x * 256u) p.zero_next[i] = 0u;
     SetPre pre;
     pre.have_ticket = false; pre.valid = false;
 #pragma unroll 1

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/qoi_mi355x.h"
@@ -114,6 +115,10 @@ struct qoimi_ctx {
     int enc_gen_grid_div = 1;           // (32 / 4 / 1: uiflat 21.3 / 21.2 / 20.4 ms, sprite_alpha 11.0 / 11.1 / 10.1 per 512, profiles/r05_s14_enc_grid.txt) env QOIMI_ENC_GEN_GRID_HOT: the pass over flagged images runs with 1/N of its units when the previous batch held flagged images
     int enc_uni = -1;                   // one encode pass, sets whose look-back window does not do take the state look-back one by one.  -1: for calls of a few
                                         // images (tree placement) behind a call that met flat stretches (host_word[14]); env QOIMI_ENC_UNI=1 always / 0 never
+    int enc_prezero = 1;                // env QOIMI_ENC_PREZERO=0: calls of a few images zero their records with hipMemsetAsync every time (see enc_sets: zero_next)
+    struct { void* ptr = nullptr; size_t bytes = 0; unsigned gen = 0; long long seq = -1; bool valid = false; } prezero;   // the region the last such call zeroed for its successor
+    long long enc_ws_seq = 0;           // calls that laid out the encode workspace so far (a zeroed region is good for the very next one only)
+    int enc_parity = 0;                 // which of the two regions the next call of a few images takes
     int enc_all_g2 = 1;                 // env QOIMI_ENC_ALL_G2=0: a batch behind a batch of flagged images only still runs its first pass (with a sixteenth of its workgroups)
     int enc_g2 = 1;                     // env QOIMI_ENC_G2=0: flagged images (flat content) go through the summary passes instead of the state look-back (ENTRY 2)
     uint32_t enc_epoch = 0;             // encode call number: the tag of the state look-back's granules
@@ -200,6 +205,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
     if (const char* e = getenv("QOIMI_ENC_ADAPT")) c->enc_adapt = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_G2")) c->enc_g2 = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_ALL_G2")) c->enc_all_g2 = atoi(e) != 0;
+    if (const char* e = getenv("QOIMI_ENC_PREZERO")) c->enc_prezero = atoi(e) != 0;
     if (const char* e = getenv("QOIMI_ENC_UNI")) c->enc_uni = atoi(e) != 0;
     c->host_word[14] = 0u; c->host_word[15] = 0u;
     if (const char* e = getenv("QOIMI_ENC_GEN_GRID_HOT")) { const int v = atoi(e); if (v >= 1) c->enc_gen_grid_div = v; }
@@ -447,6 +453,13 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     }
 
     size_t g2_bytes = 0;
+    // calls of a few images: two regions of records / tickets / flags / pool map, used in turn - the first launch of a call zeroes the region
+    // of the next (enc_sets: zero_next), which then skips its hipMemsetAsync if it is the very next user of the workspace and lays out alike
+    const long long ws_seq = ++c->enc_ws_seq;
+    const auto zeroed_before = c->prezero;
+    c->prezero.valid = false;
+    const bool pingpong = place == 2 && c->enc_prezero && p.warm && p.probe_xchg;
+    uint8_t* zero_other = nullptr; size_t zero_len = 0;
     // one of the last eight small calls the DEVICE has started met flat stretches (host_word[14]: number of the last call that did,
     // [15]: of the last call started; the calls of a pipeline are set up long before their predecessors run - read once: the device may be writing)
     const uint32_t hint = *(volatile uint32_t*)&c->host_word[14], started = *(volatile uint32_t*)&c->host_word[15];
@@ -487,9 +500,25 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         p.gent_tab = w.take<uint32_t>(Gt * 64); p.gent_le = w.take<int>(Gt);
         p.set_size = w.take<uint32_t>(lookback ? 0 : S); p.set_off = w.take<uint32_t>(lookback ? 0 : S);
         p.scratch = w.take<uint8_t>(lookback ? ((size_t)p.pool_slots + 1u) * p.set_stride : S * p.set_stride);
+        uint8_t* const alt = w.take<uint8_t>(pingpong ? zero_bytes : 0);          // the second region (256-byte aligned like the first)
         if (!pass) { int rc = c->enc_ws.reserve(w.off + 256); if (rc) return rc; }
         else {
-            HIP_TRY(hipMemsetAsync(c->enc_ws.base, 0, zero_bytes, st));   // look-back records, tickets, flags, pool map
+            uint8_t* mine = (uint8_t*)c->enc_ws.base;
+            if (pingpong) {
+                zero_other = alt; zero_len = zero_bytes;
+                if (c->enc_parity) {                       // this call's turn on the second region: everything carved from the first moves over
+                    const ptrdiff_t d = alt - mine;
+                    auto over = [d](auto*& q) { q = reinterpret_cast<std::remove_reference_t<decltype(q)>>(reinterpret_cast<uint8_t*>(q) + d); };
+                    over(p.status); over(p.ticket); over(p.err); over(p.need_generic); over(p.any_generic); over(p.status_gen); over(p.ticket_gen);
+                    over(p.tree1); over(p.tree2); over(p.tree1_gen); over(p.tree2_gen); over(p.pool_map);
+                    zero_other = mine; mine = alt;
+                }
+                c->enc_parity ^= 1;
+                p.zero_next = reinterpret_cast<uint32_t*>(zero_other); p.zero_next_dwords = (uint32_t)(zero_bytes / 4u);
+            }
+            const bool zeroed = pingpong && zeroed_before.valid && zeroed_before.seq + 1 == ws_seq && zeroed_before.ptr == (void*)mine &&
+                                zeroed_before.bytes == zero_bytes && zeroed_before.gen == c->enc_ws.gen;
+            if (!zeroed) HIP_TRY(hipMemsetAsync(mine, 0, zero_bytes, st));   // look-back records, tickets, flags, pool map
             // the state look-back's granules are told apart by the call's number; zeroed only when they come to lie somewhere new
             // (another arena, another shape of call) or the number wraps
             c->enc_epoch = (c->enc_epoch + 1u) & 0x1FFFFFFFu;
@@ -509,6 +538,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     c->timer.mark(kT_begin, st);
     launch_encode(p, st, &c->timer);
     c->timer.mark(kT_enc_total, st);
+    if (pingpong && zero_other) { c->prezero.ptr = zero_other; c->prezero.bytes = zero_len; c->prezero.gen = c->enc_ws.gen; c->prezero.seq = ws_seq; c->prezero.valid = true; }
     if (c->enc_adapt && place == 1) {                       // what this batch's streams look like, for the next call's set size (see above)
         if (hipMemcpyAsync(&c->host_word[12], d_stream_len, sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess) c->enc_hint_npx = p.npx;
         if (hipMemcpyAsync(&c->host_word[13], p.any_generic, sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess) c->enc_hint_images = (uint32_t)n_images;    // ... and how many flagged (flat) images it held: the grids of the next call's passes
@@ -538,6 +568,7 @@ extern "C" int qoimi_encode_images(qoimi_ctx* c, const void* d_pixels, const siz
     if (!c || !d_pixels || !pixel_offsets || !descs || !d_streams || !stream_offsets || !d_stream_len || n_images <= 0) return fail(QOIMI_E_ARG, "NULL/empty argument");
     for (int i = 0; i < n_images; ++i) if (!desc_ok(&descs[i])) return fail(QOIMI_E_ARG, "descriptor rejected (qoi.h:364-372 rules)");
     DeviceGuard guard(c->device);
+    ++c->enc_ws_seq; c->prezero.valid = false;               // (the encode workspace is laid out anew below: nothing a batch call zeroed ahead survives)
     hipStream_t st = (hipStream_t)stream;
     if (c->recheck_pending && hipStreamQuery(c->own_stream) == hipSuccess) {                  // (the repeat of the LDS-order self-test: see qoimi_encode_batch)
         c->recheck_pending = false;

@@ -92,6 +92,8 @@ struct EncParams {
     uint32_t* err;       // liveness-bound flag               -- zeroed before every launch
     uint32_t* need_generic;  // [n_images] image needs the E1/E2 path  -- zeroed before every launch
     uint32_t* any_generic;   // [1]                                    -- zeroed before every launch
+    uint32_t* zero_next;     // tree placement (may be null): the records / tickets / flags / pool map of the context's NEXT such call - this call's first
+    uint32_t zero_next_dwords;   // enc_sets launch zeroes them in passing (two such regions, used in turn), and that call needs no hipMemsetAsync
     uint32_t* host_hint;     // pinned HOST word (may be null): the first set of a call whose look-back window does not do leaves the call's number there - the next small call's choice of pass
     uint8_t* scratch;    // order-free mode: [n_images*sets_per_image][set_stride] parked sets; look-back mode (pool = 1): [pool_slots + 1][set_stride],
                          // the spilled pieces of the sets that hold a slot (the last slot is the emergency slot of an exhausted pool: err bit 1)
