@@ -145,6 +145,9 @@ long long qoimi_encode_suspect_calls(qoimi_ctx *ctx);
  * call this before reading the streams. */
 int qoimi_encode_status(qoimi_ctx *ctx, void *stream);
 
+/* Calls of this context that qoimi_encode_status encoded again order-free because a placement wait had given up (0: never). */
+long long qoimi_encode_retries(qoimi_ctx *ctx);
+
 /* Decode n_images streams that live in device memory.
  *   d_streams      stream i starts at d_streams + i*stream_stride and is sizes[i] bytes
  *   sizes          HOST int[n_images] (the `size` argument of qoi.h:289 per image)

@@ -24,8 +24,9 @@ QOI_SRGB = 0
 QOI_LINEAR = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (QOIMI_LIB: another build of the library - the experimental builds of tools/measure/build_exp.sh under build/; tests and tools only)
-LIB_PATH = os.path.abspath(os.environ["QOIMI_LIB"]) if os.environ.get("QOIMI_LIB") else os.path.join(_HERE, "lib", "libqoi_mi355x.so")
+# (tests and measurement tools that want another build of the library - the test flavour, an experimental build - set this before
+# the first call: tests/libsel.py; nothing in the environment changes it)
+LIB_PATH = os.path.join(_HERE, "lib", "libqoi_mi355x.so")
 
 EXPORTS = (
     # Part 1 — drop-in symbols (qoi.h:252,265,278,289)
@@ -34,7 +35,7 @@ EXPORTS = (
     "qoimi_ctx_create", "qoimi_ctx_destroy", "qoimi_last_error", "qoimi_encode_bound",
     "qoimi_encode_batch", "qoimi_encode_status", "qoimi_decode_batch", "qoimi_synth_frames",
     "qoimi_decode_stats", "qoimi_version", "qoimi_set_profiling", "qoimi_get_profile", "qoimi_kernel_name",
-    "qoimi_encode_suspect_calls", "qoimi_workspace_bytes", "qoimi_set_decode_record_cap", "qoimi_hash_streams", "qoimi_encode_images",
+    "qoimi_encode_suspect_calls", "qoimi_encode_retries", "qoimi_workspace_bytes", "qoimi_set_decode_record_cap", "qoimi_hash_streams", "qoimi_encode_images",
 )
 
 
@@ -62,9 +63,6 @@ def load_library() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise QoiError(f"{LIB_PATH} not built - run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)")
-    if os.environ.get("QOIMI_LIB"):
-        import sys
-        print(f"qoi_amd: QOIMI_LIB is set - loading {LIB_PATH} instead of the in-tree library (measurement builds only)", file=sys.stderr)
     lib = ctypes.CDLL(LIB_PATH)
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     lib.qoi_encode.restype = vp
@@ -107,6 +105,8 @@ def load_library() -> ctypes.CDLL:
     lib.qoimi_workspace_bytes.argtypes = [vp, ctypes.POINTER(sz)]
     lib.qoimi_encode_suspect_calls.restype = ctypes.c_longlong
     lib.qoimi_encode_suspect_calls.argtypes = [vp]
+    lib.qoimi_encode_retries.restype = ctypes.c_longlong
+    lib.qoimi_encode_retries.argtypes = [vp]
     lib.qoimi_encode_images.restype = ci
     lib.qoimi_encode_images.argtypes = [vp, vp, ctypes.POINTER(sz), ctypes.POINTER(QoiDesc), ci, vp, ctypes.POINTER(sz), vp, vp]
     lib.qoimi_hash_streams.restype = ci
@@ -247,6 +247,10 @@ class Context:
     def encode_suspect_calls(self) -> int:
         """Encode calls of this context made with the exchange probe since the last passed LDS-order check when a repeat failed (0: never)."""
         return int(self._lib.qoimi_encode_suspect_calls(self._h))
+
+    def encode_retries(self) -> int:
+        """Calls ``encode_status`` encoded again order-free because a placement wait had given up (0: never)."""
+        return int(self._lib.qoimi_encode_retries(self._h))
 
     def decode_batch(self, d_streams: int, stream_stride: int, sizes: Sequence[int], descs: Sequence[QoiDesc],
                      channels: int, d_pixels: int, pixel_stride: int, stream: int = 0) -> None:

@@ -1230,9 +1230,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         // QOI_OP_LUMA (ANDed onto the chunk bytes it leaves the second byte there, nothing for every other chunk), bits 30..31 class
         // ... bits 16..21 the pixels of the chunk (0 for QOI_OP_RGBA, whose records count for themselves)
         const uint32_t tplb = rec_template(b);
-        // (16-bit records: the first word is what makes the stored record of the chunk's bytes - mask in the low half, xor value in the high one)
-        const uint32_t first = QOIMI_REC16 ? (((i >> 28) & 1u ? 0xFFFFu : 0x00FFu) | (0x00FEu << 16)) : tplb;
-        s_lut.e[b] = make_uint2(first, (b == 0xFFu ? 0u : (i & 7u)) | ((i >> 28) & 1u ? 0x0000FF00u : 0u) | (i & 0xC0000000u) | (b == 0xFFu ? 0u : rec_pixels(tplb) << 16));
+        s_lut.e[b] = make_uint2(tplb, (b == 0xFFu ? 0u : (i & 7u)) | ((i >> 28) & 1u ? 0x0000FF00u : 0u) | (i & 0xC0000000u) | (b == 0xFFu ? 0u : rec_pixels(tplb) << 16));
     }
     if (threadIdx.x < 4u) s_lut.e[256u + threadIdx.x] = make_uint2(0u, 0u);
     __syncthreads();
@@ -1388,76 +1386,11 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
             if (live) { u32x4 v; v.x = rr[0]; v.y = rr[1]; v.z = rr[2]; v.w = rr[3]; __builtin_amdgcn_raw_buffer_store_b128(v, rs_rec, roff, 0, QOIMI_TR_STORE_AUX); roff += 1024u; }
         }
     };
-#if QOIMI_REC16
-    // 16-bit records (qoi_decode_core.h): eight steps per granule = two periods of the reader.  The stored record is the chunk's own
-    // bytes ((w32 & mask) ^ 0xFE, both from the table's first word); QOI_OP_RGB / QOI_OP_RGBA leave a quad on a record index that is a
-    // multiple of four - the chunk stays under the cursor for its four records, a null record goes out while it waits for its place.
-    auto half_granule = [&](auto half_tag, uint32_t (&hh)[8]) {
-        constexpr uint32_t H = decltype(half_tag)::value;
-#pragma unroll
-        for (uint32_t v = 0; v < 4u; ++v) {
-            const uint32_t c_info = info;
-            uint32_t adv = lut_len(c_info);
-            uint32_t r16;
-            asm("v_and_b32 %0, %1, %2\n\tv_xor_b32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=&v"(r16) : "v"(w32), "v"(tpl));
-            r16 &= 0xFFFFu;                                       // (mask 0x00FF / 0xFFFF leaves nothing above; the null entry's first word is 0)
-            if (lanes_where(lut_hi(c_info)) != 0 || any_pend) {
-                uint32_t cnt = (c_info >> 16) & 63u;
-                const bool hi = lut_hi(c_info), lo = lut_lo(c_info);
-                const uint32_t b5 = (b5hi >> ((b5sh & 3u) * 8u)) & 0xFFu;
-                if (v == 0u) {                                       // (no lane is inside a quad here)
-                    r16 = hi ? (kRec16Marker | (lo ? 0x0100u : 0u)) : r16;
-                    adv = hi ? 0u : adv; cnt = hi ? 0u : cnt;
-                    pend = hi ? 3u : 0u;
-                } else {
-                    const bool inside = pend != 0u, stall = hi && pend == 0u;
-                    const uint32_t q16 = v == 1u ? ((w32 >> 8) & 0xFFFFu) : (v == 2u ? ((w32 >> 24) | (lo ? b5 << 8 : 0u)) : 0u);
-                    r16 = inside ? q16 : (stall ? 0u : r16);
-                    adv = inside ? (v == 3u ? (lo ? 5u : 4u) : 0u) : (stall ? 0u : adv);
-                    cnt = inside ? (v == 3u ? 1u : 0u) : (stall ? 0u : cnt);
-                    if (v == 3u) { a_abs = (inside && lo) ? 1u : a_abs; a_last = (inside && lo) ? b5 : a_last; }
-                    pend = inside ? 3u - v : 0u;
-                }
-                any_pend = lanes_where(pend != 0u) != 0;
-                npix += cnt;
-            } else {
-                add_dword_byte2(npix, c_info);
-            }
-            const uint32_t nrp = rp + adv;
-            uint32_t nw32; R.peek4_rel(nrp, nw32, b5hi, b5sh);
-            active = active && nrp < end_rel;
-            const uint32_t i8 = byte0_times8(nw32);
-            const u32x2v te = *(lds_u32x2*)(lut_base + (active ? i8 : 2048u));
-            hh[4u * H + v] = r16;
-            rp = nrp; w32 = nw32; tpl = te.x; info = te.y;
-        }
-    };
-    while (lanes_where(active)) {
-        uint32_t hh[8];
-        // three register sets of the reader, two periods per granule: three granules per six periods
-        {   const bool live = active;
-            R.template turn_rel<0>(rp); half_granule(std::integral_constant<uint32_t, 0u>{}, hh);
-            R.template turn_rel<1>(rp); half_granule(std::integral_constant<uint32_t, 1u>{}, hh);
-            if (live) { u32x4 v; v.x = hh[0] | (hh[1] << 16); v.y = hh[2] | (hh[3] << 16); v.z = hh[4] | (hh[5] << 16); v.w = hh[6] | (hh[7] << 16);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_rec, roff, 0, QOIMI_TR_STORE_AUX); roff += 1024u; } }
-        {   const bool live = active;
-            R.template turn_rel<2>(rp); half_granule(std::integral_constant<uint32_t, 0u>{}, hh);
-            R.template turn_rel<0>(rp); half_granule(std::integral_constant<uint32_t, 1u>{}, hh);
-            if (live) { u32x4 v; v.x = hh[0] | (hh[1] << 16); v.y = hh[2] | (hh[3] << 16); v.z = hh[4] | (hh[5] << 16); v.w = hh[6] | (hh[7] << 16);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_rec, roff, 0, QOIMI_TR_STORE_AUX); roff += 1024u; } }
-        {   const bool live = active;
-            R.template turn_rel<1>(rp); half_granule(std::integral_constant<uint32_t, 0u>{}, hh);
-            R.template turn_rel<2>(rp); half_granule(std::integral_constant<uint32_t, 1u>{}, hh);
-            if (live) { u32x4 v; v.x = hh[0] | (hh[1] << 16); v.y = hh[2] | (hh[3] << 16); v.z = hh[4] | (hh[5] << 16); v.w = hh[6] | (hh[7] << 16);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_rec, roff, 0, QOIMI_TR_STORE_AUX); roff += 1024u; } }
-    }
-#else
     while (lanes_where(active)) {                                 // a period = one granule of four steps; three periods per turn of the register sets
         R.template turn_rel<0>(rp); granule_steps();
         R.template turn_rel<1>(rp); granule_steps();
         R.template turn_rel<2>(rp); granule_steps();
     }
-#endif
     pos = rp + R.aoff;
     if (have && !failed) {
         p.rec_gran[q] = roff >> 10;                                     // granules written
@@ -1515,41 +1448,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-#if QOIMI_REC16
-// 16-bit records: the eight 32-bit records of a granule (qoi_decode_core.h: rec16_expand_granule), on the device with the templates
-// of the one / two-byte chunks in an LDS table (256 words, indexed by the stored byte; entries 0 and 1 - null record, quad marker - are 0).
-__device__ __forceinline__ void rec16_lut_build(uint32_t* lut, uint32_t lane) {
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; ++k) { const uint32_t b = lane + 64u * k; lut[b] = b < 2u ? 0u : rec_template(b ^ 0xFEu); }
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ void rec16_expand8(const u32x4& c, const uint32_t* lut, uint32_t (&rc)[8]) {
-    const uint32_t d[4] = {c.x, c.y, c.z, c.w};
-    uint32_t t[8];
-#pragma unroll
-    for (uint32_t u = 0; u < 8u; ++u) t[u] = lut[(u & 1u) ? __builtin_amdgcn_ubfe(d[u >> 1], 16, 8) : (d[u >> 1] & 0xFFu)];      // eight table reads in flight
-#pragma unroll
-    for (uint32_t u = 0; u < 8u; ++u) {
-        const uint32_t sh = (u & 1u) * 16u;
-        uint32_t r = t[u];
-        add_byte0(r, __builtin_amdgcn_ubfe(d[u >> 1], sh + 12u, 4)); add_byte2_from0(r, __builtin_amdgcn_ubfe(d[u >> 1], sh + 8u, 4));   // QOI_OP_LUMA's second byte (0 for every other chunk)
-        rc[u] = r;
-    }
-    const bool q0 = (d[0] & 0xFFu) == kRec16Marker, q1 = (d[2] & 0xFFu) == kRec16Marker;
-    if (__builtin_expect(lanes_where(q0 || q1) != 0ull, 0)) {          // a QOI_OP_RGB / QOI_OP_RGBA quad in some lane: as the pair of records the passes know
-#pragma unroll
-        for (uint32_t k = 0; k < 2u; ++k) {
-            const uint32_t m = d[2u * k], n = d[2u * k + 1u];
-            const bool esc = k ? q1 : q0, rgba = ((m >> 8) & 1u) != 0u;
-            const uint32_t rgb = (m >> 16) | ((n & 0xFFu) << 16), a = (n >> 8) & 0xFFu;
-            rc[4u * k] = esc ? rec_make(2u, rgba ? kRecStash : 1u, rgb) : rc[4u * k];
-            rc[4u * k + 1u] = esc ? (rgba ? rec_make(3u, 1u, a) : 0u) : rc[4u * k + 1u];
-            rc[4u * k + 2u] = esc ? 0u : rc[4u * k + 2u];
-            rc[4u * k + 3u] = esc ? 0u : rc[4u * k + 3u];
-        }
-    }
-}
-#endif
 
 // P2 on records: the slot/alpha transfer of every segment from the TAIL of its records (tail_step, qoi_decode_core.h).
 // One wavefront per 64 segments reads their granule rows from the last one backwards until every lane has met a chunk that
@@ -1575,16 +1473,8 @@ __global__ __launch_bounds__(64) void dec_slot_tails(DecParams p) {
     for (uint32_t i = 0; i < most && lanes_where(t.found == 0u) != 0; i += 2u) {
         const uint32_t g0 = S.n_gran - 1u - i, g1 = S.n_gran - 2u - i;    // (wrap past row 0: far beyond n_gran, granule() returns zeros)
         const u32x4 v0 = S.granule(g0), v1 = S.granule(g1);
-#if QOIMI_REC16
-        {   const uint32_t d0[4] = {v0.x, v0.y, v0.z, v0.w}, d1[4] = {v1.x, v1.y, v1.z, v1.w};
-            uint32_t e0[8], e1[8];
-            rec16_expand_granule(d0, e0); rec16_expand_granule(d1, e1);
-            if (i < S.n_gran) { for (int k = 7; k >= 0; --k) tail_step(t, e0[k], in.a_abs, in.ac); }
-            if (i + 1u < S.n_gran) { for (int k = 7; k >= 0; --k) tail_step(t, e1[k], in.a_abs, in.ac); } }
-#else
         if (i < S.n_gran) { tail_step(t, v0.w, in.a_abs, in.ac); tail_step(t, v0.z, in.a_abs, in.ac); tail_step(t, v0.y, in.a_abs, in.ac); tail_step(t, v0.x, in.a_abs, in.ac); }
         if (i + 1u < S.n_gran) { tail_step(t, v1.w, in.a_abs, in.ac); tail_step(t, v1.z, in.a_abs, in.ac); tail_step(t, v1.y, in.a_abs, in.ac); tail_step(t, v1.x, in.a_abs, in.ac); }
-#endif
     }
     if (empty) t.found = 0u;
     if (have) p.slot_rec[q] = tail_finish(t, in.a_abs, in.ac);
@@ -1629,13 +1519,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     if (REFINE && p.only_flat) have = have && dec_image_is_flat(im.chunks_end, im.npx);      // the first round's extra passes
     if (!lanes_where(have)) return;
     RecSource S; S.init(p, blockIdx.x, lane, have ? p.rec_gran[q] : 0u);
-#if QOIMI_REC16
-    __shared__ uint32_t s_lut16[256];
-    rec16_lut_build(s_lut16, lane);
-    const uint32_t nblk = wave_max_u32(S.n_gran);                        // a granule of 16-bit records = eight steps
-#else
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);            // blocks of two granules = eight steps
-#endif
     // Records are fetched kDepth blocks ahead.  A wavefront has 20 KiB of LDS, so eight of them share a CU and the record
     // stream (4 B per chunk, 2.7 x the QOI bytes of a photograph) has to be kept in flight by the few wavefronts there are:
     // one block ahead = 2 KiB per wavefront = 4 MiB over the chip, which at ~2 us of loaded HBM latency is 2 TB/s - the plain
@@ -1646,11 +1530,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     constexpr uint32_t kDepth = QOIMI_P3_DEPTH;
     u32x4 ring[2u * kDepth];
 #pragma unroll
-#if QOIMI_REC16
-    for (uint32_t i = 0; i < kDepth; ++i) { ring[2u * i] = S.granule_nt(i); ring[2u * i + 1u] = ring[2u * i]; }
-#else
     for (uint32_t i = 0; i < 2u * kDepth; ++i) ring[i] = S.granule_nt(i);
-#endif
     const uint32_t tc_base = lds_addr_of(&s_tabc[lane]);                 // slot k at + k*256
     const uint32_t tm_lane = lds_addr_of(&s_tabm[0]) + (lane & 31u) * 4u + (lane >> 5);
     // PLAIN form, for as long as no lane of the wavefront has met a QOI_OP_RGBA record (opaque images: the whole segment): the
@@ -1688,11 +1568,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     // skip the store by writing back the word they read (see dec_summarize)
     const bool skip_runs = REFINE && j != 0u;
     // read-ahead state of the plain form: address and word of the next step's table read, address and word of the last table write
-#if QOIMI_REC16
-    uint32_t ra_cur = and_or_b32(s_lut16[ring[0].x & 0xFFu], 0x3F00u, tc_base), t_cur = 0u, wa_prev = ~0u, wv_prev = 0u;      // (the first record's template: only its slot bits count)
-#else
     uint32_t ra_cur = and_or_b32(ring[0].x, 0x3F00u, tc_base), t_cur = 0u, wa_prev = ~0u, wv_prev = 0u;
-#endif
     if (plain) t_cur = *(const lds_u32*)ra_cur;
     // One loop over the blocks, unrolled kDepth times (the ring is indexed statically: registers); a block of eight steps is
     // taken in the plain form or in the general one.  A block that holds a half of a QOI_OP_RGBA in any lane (class 3, or class 2
@@ -1703,13 +1579,8 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
 #pragma unroll
       for (uint32_t d = 0; d < kDepth; ++d) {
         const uint32_t blk = blk0 + d;
-#if QOIMI_REC16
-        uint32_t rc[8];
-        rec16_expand8(ring[2u * d], s_lut16, rc);
-#else
         const u32x4 c0 = ring[2u * d], c1 = ring[2u * d + 1u];
         const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#endif
         if (plain) {
             const uint32_t top = max(max(max(rc[0], rc[1]), max(rc[2], rc[3])), max(max(rc[4], rc[5]), max(rc[6], rc[7])));
             if (__builtin_expect(lanes_where(top >= 0xBF000000u) != 0, 0)) {
@@ -1735,12 +1606,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
             //  * the table word an INDEX names is read ONE STEP AHEAD of its use - before the previous step's table write, which
             //    is forwarded from registers when the addresses match - so the LDS round trip is not part of a step's chain.
             const u32x4 nx = ring[2u * ((d + 1u) % kDepth)];                // first record of the next block (null past the end)
-#if QOIMI_REC16
-            // (only its slot bits are looked at - the table word an INDEX names is read a step ahead - so the template alone will do)
-            const uint32_t rx[9] = {rc[0], rc[1], rc[2], rc[3], rc[4], rc[5], rc[6], rc[7], s_lut16[nx.x & 0xFFu]};
-#else
             const uint32_t rx[9] = {rc[0], rc[1], rc[2], rc[3], rc[4], rc[5], rc[6], rc[7], nx.x};
-#endif
             // whether the block has a QOI_OP_RGB in some lane: the sign bit of the OR of its records
             const uint32_t any = rc[0] | rc[1] | rc[2] | rc[3] | rc[4] | rc[5] | rc[6] | rc[7];
             auto plain_block = [&](auto rgb_tag) {
@@ -1849,11 +1715,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
         }
         // the ring slot is refilled when the block is through with it: the load goes straight into the registers the block
         // after next ... reads (a refill at the top of the block lands in shadow registers and the copies wait for it)
-#if QOIMI_REC16
-        ring[2u * d] = S.granule_nt(blk + kDepth);
-#else
         ring[2u * d] = S.granule_nt(2u * (blk + kDepth)); ring[2u * d + 1u] = S.granule_nt(2u * (blk + kDepth) + 1u);
-#endif
       }
     }
     if (have) {
@@ -2035,24 +1897,14 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     uint32_t n_desc = 0u, span_start = px_first, span_len = 0u;     // FLAT: the pixels since the value last changed: [span_start, span_start + span_len), all of them px
     uint32_t span_px = 0u;                                          // the other images: the span of long runs in the making holds this pixel
     RecSource S; S.init(p, blockIdx.x, lane, have && px_first < limit ? p.rec_gran[q] : 0u);
-#if QOIMI_REC16
-    __shared__ uint32_t s_lut16[256];
-    rec16_lut_build(s_lut16, lane);
-    const uint32_t nblk = wave_max_u32(S.n_gran);
-#else
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);
-#endif
 #ifndef QOIMI_P4_DEPTH
 #define QOIMI_P4_DEPTH 2
 #endif
     constexpr uint32_t kDepth = QOIMI_P4_DEPTH;                  // blocks of records in flight (see dec_summarize_rec)
     u32x4 ring[2u * kDepth];
 #pragma unroll
-#if QOIMI_REC16
-    for (uint32_t i = 0; i < kDepth; ++i) { ring[2u * i] = S.granule(i); ring[2u * i + 1u] = ring[2u * i]; }
-#else
     for (uint32_t i = 0; i < 2u * kDepth; ++i) ring[i] = S.granule(i);
-#endif
     Writer W;
     {   // descriptor base: the image of the wavefront's first segment (its lanes' images follow it in memory)
         const uint32_t q0 = blockIdx.x * 64u;
@@ -2079,8 +1931,13 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     const bool clip_lane = have && (j + 1u >= im.n_active || p.px_off[q + 1u] >= limit);
     // FLAT: the lane's span ends (its pixels have the value v): a descriptor for the expander, or - a few pixels - stored here
     constexpr uint32_t kMinSpan = 8;
+    // (a descriptor is written and read as two 8-byte halves: the slots in the summary region lie 520 bytes apart - 8-byte aligned, no more)
+    auto put_desc = [&](uint32_t at, uint32_t start, uint32_t len, uint32_t v) {
+        uint2* d = reinterpret_cast<uint2*>(my_desc + at);
+        d[0] = make_uint2(start, len); d[1] = make_uint2(v, 0u);
+    };
     auto close_span = [&](uint32_t v) {
-        if (span_len >= kMinSpan && n_desc < p.desc_cap) { my_desc[n_desc] = make_uint4(span_start, span_len, v, 0u); ++n_desc; }
+        if (span_len >= kMinSpan && n_desc < p.desc_cap) { put_desc(n_desc, span_start, span_len, v); ++n_desc; }
         else for (uint32_t i = 0; i < span_len; ++i) W.store_one(span_start + i, v);       // (no room: never - a span of eight takes two records at least)
         span_len = 0u;
     };
@@ -2093,12 +1950,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
             constexpr uint32_t d = decltype(dtag)::value;
             const u32x4 c0 = ring[2u * d], c1 = ring[2u * d + 1u];      // the loads issued kDepth - 1 blocks (of eight steps) ago
             if (!FLAT) W.drain_block();                         // a static number of stores (BurstWriter)
-#if QOIMI_REC16
-            uint32_t rc[8];
-            rec16_expand8(c0, s_lut16, rc); (void)c1;
-#else
             const uint32_t rc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#endif
             // Which steps of the block have a QOI_OP_RGB / QOI_OP_RGBA record, and which a run of three pixels or more, in some lane:
             // sixteen compares up front, SCALAR tests at the steps.  (A branch on a vector compare made in the step holds the
             // wavefront for ~40 cycles even when it is not taken, tools/ubench/valu_lat.hip - there were two per step.)
@@ -2123,11 +1975,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                     *(lds_u32*)(((h << 8) & 0x3F00u) | tab_base) = px;    // qoi.h:577
                     W.put2n(px, real ? 1u : 0u);
                 }
-#if QOIMI_REC16
-                ring[2u * d] = S.granule(blk + kDepth);
-#else
                 ring[2u * d] = S.granule(2u * (blk + kDepth)); ring[2u * d + 1u] = S.granule(2u * (blk + kDepth) + 1u);
-#endif
                 return;
             }
 #pragma unroll
@@ -2198,7 +2046,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                                 if (span_len != 0u && W.fpos + n2 == W.ppos && span_start + span_len + n2 == W.ppos && span_px == px) {
                                     W.ppos += rem; span_len += rem + n2; W.fpos = W.ppos; rem = 0u;
                                 } else if (n_desc + 1u < kSummaryDescs) {
-                                    if (span_len != 0u) { my_desc[n_desc] = make_uint4(span_start, span_len, span_px, 0u); ++n_desc; }
+                                    if (span_len != 0u) { put_desc(n_desc, span_start, span_len, span_px); ++n_desc; }
                                     W.ppos -= n2;
                                     W.finish();
                                     span_start = W.ppos; span_len = rem + n2; span_px = px;
@@ -2211,11 +2059,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                     }
                 }
             }
-#if QOIMI_REC16
-            ring[2u * d] = S.granule(blk + kDepth);
-#else
             ring[2u * d] = S.granule(2u * (blk + kDepth)); ring[2u * d + 1u] = S.granule(2u * (blk + kDepth) + 1u);
-#endif
         };
         static_assert(kDepth >= 1u && kDepth <= 4u, "ring slots are spelled out");
         for (uint32_t blk0 = 0; blk0 < nblk; blk0 += kDepth) {
@@ -2227,7 +2071,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     };
     if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
     if (FLAT) { if (span_len != 0u) close_span(px); W.fpos = W.ppos; }
-    else if (span_len != 0u) { my_desc[n_desc] = make_uint4(span_start, span_len, span_px, 0u); ++n_desc; }       // (a place was kept for it)
+    else if (span_len != 0u) { put_desc(n_desc, span_start, span_len, span_px); ++n_desc; }       // (a place was kept for it)
     if (FLAT || p.desc_all) {
         // segments with descriptors queue up for dec_expand_runs: one returning atomic per wavefront that has any
         const bool some = have && n_desc != 0u;
@@ -2285,17 +2129,23 @@ __global__ __launch_bounds__(256) void dec_expand_runs(DecParams p) {
         const uint4* __restrict__ dsc = desc_base != kNoRunDesc ? p.run_desc + (size_t)(desc_base + (q - seg_base)) * p.desc_cap
                                                                  : reinterpret_cast<const uint4*>(p.summary + (size_t)q * 65u);
         uint8_t* __restrict__ out = p.pixels + (size_t)img * p.pixel_stride;
-        uint4 cur = lane < n ? dsc[lane] : make_uint4(0u, 0u, 0u, 0u);
+        auto get_desc = [&](uint32_t at) {                   // (two 8-byte halves: see dec_segments_rec)
+            const uint2* d = reinterpret_cast<const uint2*>(dsc + at);
+            const uint2 a = d[0], b = d[1];
+            return make_uint4(a.x, a.y, b.x, 0u);
+        };
+        uint4 cur = lane < n ? get_desc(lane) : make_uint4(0u, 0u, 0u, 0u);
         for (uint32_t d0 = 0; d0 < n; d0 += 64u) {
-            const uint4 nxt = d0 + 64u + lane < n ? dsc[d0 + 64u + lane] : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 nxt = d0 + 64u + lane < n ? get_desc(d0 + 64u + lane) : make_uint4(0u, 0u, 0u, 0u);
             const uint32_t m = min(n - d0, 64u);
             for (uint32_t i = 0; i < m; ++i) {
                 const uint32_t start = read_lane_dyn(cur.x, i), len = read_lane_dyn(cur.y, i), px = read_lane_dyn(cur.z, i);
                 if (OCH == 4) {
                     // pixels up to the first 16-byte boundary and behind the last one as dwords (one store instruction for both ends),
                     // the aligned middle 16 bytes per lane
-                    const uint32_t head = min(len, (4u - (start & 3u)) & 3u), mid = (len - head) >> 2, tail = (len - head) & 3u;
+                    // (from the ADDRESS, not from the pixel index: an image need not begin on a 16-byte boundary)
                     uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(out) + start;
+                    const uint32_t head = min(len, (4u - ((uint32_t)(reinterpret_cast<uintptr_t>(o32) >> 2) & 3u)) & 3u), mid = (len - head) >> 2, tail = (len - head) & 3u;
                     if (lane < head + tail) o32[lane < head ? lane : head + (mid << 2) + (lane - head)] = px;
                     uint4* __restrict__ o = reinterpret_cast<uint4*>(o32 + head);
                     const uint4 w4 = make_uint4(px, px, px, px);
@@ -2304,7 +2154,7 @@ __global__ __launch_bounds__(256) void dec_expand_runs(DecParams p) {
                     // 3-byte pixels: bytes up to the first dword boundary and behind the last one singly, the middle as dwords of the
                     // repeating r,g,b pattern (the dword k dwords in starts (head + k) % 3 bytes into a pixel)
                     const uint32_t b0 = start * 3u, nb = len * 3u;
-                    const uint32_t head = min(nb, (4u - (b0 & 3u)) & 3u), mid = (nb - head) >> 2, tail = (nb - head) & 3u;
+                    const uint32_t head = min(nb, (4u - ((uint32_t)reinterpret_cast<uintptr_t>(out + b0) & 3u)) & 3u), mid = (nb - head) >> 2, tail = (nb - head) & 3u;
                     const uint32_t c0 = px & 0xFFu, c1 = (px >> 8) & 0xFFu, c2 = (px >> 16) & 0xFFu;
                     auto byte_at = [&](uint32_t ph) { return ph == 0u ? c0 : (ph == 1u ? c1 : c2); };
                     uint8_t* __restrict__ o8 = out + b0;
@@ -2348,15 +2198,8 @@ __global__ __launch_bounds__(64) void dec_sequential(DecParams p) {
         const uint32_t n = p.rec_gran[q];
         for (uint32_t g = 0; g < n && pos < limit; ++g) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(col + (size_t)g * 256u);
-#if QOIMI_REC16
-            const uint32_t dd[4] = {v.x, v.y, v.z, v.w};
-            uint32_t rr[8];
-            rec16_expand_granule(dd, rr);
-            for (uint32_t k = 0; k < 8u && pos < limit; ++k) {
-#else
             const uint32_t rr[4] = {v.x, v.y, v.z, v.w};
             for (uint32_t k = 0; k < 4u && pos < limit; ++k) {
-#endif
                 const uint32_t rec = rr[k], cls = rec_class(rec);
                 if (cls == 2u && rec_pixels(rec) == kRecStash) { stash = rec & 0x00FFFFFFu; continue; }
                 const uint32_t t = s_tab[rec & 63u];

@@ -574,40 +574,12 @@ QOIMI_HD uint32_t rec_of_chunk(unsigned long long w, uint32_t out[2]) {
     }
     out[0] = r; return 1u;
 }
-// ---- 16-bit records (round 5 experiment, a build of its own: -DQOIMI_REC16=1; tools/measure/build_rec16.sh) ----------------------------
-// The three record passes move 4 bytes per chunk (3.2 x the stream of a photograph), written once and read twice.  Here the transcoder
-// STORES two bytes per chunk - the chunk's own bytes, aligned to 16 bits - and P3 / P4 make the 32-bit record of it when they read it
-// (one LDS table word per record + the two nibbles of a LUMA's second byte: the transcoder's work, now done in both consumers):
-//   one / two-byte chunk      (b1 ^ 0xFE) | b2 << 8        b2 only for QOI_OP_LUMA; 0x0000 is the null record (b1 = 0xFE never occurs here)
-//   QOI_OP_RGB / QOI_OP_RGBA   a QUAD on a record index that is a multiple of four: 0x0001 | rgba << 8,  r | g << 8,  b | a << 8,  0x0000
-//                              (b1 = 0xFF never occurs as a one-byte record: stored byte 0x01 is the quad's marker); null records pad up to it
-// A 16-byte granule holds eight records = one block of P3 / P4.  Worst case [one-byte chunk][QOI_OP_RGB]: eight records for five
-// bytes - 3.2 stored bytes per stream byte (4 with 32-bit records), 1.6 on photographs (3.2).
-#ifndef QOIMI_REC16
-#define QOIMI_REC16 0
-#endif
-constexpr uint32_t kRec16Marker = 0x0001u;
 // records a segment of B stream bytes can leave (whole granules), granule rows and run-descriptor capacity that follow from it
-QOIMI_HD uint32_t rec_max_records(uint32_t B) { return QOIMI_REC16 ? (((B * 8u + 4u) / 5u + 8u + 7u) & ~7u) : rec_region_dwords(B); }
-QOIMI_HD uint32_t rec_rows_of(uint32_t B) { return QOIMI_REC16 ? rec_max_records(B) / 8u : rec_region_dwords(B) / 4u; }
-// the 32-bit record of a stored one / two-byte chunk record (not of a quad's records)
-QOIMI_HD uint32_t rec16_expand(uint32_t h) {
-    if ((h & 0xFFu) < 2u) return 0u;                                   // null record, quad marker
-    uint32_t r = rec_template((h & 0xFFu) ^ 0xFEu);
-    const uint32_t b2 = (h >> 8) & 0xFFu, ex = (b2 >> 4) | ((b2 & 15u) << 16);        // (b2 = 0 for every chunk but QOI_OP_LUMA)
-    return (r & 0xFF000000u) | (add_bytes(r & 0x00FFFFFFu, ex) & 0x00FFFFFFu);
-}
-// the eight 32-bit records of a granule of stored records (d: its four dwords, two records each)
-QOIMI_HD void rec16_expand_granule(const uint32_t d[4], uint32_t out[8]) {
-    for (uint32_t u = 0; u < 8u; ++u) out[u] = rec16_expand((d[u >> 1] >> ((u & 1u) * 16u)) & 0xFFFFu);
-    for (uint32_t k = 0; k < 2u; ++k) {
-        const uint32_t m = d[2u * k], n = d[2u * k + 1u];
-        if ((m & 0xFFu) != kRec16Marker) continue;
-        const uint32_t rgb = (m >> 16) | ((n & 0xFFu) << 16), a = (n >> 8) & 0xFFu, rgba = (m >> 8) & 1u;
-        out[4u * k] = rec_make(2u, rgba ? kRecStash : 1u, rgb); out[4u * k + 1u] = rgba ? rec_make(3u, 1u, a) : 0u;
-        out[4u * k + 2u] = 0u; out[4u * k + 3u] = 0u;
-    }
-}
+// (round 5 built a 16-bit record format behind -DQOIMI_REC16: the transcoder gained 6 %, P3 and P4 lost more to making the 32-bit
+// record again than they gained from half the bytes - EXPERIMENTS.md "16-bit records", profiles/r05_s8_*, r05_s9_*; the code is in
+// the history at 06d3f17)
+QOIMI_HD uint32_t rec_max_records(uint32_t B) { return rec_region_dwords(B); }
+QOIMI_HD uint32_t rec_rows_of(uint32_t B) { return rec_region_dwords(B) / 4u; }
 // The speculative slot/alpha transfer of a segment (SlotRec, the old P2 walk) read off its RECORDS, last record first.
 // QOI_COLOR_HASH is linear mod 64, so the slot the segment leaves is "what the last chunk that names a slot absolutely
 // left + the hash shifts of the relative chunks behind it": scanning backwards, shifts add up until an INDEX, an RGB or

@@ -20,7 +20,11 @@
 #include <type_traits>
 #include <vector>
 
+// The library is built with -fvisibility=hidden: what the header declares is the whole exported surface (tests/test_abi.py
+// reads it back with nm -D).
+#pragma GCC visibility push(default)
 #include "../../include/qoi_mi355x.h"
+#pragma GCC visibility pop
 #include "qoi_decode_core.h"
 #include "qoi_kernels.h"
 
@@ -97,6 +101,9 @@ struct qoimi_ctx {
     long long dec_stats[4] = {0, 0, 0, 0};
     uint32_t seg_bytes = 0;     // decode segment size; 0: chosen per call from the batch's stream bytes
     uint32_t* last_enc_err = nullptr;   // device flag of the most recent encode launch
+    uint32_t* last_enc_err2 = nullptr;  // ... of the other channel group of a qoimi_encode_images call that held 3- and 4-channel images
+    void* enc_pin_buf = nullptr; size_t enc_pin_cap = 0; hipEvent_t enc_pin_ev = nullptr;   // pinned staging of qoimi_encode_images' tables (its own: the call is
+                                        // asynchronous, decode calls reuse pin_buf at once) and the event behind the last copies out of it
     bool xchg_ordered = false;          // result of the LDS exchange-order self-test (enc_slabs PROBE 1)
     long long enc_calls = 0;            // encode calls so far: the self-test is repeated every enc_recheck_every of them
     long long enc_calls_at_check = 0;   // ... as of the launch of the repeat in flight (or of the last one)
@@ -106,9 +113,13 @@ struct qoimi_ctx {
     bool recheck_failed_unreported = false;   // a repeat failed: the next qoimi_encode_status reports it (once)
     bool test_force_recheck_fail = false;     // env QOIMI_TEST_FORCE_RECHECK_FAIL (tests): every repeat counts as failed
     int enc_ticket = 1, enc_set_slabs = 0, enc_warm = 1;   // tuning / test knobs (env QOIMI_ENC_*)
-    int enc_tree_ticket = 0;            // env QOIMI_ENC_TREE_TICKET=1: tree placement hands its units out by one ticket per workgroup (start order) instead of by workgroup index
+    bool dropin = false;                // the context of a thread's qoi_encode / qoi_decode calls (thread_ctx)
+    int enc_tree_ticket = -1;           // -1: 1 for qoimi_encode_batch, 0 inside the drop-in qoi_encode.  1: tree placement hands its units out by one ticket per workgroup (start order: no assumption about the dispatcher); 0 (QOIMI_ENC_TREE_TICKET=0,
+                                        // and always inside the drop-in qoi_encode, which encodes again by itself): by workgroup index, 4 us less per 4K frame
+    int dec_fused = 1;                  // env QOIMI_DEC_FUSED=0: calls of a few images take the three-level chains of the batch path instead of the single-pass look-back kernels
     uint32_t test_spin_bound = 0;       // env QOIMI_TEST_SPIN_BOUND (tests): polls before a placement wait gives up
-    bool worst_case_buffer = false;     // env QOIMI_ENCODE_WORST_CASE_BUFFER=1 (read once, at creation): qoi_encode returns the reference's worst-case allocation
+    bool tight_buffer = false;          // env QOIMI_ENCODE_TIGHT_BUFFER=1 (read once, at creation): qoi_encode sizes its result by the thread's previous stream instead of
+                                        // returning the reference's worst-case allocation (qoi.h:374-379)
     int enc_gen_slabs = 0;              // env QOIMI_ENC_GEN_SLABS (1..16): slabs per set of the pass over flagged images; 0: kEncGenSetSlabs, twice that for
                                         // calls of 3 x 65536 slabs and more (8 / 12 / 16 slabs, 1024 frames: constant 7.69 / 7.34 / 6.75 ms, uiflat 20.62 / 20.49 / 20.34,
                                         // 512 sprites 8.86 / 8.70 / 8.76 - profiles/r05_s22_enc_gen_slabs16.txt; a single frame has too few sets for that)
@@ -192,44 +203,40 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         c->own_stream = pst;           // also the stream of the drop-in entry points (one context per calling thread)
         c->xchg_ordered = run_lds_order_selftest(pst) == 0;
     }
+    c->host_word[12] = 0u; c->host_word[13] = 0u; c->host_word[14] = 0u; c->host_word[15] = 0u;
+    // Documented settings: the order-independent colour-table probe from the start; the tight result buffer of qoi_encode.
     if (const char* e = getenv("QOIMI_ENC_PROBE")) { if (atoi(e) == 0) c->xchg_ordered = false; }
-    if (const char* e = getenv("QOIMI_ENC_RECHECK_EVERY")) { long v = atol(e); if (v >= 1) c->enc_recheck_every = v; }
-    if (const char* e = getenv("QOIMI_TEST_FORCE_RECHECK_FAIL")) c->test_force_recheck_fail = atoi(e) != 0;
-    if (const char* e = getenv("QOIMI_ENC_TICKET")) c->enc_ticket = atoi(e);
-    if (const char* e = getenv("QOIMI_ENC_SET_SLABS")) c->enc_set_slabs = atoi(e);
-    if (const char* e = getenv("QOIMI_ENC_DEBUG_DUMP")) c->enc_debug_dump = e;
-    if (const char* e = getenv("QOIMI_ENC_WARM")) c->enc_warm = atoi(e);
-    if (const char* e = getenv("QOIMI_ENC_LOOKBACK")) c->enc_lookback = atoi(e);
-    if (const char* e = getenv("QOIMI_ENC_SPREAD")) c->enc_spread = atoi(e) != 0;
-    if (const char* e = getenv("QOIMI_ENC_TREE_TICKET")) c->enc_tree_ticket = atoi(e) != 0;
-    if (const char* e = getenv("QOIMI_ENC_ADAPT")) c->enc_adapt = atoi(e) != 0;
-    if (const char* e = getenv("QOIMI_ENC_G2")) c->enc_g2 = atoi(e) != 0;
-    if (const char* e = getenv("QOIMI_ENC_ALL_G2")) c->enc_all_g2 = atoi(e) != 0;
-    if (const char* e = getenv("QOIMI_ENC_PREZERO")) c->enc_prezero = atoi(e) != 0;
-    if (const char* e = getenv("QOIMI_ENC_UNI")) c->enc_uni = atoi(e) != 0;
-    c->host_word[14] = 0u; c->host_word[15] = 0u;
-    if (const char* e = getenv("QOIMI_ENC_GEN_GRID_HOT")) { const int v = atoi(e); if (v >= 1) c->enc_gen_grid_div = v; }
-    c->host_word[13] = 0u;
-    if (const char* e = getenv("QOIMI_ENC_GEN_SLABS")) { const int v = atoi(e); if (v >= 1 && v <= (int)kEncMaxSetSlabs) c->enc_gen_slabs = v; }
-    if (const char* e = getenv("QOIMI_TEST_SPIN_BOUND")) { const long v = atol(e); if (v >= 1) c->test_spin_bound = (uint32_t)v; }
-    if (const char* e = getenv("QOIMI_ENCODE_WORST_CASE_BUFFER")) c->worst_case_buffer = atoi(e) != 0;
-    c->host_word[12] = 0u;
-    if (const char* e = getenv("QOIMI_ENC_PERSIST")) { const int v = atoi(e); if (v >= 0) c->enc_persist = v; }
-    if (const char* e = getenv("QOIMI_ENC_PIPE")) c->enc_pipe = atoi(e) != 0;
-    if (const char* e = getenv("QOIMI_DEC_FINE")) c->dec_fine = atoi(e);
-    if (const char* e = getenv("QOIMI_DEC_REFINE")) c->dec_refine = atoi(e);
-    if (const char* e = getenv("QOIMI_P3_PLAIN")) c->dec_p3_plain = atoi(e);
-    if (const char* e = getenv("QOIMI_DEC_INNER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner = v; }
-    if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
-    if (const char* e = getenv("QOIMI_DEC_L2M")) c->dec_l2_wgs = atoi(e);
-    if (const char* e = getenv("QOIMI_DEC_RUN_DESC")) c->dec_run_desc = atoi(e);
-    if (const char* e = getenv("QOIMI_DEC_FLAT_SEG")) c->dec_flat_seg = atoi(e);
-    if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
-    if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
-    if (const char* e = getenv("QOIMI_SEG_BYTES")) {
-        long v = atol(e);
-        if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v;
+    if (const char* e = getenv("QOIMI_ENCODE_TIGHT_BUFFER")) c->tight_buffer = atoi(e) != 0;
+    // Everything else in the environment is a measurement / test knob and is looked at only under QOIMI_TUNING=1 (tests/conftest.py and
+    // tools/measure set it): an inherited QOIMI_* variable cannot change kernels, segment sizes or placement of a production process.
+    const char* tune = getenv("QOIMI_TUNING");
+    if (tune && atoi(tune) != 0) {
+        auto knob = [](const char* name, int& v) { if (const char* e = getenv(name)) v = atoi(e); };
+        auto flag = [](const char* name, int& v) { if (const char* e = getenv(name)) v = atoi(e) != 0; };
+        if (const char* e = getenv("QOIMI_ENC_RECHECK_EVERY")) { long v = atol(e); if (v >= 1) c->enc_recheck_every = v; }
+        knob("QOIMI_ENC_TICKET", c->enc_ticket); knob("QOIMI_ENC_SET_SLABS", c->enc_set_slabs); knob("QOIMI_ENC_WARM", c->enc_warm);
+        knob("QOIMI_ENC_LOOKBACK", c->enc_lookback);
+        if (const char* e = getenv("QOIMI_ENC_DEBUG_DUMP")) c->enc_debug_dump = e;
+        flag("QOIMI_ENC_SPREAD", c->enc_spread); flag("QOIMI_ENC_TREE_TICKET", c->enc_tree_ticket); flag("QOIMI_ENC_ADAPT", c->enc_adapt);
+        flag("QOIMI_ENC_G2", c->enc_g2); flag("QOIMI_ENC_ALL_G2", c->enc_all_g2); flag("QOIMI_ENC_PREZERO", c->enc_prezero); flag("QOIMI_ENC_UNI", c->enc_uni);
+        flag("QOIMI_ENC_PIPE", c->enc_pipe);
+        if (const char* e = getenv("QOIMI_ENC_GEN_GRID_HOT")) { const int v = atoi(e); if (v >= 1) c->enc_gen_grid_div = v; }
+        if (const char* e = getenv("QOIMI_ENC_GEN_SLABS")) { const int v = atoi(e); if (v >= 1 && v <= (int)kEncMaxSetSlabs) c->enc_gen_slabs = v; }
+        if (const char* e = getenv("QOIMI_ENC_PERSIST")) { const int v = atoi(e); if (v >= 0) c->enc_persist = v; }
+        knob("QOIMI_DEC_FINE", c->dec_fine); knob("QOIMI_DEC_REFINE", c->dec_refine); knob("QOIMI_P3_PLAIN", c->dec_p3_plain);
+        if (const char* e = getenv("QOIMI_DEC_INNER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner = v; }
+        if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
+        knob("QOIMI_DEC_L2M", c->dec_l2_wgs); knob("QOIMI_DEC_RUN_DESC", c->dec_run_desc); knob("QOIMI_DEC_FLAT_SEG", c->dec_flat_seg);
+        knob("QOIMI_DEC_FUSED", c->dec_fused);
+        if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
+        if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
+        if (const char* e = getenv("QOIMI_SEG_BYTES")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v; }
     }
+#ifdef QOIMI_TEST_HOOKS
+    // failure injection, compiled into the test flavour of the library only (make TEST_HOOKS=1 -> libqoi_mi355x_test.so)
+    if (const char* e = getenv("QOIMI_TEST_FORCE_RECHECK_FAIL")) c->test_force_recheck_fail = atoi(e) != 0;
+    if (const char* e = getenv("QOIMI_TEST_SPIN_BOUND")) { const long v = atol(e); if (v >= 1) c->test_spin_bound = (uint32_t)v; }
+#endif
     *out = c;
     return QOIMI_OK;
 }
@@ -242,6 +249,8 @@ extern "C" void qoimi_ctx_destroy(qoimi_ctx* c) {
     c->enc_ws.release(); c->dec_ws.release(); c->io_a.release(); c->io_b.release(); c->io_c.release();
     if (c->host_word) (void)hipHostFree(c->host_word);
     if (c->pin_buf) (void)hipHostFree(c->pin_buf);
+    if (c->enc_pin_buf) (void)hipHostFree(c->enc_pin_buf);
+    if (c->enc_pin_ev) (void)hipEventDestroy(c->enc_pin_ev);
     delete c;
 }
 
@@ -308,6 +317,7 @@ extern "C" const char* qoimi_kernel_name(int i) {
 }
 
 extern "C" long long qoimi_encode_suspect_calls(qoimi_ctx* c) { return c ? c->enc_suspect_calls : 0; }
+extern "C" long long qoimi_encode_retries(qoimi_ctx* c) { return c ? c->enc_retries : 0; }
 
 // device memory the context holds: [0] encode workspace, [1] decode workspace, [2] staging of the host-pointer entry points
 extern "C" void qoimi_workspace_bytes(qoimi_ctx* c, size_t out[3]) {
@@ -416,10 +426,12 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         // Tree: units by workgroup index (a wait is for lower-numbered sets, which the dispatcher started earlier - true of one launch
         // on an idle device; two launches from different streams could in principle hold each other's predecessors out: the waits are
         // bounded - 2^15 polls, tens of milliseconds, where a set's predecessors finish within microseconds - a tripped bound ends every
-        // wait of the launch and the call is encoded again order-free by qoi_encode / qoimi_encode_status).  QOIMI_ENC_TREE_TICKET=1:
-        // one ticket per workgroup hands the units out in START order instead - no assumption at all, 4 us more per 4K frame
-        // (46.8 against 42.6 us, 720p 23.8 against 21.5: profiles/r05_s1_single_ticket.txt).
-        if (place == 2) { p.spread = 0; p.use_ticket = c->enc_tree_ticket ? 1 : 0; }
+        // wait of the launch and the call is encoded again order-free by qoi_encode / qoimi_encode_status).  That form is what the
+        // drop-in qoi_encode takes (it reads the error word and encodes again by itself).  qoimi_encode_batch (round 6: the default)
+        // hands the units out by one ticket per workgroup - START order, no assumption about the dispatcher, so a caller that only
+        // synchronises its stream never reads a truncated stream - 4 us more per 4K frame (46.8 against 42.6 us, 720p 23.8 against
+        // 21.5: profiles/r05_s1_single_ticket.txt).
+        if (place == 2) { p.spread = 0; p.use_ticket = (c->enc_tree_ticket >= 0 ? c->enc_tree_ticket != 0 : !c->dropin) ? 1 : 0; }
     }
     const int place = p.lookback;
     const bool lookback = place != 0;
@@ -530,8 +542,11 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
             p.epoch = c->enc_epoch;
         }
     }
+    // (a call that lays the workspace out WITHOUT state granules writes scratch, tables or summaries where an earlier call's granules lay:
+    // the next call with granules must zero them again, whatever it finds at the same address)
+    if (!g2_bytes) c->g2_zeroed_at = nullptr;
     p.out = (uint8_t*)d_streams; p.out_stride = stream_stride; p.out_len = d_stream_len;
-    c->last_enc_err = p.err;
+    c->last_enc_err = p.err; c->last_enc_err2 = nullptr;
     if (c->timer.n > KernelTimer::kMax - 32) { HIP_TRY(hipStreamSynchronize(st)); timer_collect(c); }
     // (Running the placement passes of one sub-batch on a second stream beside the slab passes of the next was tried in round
     // 2: 4.996 vs 4.986 ms per 256 4K frames - the two kernels time-slice the CUs, nothing overlaps.)
@@ -569,6 +584,7 @@ extern "C" int qoimi_encode_images(qoimi_ctx* c, const void* d_pixels, const siz
     for (int i = 0; i < n_images; ++i) if (!desc_ok(&descs[i])) return fail(QOIMI_E_ARG, "descriptor rejected (qoi.h:364-372 rules)");
     DeviceGuard guard(c->device);
     ++c->enc_ws_seq; c->prezero.valid = false;               // (the encode workspace is laid out anew below: nothing a batch call zeroed ahead survives)
+    c->g2_zeroed_at = nullptr;                               // ... nor the state granules of an earlier batch call
     hipStream_t st = (hipStream_t)stream;
     if (c->recheck_pending && hipStreamQuery(c->own_stream) == hipSuccess) {                  // (the repeat of the LDS-order self-test: see qoimi_encode_batch)
         c->recheck_pending = false;
@@ -581,11 +597,10 @@ extern "C" int qoimi_encode_images(qoimi_ctx* c, const void* d_pixels, const siz
     }
     ++c->enc_calls;
     c->last_enc.valid = false;
-    c->last_enc_err = nullptr;
+    c->last_enc_err = nullptr; c->last_enc_err2 = nullptr;
     // the table of a channel group travels through pinned staging; both groups' tables and workspaces live side by side in the
     // arena (the second group's launches follow the first's on the stream and must not overwrite what those still read)
     size_t ws_off = 0;
-    std::vector<uint32_t*> errs;
     for (int pass = 0; pass < 2; ++pass) {               // pass 0 measures the arena (both groups), pass 1 carves and launches
         ws_off = 0;
         size_t pin_off = 0;
@@ -636,26 +651,28 @@ extern "C" int qoimi_encode_images(qoimi_ctx* c, const void* d_pixels, const siz
             if (pass) {
                 const size_t tbytes = tab.size() * sizeof(EncImage);
                 if (hipMemsetAsync((uint8_t*)c->enc_ws.base + ws_off, 0, zero_bytes, st) != hipSuccess) return fail(QOIMI_E_INTERNAL, "hipMemsetAsync failed");
-                memcpy((uint8_t*)c->pin_buf + pin_off, tab.data(), tbytes);
-                HIP_TRY(hipMemcpyAsync(d_tab, (uint8_t*)c->pin_buf + pin_off, tbytes, hipMemcpyHostToDevice, st));
+                memcpy((uint8_t*)c->enc_pin_buf + pin_off, tab.data(), tbytes);
+                HIP_TRY(hipMemcpyAsync(d_tab, (uint8_t*)c->enc_pin_buf + pin_off, tbytes, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipEventRecord(c->enc_pin_ev, st));
                 p.img_tab = d_tab; p.out_len = d_stream_len;           // (written at EncImage::len_index: the caller's image number)
-                errs.push_back(p.err);
                 launch_encode_mixed(p, (uint32_t)units, (uint32_t)slabs, (uint32_t)groups, (uint32_t)sets, st, &c->timer);
-                c->last_enc_err = p.err;
+                c->last_enc_err2 = c->last_enc_err; c->last_enc_err = p.err;       // (qoimi_encode_status looks at both channel groups)
             }
             ws_off += used;
             pin_off += (tab.size() * sizeof(EncImage) + 255u) & ~(size_t)255u;
         }
         if (!pass) {
             int rc = c->enc_ws.reserve(ws_off + 256); if (rc) return rc;
-            // (the staging of the previous call's tables may still be read by its copies: wait for the stream before it is overwritten)
+            // The staging of the previous call's tables may still be read by its copies - on whatever stream that call ran: wait for the
+            // event recorded behind them (not for the stream: the call stays asynchronous) before the buffer is overwritten or freed.
             const size_t need = (size_t)(n_images + 2) * sizeof(EncImage) + 1024u;
-            HIP_TRY(hipStreamSynchronize(st));
-            if (need > c->pin_cap) {
-                if (c->pin_buf) (void)hipHostFree(c->pin_buf);
-                c->pin_buf = nullptr; c->pin_cap = 0;
-                HIP_TRY(hipHostMalloc(&c->pin_buf, need + 4096));
-                c->pin_cap = need + 4096;
+            if (!c->enc_pin_ev) HIP_TRY(hipEventCreateWithFlags(&c->enc_pin_ev, hipEventDisableTiming));
+            else HIP_TRY(hipEventSynchronize(c->enc_pin_ev));
+            if (need > c->enc_pin_cap) {
+                if (c->enc_pin_buf) (void)hipHostFree(c->enc_pin_buf);
+                c->enc_pin_buf = nullptr; c->enc_pin_cap = 0;
+                HIP_TRY(hipHostMalloc(&c->enc_pin_buf, need + 4096));
+                c->enc_pin_cap = need + 4096;
             }
         }
     }
@@ -670,25 +687,29 @@ extern "C" int qoimi_encode_status(qoimi_ctx* c, void* stream) {
     if (!c) return fail(QOIMI_E_ARG, "ctx is NULL");
     DeviceGuard guard(c->device);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (c->last_enc.valid && c->last_enc.st != stream) HIP_TRY(hipStreamSynchronize((hipStream_t)c->last_enc.st));   // the stream the call was made on
     if (c->recheck_failed_unreported) {
         c->recheck_failed_unreported = false;
         return fail(QOIMI_E_INTERNAL, "the LDS exchange-order self-test failed on repetition: " + std::to_string(c->enc_suspect_calls) +
                     " earlier encode calls of this context are suspect (qoimi_encode_suspect_calls); the context now uses the order-free probe");
     }
     if (!c->last_enc_err) return QOIMI_OK;
-    uint32_t err = 0;
+    uint32_t err = 0, err2 = 0;
     HIP_TRY(hipMemcpy(&err, c->last_enc_err, sizeof err, hipMemcpyDeviceToHost));
+    if (c->last_enc_err2) { HIP_TRY(hipMemcpy(&err2, c->last_enc_err2, sizeof err2, hipMemcpyDeviceToHost)); err |= err2; }
     if (err && c->last_enc.valid && c->enc_lookback != 0) {
         // A placement wait gave up (never observed: the sets a wait is for are resident or done unless another stream's launch holds
         // them out) or the scratch pool ran dry: the call is encoded again ORDER-FREE - no set waits for another, every set has a
-        // scratch slot of its own - from the caller's buffers, which it has not read yet (it is asking for the status first).
+        // scratch slot of its own - from the caller's buffers, which it has not read yet (it is asking for the status first), on the
+        // stream the call was made on (the one this function waits for next, whatever `stream` is).
         const int forced = c->enc_lookback;
         c->enc_lookback = 0;
         c->last_enc.valid = false;
-        const int rc = qoimi_encode_batch(c, c->last_enc.px, c->last_enc.ps, &c->last_enc.desc, c->last_enc.n, c->last_enc.out, c->last_enc.os, c->last_enc.len, c->last_enc.st);
+        const auto again = c->last_enc;
+        const int rc = qoimi_encode_batch(c, again.px, again.ps, &again.desc, again.n, again.out, again.os, again.len, again.st);
         c->enc_lookback = forced;
         if (rc != QOIMI_OK) return rc;
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)again.st));
         HIP_TRY(hipMemcpy(&err, c->last_enc_err, sizeof err, hipMemcpyDeviceToHost));
         c->enc_retries += 1;
     }
@@ -908,9 +929,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     const uint32_t B = choose_seg_bytes(c, sizes, descs, n_images);
     // The chunk records take four bytes per stream byte (worst case) while a call is in flight.  Calls whose streams would
     // need more than dec_rec_cap are decoded as consecutive sub-batches of whole images through the same workspace.
-    // (16-bit records: 3.2 stored bytes per stream byte at the worst, not 4)
-    const uint64_t cap_stream = QOIMI_REC16 ? (uint64_t)(c->dec_rec_cap / 16u) * 5u - (uint64_t)(c->dec_rec_cap / 16u) * 5u / 32u
-                                            : (uint64_t)(c->dec_rec_cap / 4u) - (uint64_t)(c->dec_rec_cap / 4u) / 64u;
+    const uint64_t cap_stream = (uint64_t)(c->dec_rec_cap / 4u) - (uint64_t)(c->dec_rec_cap / 4u) / 64u;
     long long acc[4] = {0, 0, 0, 0};
     for (int first = 0; first < n_images;) {
         uint64_t bytes = 0;
@@ -1068,7 +1087,7 @@ static qoimi_ctx* thread_ctx() {
             std::lock_guard<std::mutex> lock(g_mutex);
             fprintf(stderr, "qoi_mi355x: no usable MI355X (%s); there is no CPU fallback\n", t_error.c_str());
             t_ctx.c = nullptr;
-        }
+        } else t_ctx.c->dropin = true;
     }
     return t_ctx.c;
 }
@@ -1084,13 +1103,15 @@ extern "C" void* qoi_encode(const void* data, const qoi_desc* desc, int* out_len
     const size_t bound = qoimi_encode_bound(desc);                        // qoi.h:374-376
     if (c->io_a.reserve(in_bytes + 16) || c->io_b.reserve(bound + 16) || c->io_c.reserve(256)) return NULL;
     void* result = NULL;
-    // The reference allocates the worst case (qoi.h:379) and the caller learns only *out_len; here the buffer is sized by this
-    // thread's previous stream (+ 1/8; a third of the bound at first) and replaced by an exact one in the rare case the stream
-    // turns out longer.  A 4K frame's worst case is 39.6 MiB - above the 32 MiB ceiling of glibc's dynamic mmap threshold, so every
-    // call would map, populate and (in the caller's free) unmap it: 1.1 ms of a 2.0 ms call in qoibench's encode-free loop.  A buffer
-    // of the expected size comes back from the allocator's heap with its pages in place.
-    // QOIMI_ENCODE_WORST_CASE_BUFFER=1 restores the reference's allocation for callers that count on its capacity.
-    const bool worst_case = c->worst_case_buffer;
+    // The result is the reference's allocation (qoi.h:374-379: the worst case, w * h * (channels + 1) + 22 bytes) - a caller written
+    // against the reference may count on that capacity.  Only the pages the stream will touch are populated (by the thread's parked
+    // helpers, while the pixels go in and the kernels run); the rest of the allocation stays untouched address space.  What it costs:
+    // a 4K frame's worst case is 39.6 MiB, above the 32 MiB ceiling of glibc's dynamic mmap threshold, so every call maps fresh
+    // zero-filled pages and the caller's free() unmaps them (qoibench's encode-free loop, qoibench.c:446-449: 1.7 ms per call
+    // against 0.84 with the tight buffer, profiles/r06_s1_dropin_worst_case.txt).  QOIMI_ENCODE_TIGHT_BUFFER=1 (opt-in, read when the
+    // thread's context is created) sizes the buffer by this thread's previous stream instead (+ 1/8; a third of the bound at first; an
+    // exact buffer in the rare case the stream turns out longer): it comes back from the allocator's heap with its pages in place.
+    const bool worst_case = !c->tight_buffer;
     const size_t guess = worst_case ? bound : (c->last_drop_len ? c->last_drop_len + c->last_drop_len / 8u : bound / 3u);
     size_t ahead = guess < bound ? guess : bound;
     if (ahead < (size_t)kHeaderBytes + kTrailerBytes) ahead = (size_t)kHeaderBytes + kTrailerBytes;

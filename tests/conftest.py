@@ -9,6 +9,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# The library looks at its measurement / test knobs (QOIMI_ENC_*, QOIMI_DEC_*, QOIMI_SEG_BYTES ...) only under QOIMI_TUNING=1
+# (qoi_host.hip: qoimi_ctx_create); the tests that select kernel paths with them run with it.
+os.environ["QOIMI_TUNING"] = "1"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -29,6 +29,33 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, name), name
 
 
+def test_nothing_else_is_exported():
+    """-fvisibility=hidden (qoi_amd/csrc/Makefile): the dynamic symbol table of every flavour holds the functions the header declares
+    and nothing of the implementation (no mangled qoimi:: kernels or launchers, no helper classes)."""
+    import subprocess
+    for flavour in ("libqoi_mi355x.so", "libqoi_mi355x_nostdio.so", "libqoi_mi355x_test.so"):
+        path = os.path.join(ROOT, "qoi_amd", "lib", flavour)
+        if not os.path.exists(path):
+            continue
+        syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        names = {l.split()[-1] for l in syms.splitlines() if l.strip()}
+        extra = {n for n in names if not re.fullmatch(r"qoi_[a-z]+|qoimi_[a-z_]+", n)}
+        assert not extra, (flavour, sorted(extra)[:10])
+        want = set(api.EXPORTS) - ({"qoi_write", "qoi_read"} if "nostdio" in flavour else set())
+        assert names == want, (flavour, names ^ want)
+
+
+def test_environment_knobs_are_gated(lib):
+    """The product library reads its tuning knobs only under QOIMI_TUNING=1 and holds no failure-injection hook at all: the strings
+    of the test hooks occur in the test flavour only."""
+    prod = open(os.path.join(ROOT, "qoi_amd", "lib", "libqoi_mi355x.so"), "rb").read()
+    assert b"QOIMI_TUNING" in prod and b"QOIMI_TEST_SPIN_BOUND" not in prod and b"QOIMI_TEST_FORCE_RECHECK_FAIL" not in prod
+    test = os.path.join(ROOT, "qoi_amd", "lib", "libqoi_mi355x_test.so")
+    if os.path.exists(test):
+        assert b"QOIMI_TEST_SPIN_BOUND" in open(test, "rb").read()
+    assert "QOIMI_LIB" not in open(os.path.join(ROOT, "qoi_amd", "api.py")).read()
+
+
 def test_desc_layout():
     assert ctypes.sizeof(api.QoiDesc) == 12
     assert (api.QoiDesc.width.offset, api.QoiDesc.height.offset,

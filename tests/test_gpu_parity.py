@@ -216,15 +216,15 @@ def test_round_trip_random_host_api(api, oracle):
             assert np.array_equal(got, want), (it, chn)
 
 
-@pytest.mark.parametrize("worst_case", ["0", "1"])
-def test_host_encode_result_outgrows_the_expected_size(api, oracle, worst_case):
-    """qoi_encode sizes its malloc by the calling thread's previous stream (qoi_host.hip): a flat frame, then noise (the stream is
-    two hundred times longer than expected: the exact-size path), then flat again - byte-identical every time; the same with the
-    reference's worst-case allocation (QOIMI_ENCODE_WORST_CASE_BUFFER=1)."""
+@pytest.mark.parametrize("tight", ["1", "0"])
+def test_host_encode_result_outgrows_the_expected_size(api, oracle, tight):
+    """QOIMI_ENCODE_TIGHT_BUFFER=1: qoi_encode sizes its malloc by the calling thread's previous stream (qoi_host.hip): a flat frame,
+    then noise (the stream is two hundred times longer than expected: the exact-size path), then flat again - byte-identical every
+    time; the same with the default, the reference's worst-case allocation (qoi.h:374-379), of which only the expected pages are populated."""
     from qoi_amd import synth
     w, h = 1920, 1080
     import threading
-    os.environ["QOIMI_ENCODE_WORST_CASE_BUFFER"] = worst_case
+    os.environ["QOIMI_ENCODE_TIGHT_BUFFER"] = tight
     bad = []
 
     def work():                       # a fresh thread: its context reads the variable when it is created (once, not per call)
@@ -238,28 +238,27 @@ def test_host_encode_result_outgrows_the_expected_size(api, oracle, worst_case):
         t.start(); t.join()
         assert not bad, bad
     finally:
-        del os.environ["QOIMI_ENCODE_WORST_CASE_BUFFER"]
+        del os.environ["QOIMI_ENCODE_TIGHT_BUFFER"]
+
+
+def _hook_scenario(*args):
+    """The failure-injection hooks (QOIMI_TEST_*) exist in the TEST flavour of the library only (make TEST_HOOKS=1): scenarios that
+    need them run in a child process that selects that build before its first call (tests/libsel.py, tests/hook_scenarios.py)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "hook_scenarios.py")] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
 
 
 @pytest.mark.parametrize("n,w,h", [(1, 1920, 1080), (3, 1280, 720), (12, 1280, 720)])
-def test_a_placement_wait_that_gives_up_is_encoded_again_order_free(api, oracle, n, w, h):
-    """QOIMI_TEST_SPIN_BOUND=1: every placement wait (tree for fewer than 8 images, look-back for more) that needs a second poll gives up,
-    ends the launch's other waits and leaves err set; qoimi_encode_status then encodes the call again order-free - QOIMI_OK and the
-    reference's bytes."""
-    from gpu_util import DeviceBatch
-    from qoi_amd import synth
-    os.environ["QOIMI_TEST_SPIN_BOUND"] = "1"
-    try:
-        c = api.Context(0)
-    finally:
-        del os.environ["QOIMI_TEST_SPIN_BOUND"]
-    b = DeviceBatch(c, w, h, 4, n)
-    for i in range(n):
-        c.synth_frames(synth.KIND_ID["photo"], synth.DEFAULT_SEED, 300 + i, 1, w, h, b.pixels.data_ptr() + i * b.pixel_stride, b.pixel_stride, b.stream)
-    lens = b.encode()                 # encode_batch + encode_status (raises on an error status)
-    for i in range(n):
-        assert b.stream_bytes(i, lens[i]) == oracle.encode(synth.frame_rgba("photo", w, h, 300 + i), w, h, 4), i
-    c.close()
+def test_a_placement_wait_that_gives_up_is_encoded_again_order_free(api, n, w, h):
+    """QOIMI_TEST_SPIN_BOUND=1: every placement wait (tree by workgroup index for fewer than 8 images, look-back for more) that needs a
+    second poll gives up, ends the launch's other waits and leaves err set; qoimi_encode_status then encodes the call again order-free -
+    QOIMI_OK, the reference's bytes, and qoimi_encode_retries counts it (tests/hook_scenarios.py: spin_bound)."""
+    out = _hook_scenario("spin_bound", n, w, h)
+    assert "retries" in out
 
 
 # ------------------------------------------------------------------ device batch API
@@ -490,7 +489,7 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_G2": "0", "QOIMI_ENC_LOOKBACK": "1"},
     {"QOIMI_ENC_LOOKBACK": "1"},                          # look-back placement (forced for four images): flat images by state look-back with tickets
     {"QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "1"},
-    {"QOIMI_ENC_TREE_TICKET": "1"},                       # tree placement with its units by one ticket per workgroup
+    {"QOIMI_ENC_TREE_TICKET": "0"},                       # tree placement with its units by workgroup index (the drop-in qoi_encode's form; tickets are the default)
     {"QOIMI_DEC_RUN_DESC": "0"},                          # every long run written lane by lane
     {"QOIMI_DEC_RUN_DESC": "1"},                          # run descriptors for flat images only
 ])
@@ -727,7 +726,7 @@ def test_decode_repair_loop_is_bounded(api, oracle, rounds):
 @pytest.mark.parametrize("env", [{}, {"QOIMI_ENC_WARM": "0"}, {"QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_SET_SLABS": "4"},
                                  {"QOIMI_ENC_SET_SLABS": "2", "QOIMI_ENC_LOOKBACK": "0"}, {"QOIMI_ENC_LOOKBACK": "2"}, {"QOIMI_ENC_LOOKBACK": "1"},
                                  {"QOIMI_ENC_LOOKBACK": "1", "QOIMI_ENC_SET_SLABS": "4"}, {"QOIMI_ENC_G2": "0"}, {"QOIMI_ENC_G2": "0", "QOIMI_ENC_LOOKBACK": "2"},
-                                 {"QOIMI_ENC_TREE_TICKET": "1", "QOIMI_ENC_LOOKBACK": "2"}, {"QOIMI_ENC_UNI": "1"}, {"QOIMI_ENC_UNI": "1", "QOIMI_ENC_LOOKBACK": "2"}])
+                                 {"QOIMI_ENC_TREE_TICKET": "0", "QOIMI_ENC_LOOKBACK": "2"}, {"QOIMI_ENC_UNI": "1"}, {"QOIMI_ENC_UNI": "1", "QOIMI_ENC_LOOKBACK": "2"}])
 def test_flat_frames_byte_identical(api, oracle, env):
     """Flat UI frames go through the generic entry-state path (per-slab summaries + scans).  Frame 60 of this sweep was
     encoded three bytes too long by every path until round 2: a 64-bit lane mask lost its upper half (sign extension of
@@ -1107,47 +1106,12 @@ def test_encode_batch_many_small_images(api, ctx, oracle, shape):
         assert b.stream_bytes(i, len(want)) == want, (shape, i)
 
 
-def test_failed_lds_order_recheck_is_counted_and_reported_once(api, oracle):
+def test_failed_lds_order_recheck_is_counted_and_reported_once(api):
     """The repeat of the LDS exchange-order self-test (qoi_host.hip, include/qoi_mi355x.h): forced to fail by the test hook with a
     repeat after every call.  The call that notices is encoded with the order-independent probe and succeeds, the calls made with
     the suspect probe since the last passed check are counted (all of them - the one made before the repeat was launched too),
-    and the next qoimi_encode_status reports the event exactly once."""
-    from gpu_util import DeviceBatch
-    from qoi_amd import synth
-    env = {"QOIMI_ENC_RECHECK_EVERY": "1", "QOIMI_TEST_FORCE_RECHECK_FAIL": "1"}
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        c = api.Context(0)
-        w, h = 640, 360
-        b = DeviceBatch(c, w, h, 4, 2)
-        frames = [synth.frame_rgba(k, w, h, 11 + i) for i, k in enumerate(("photo", "uiflat"))]
-        for i, f in enumerate(frames):
-            b.upload(i, f)
-        want = [oracle.encode(f, w, h, 4) for f in frames]
-        lens = b.encode()                                   # call 1: launches the first repeat
-        assert c.encode_suspect_calls() == 0
-        assert [b.stream_bytes(i, lens[i]) for i in range(2)] == want
-        import torch
-        torch.cuda.synchronize()
-        # call 2 notices the (forced) failure: it still succeeds, byte-identical, now with the order-independent probe
-        c.encode_batch(b.pixels.data_ptr(), b.pixel_stride, b.desc, b.n, b.streams.data_ptr(), b.stream_stride, b.lens.data_ptr(), b.stream)
-        assert c.encode_suspect_calls() == 1                # call 1 was made with the suspect probe
-        with pytest.raises(api.QoiError, match="self-test failed"):
-            c.encode_status(b.stream)
-        c.encode_status(b.stream)                           # reported once
-        lens = b.lens.cpu().numpy()
-        assert [b.stream_bytes(i, lens[i]) for i in range(2)] == want
-        lens = b.encode()                                   # call 3: no further repeats, nothing more to report
-        assert c.encode_suspect_calls() == 1
-        assert [b.stream_bytes(i, lens[i]) for i in range(2)] == want
-        c.close()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    and the next qoimi_encode_status reports the event exactly once (tests/hook_scenarios.py: recheck_fail, on the test flavour)."""
+    _hook_scenario("recheck_fail")
 
 
 def test_spilling_sets_share_a_scratch_pool(api, oracle):
