@@ -611,6 +611,7 @@ __global__ __launch_bounds__(64) void dec_chain_parse_l1(DecParams p) {
     const uint32_t img = find_image_by_group(p.images, p.n_images, G);
     const DecImage im = p.images[img];
     const uint32_t j0 = (G - im.grp_base) * kGrp;
+    if (j0 >= im.nseg) return;                              // a padding group between two images (DecParams::fused)
     const uint32_t cnt = min(kGrp, im.nseg - j0);
     ParseRec r = parse_identity();
     if (lane < cnt) r = p.parse[im.seg_base + j0 + lane];
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(64) void dec_chain_parse_l3(DecParams p) {
     const uint32_t img = find_image_by_group(p.images, p.n_images, G);
     const DecImage im = p.images[img];
     const uint32_t j0 = (G - im.grp_base) * kGrp;
+    if (j0 >= im.nseg) return;                              // (a padding group)
     const uint32_t cnt = min(kGrp, im.nseg - j0);
     ParseRec r = parse_identity();
     if (lane < cnt) r = p.parse[im.seg_base + j0 + lane];
@@ -1240,6 +1242,10 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     const DecImage im = p.images[img];
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
     if (MODE == 1) have = have && j >= im.start_seg && j < im.n_active && (p.sync_all || p.sync_fail[q] != 0u);
+    if (MODE == 0 && have && j >= im.nseg) {               // a padding segment between two images (DecParams::fused): nothing to read, nothing flagged
+        p.sync_fail[q] = 0; p.rec_gran[q] = 0u;
+        have = false;
+    }
     if (!lanes_where(have)) return;
     const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
     const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
@@ -1478,6 +1484,158 @@ __global__ __launch_bounds__(64) void dec_slot_tails(DecParams p) {
     }
     if (empty) t.found = 0u;
     if (have) p.slot_rec[q] = tail_finish(t, in.a_abs, in.ac);
+}
+
+// ---------------------------------------------------------------------------------
+// dec_scan_entry (round 6): S1, the tails of P2 and S2 in ONE single-pass kernel, for calls of a few images.
+//
+// A lone 4K frame at 128-byte segments is 80 000 segments, and what stood between dec_transcode<0> and P3 was ten launches -
+// dec_parse_fine (nothing to do), S1 x 3, dec_transcode<1> (nothing to do), dec_slot_tails, S2 x 3 - of which six did a microsecond
+// of work under a launch floor of 4.7 us each: 63 of the call's 228 us (profiles/r06_s1_single_dec_timeline.txt).  Both chains carry a
+// few bits per segment - pixels before the segment (a sum), slot / alpha transfer (SlotRec, closed under composition) - so they are
+// a decoupled look-back scan (the encoder's placement, qoi_encode.hip): a workgroup of 256 segments scans its own values, publishes
+// the aggregate as ONE tagged 8-byte word, looks back over the words of the workgroups in front of it 64 at a time until it meets
+// an inclusive one, publishes its own inclusive word and writes px_off / slot_in / alpha_in of its segments.  Workgroups take their
+// place by ticket (start order): whatever a workgroup waits for has started.  The word's tag is the call's number: nothing is zeroed
+// per call (qoimi_decode_batch zeroes the words when their arena is allocated and when the 16-bit tag wraps).
+// Only valid when dec_transcode<0> synchronised EVERY segment (sync_fails == 0: encoder-made streams of natural content); otherwise the
+// kernel returns at once, the host sees the counter behind the round and continues with the five-phase parse and the three-level chains.
+//   word: bits 0..28 pixels (saturating at 2^29 - 1 > QOI_PIXELS_MAX), 29..45 slot transfer, 46..61 tag, 62..63 state
+// ---------------------------------------------------------------------------------
+constexpr u64 kScanAgg = 1ull << 62, kScanIncl = 2ull << 62;
+constexpr uint32_t kScanPxCap = (1u << 29) - 1u;
+__device__ __forceinline__ uint32_t scan_sat(uint32_t a, uint32_t b) { const uint32_t s = sat_add(a, b); return s < kScanPxCap ? s : kScanPxCap; }
+__device__ __forceinline__ uint32_t slots_then(uint32_t a, uint32_t b) { return slot_pack(slot_compose(slot_unpack(a), slot_unpack(b))); }     // b after a, packed
+__device__ __forceinline__ u64 scan_word(const DecParams& p, u64 state, uint32_t px, uint32_t slots) {
+    const SlotRec r = slot_unpack(slots);
+    const uint32_t s17 = (uint32_t)r.hc | ((uint32_t)r.h_rel << 6) | ((uint32_t)r.h_alpha << 7) | ((uint32_t)r.a_abs << 8) | ((uint32_t)r.ac << 9);
+    return state | ((u64)(p.epoch & 0xFFFFu) << 46) | ((u64)s17 << 29) | (u64)(px < kScanPxCap ? px : kScanPxCap);
+}
+__device__ __forceinline__ uint32_t scan_word_slots(u64 w) {
+    const uint32_t s17 = (uint32_t)(w >> 29) & 0x1FFFFu;
+    SlotRec r; r.hc = s17 & 63u; r.h_rel = (s17 >> 6) & 1u; r.h_alpha = (s17 >> 7) & 1u; r.a_abs = (s17 >> 8) & 1u; r.ac = (s17 >> 9) & 0xFFu;
+    return slot_pack(r);
+}
+// both inclusive scans of dec_scan_entry in one loop (the two gathers of a round travel together)
+__device__ __forceinline__ void wave_scan_px_slots(uint32_t& px, uint32_t& sl, uint32_t lane) {
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up_p = gather_lane(px, lane - d), up_s = gather_lane(sl, lane - d);
+        if (lane >= d) { px = sat_add(up_p, px); sl = slot_pack(slot_compose(slot_unpack(up_s), slot_unpack(sl))); }
+    }
+}
+__global__ __launch_bounds__(kScanSegs) void dec_scan_entry(DecParams p) {
+    __shared__ uint32_t s_wpx[4], s_wsl[4], s_epx, s_esl, s_blk;
+    const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (blockIdx.x == 0u && threadIdx.x < p.n_images) p.first_bad[threadIdx.x] = 0xFFFFFFFFu;     // (whatever follows: dec_fill looks at it)
+    if (*p.sync_fails != 0u) return;                       // (every workgroup: the counter stands since dec_transcode<0> ended)
+#ifndef QOIMI_SCAN_EXP
+#define QOIMI_SCAN_EXP 0              // timing-only builds (tools/measure): 1 no tail walk, 2 no look-back, 4 no ticket - wrong pixels
+#endif
+    if ((QOIMI_SCAN_EXP & 4) == 0) { if (threadIdx.x == 0) s_blk = atomicAdd(p.scan_ticket, 1u); } else s_blk = blockIdx.x;
+    __syncthreads();
+    const uint32_t gb = s_blk;                             // this workgroup's place: segments 256 gb ... of the call
+    const uint32_t q0 = gb * kScanSegs, q = q0 + threadIdx.x;
+    const uint32_t img = find_image(p.images, p.n_images, q0);       // every image begins on a multiple of 256 segments: one image per workgroup
+    const DecImage im = p.images[img];
+    const uint32_t j = q - im.seg_base;
+    const bool have = j < im.nseg;
+    const uint32_t first_blk = im.seg_base / kScanSegs, blk = gb - first_blk;
+    if (blk == 0u && wave == 0u && im.nseg != 0u) {        // the decoder's start state (qoi.h:533-537) at the image's first segment
+        p.entry[(size_t)im.seg_base * 65u + lane] = 0u;
+        if (lane == 0) p.entry[(size_t)im.seg_base * 65u + 64u] = kInitPx;
+    }
+    // ---- the segment's own values: its pixels (dec_transcode<0> counted them) and its slot / alpha transfer from the TAIL of its records (dec_slot_tails)
+    const uint32_t npix = have ? p.parse[q].pixels[0] : 0u;
+    const SlotRec in = have ? p.slot_rec[q] : SlotRec{0, 0, 0, 0, 0};
+    RecSource S; S.init(p, (q0 >> 6) + wave, lane, have ? p.rec_gran[q] : 0u);
+    TailState t; tail_init(t);
+    t.found = (have && S.n_gran != 0u) ? 0u : 1u;
+    const bool empty = have && S.n_gran == 0u;
+    const uint32_t most = wave_max_u32(S.n_gran);
+    for (uint32_t i = 0; i < most && lanes_where(t.found == 0u) != 0 && !(QOIMI_SCAN_EXP & 1); i += 4u) {              // four rows in flight (a lane's anchor is a few records back)
+        u32x4 v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) v[k] = S.granule(S.n_gran - 1u - i - k);           // (wrap past row 0: far beyond n_gran, granule() returns zeros)
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (i + k < S.n_gran) { tail_step(t, v[k].w, in.a_abs, in.ac); tail_step(t, v[k].z, in.a_abs, in.ac); tail_step(t, v[k].y, in.a_abs, in.ac); tail_step(t, v[k].x, in.a_abs, in.ac); }
+    }
+    if (empty) t.found = 0u;
+    const SlotRec mine_r = tail_finish(t, in.a_abs, in.ac);
+    const uint32_t mine = have ? slot_pack(mine_r) : kSlotIdentity;
+    // ---- scan inside the workgroup
+    uint32_t ipx = npix, isl = mine;
+    wave_scan_px_slots(ipx, isl, lane);                                                      // inclusive over the wavefront
+    if (lane == 63u) { s_wpx[wave] = ipx; s_wsl[wave] = isl; }
+    __syncthreads();
+    uint32_t wpx = 0u, wsl = kSlotIdentity, bpx = 0u, bsl = kSlotIdentity;                   // in front of this wavefront / the whole workgroup
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t a = s_wpx[k], b = s_wsl[k];
+        if (k < wave) { wpx = scan_sat(wpx, a); wsl = slots_then(wsl, b); }
+        bpx = scan_sat(bpx, a); bsl = slots_then(bsl, b);
+    }
+    // ---- look-back over the workgroups in front of this one in its image (first wavefront)
+    if (wave == 0u) {
+        u64* const st = p.scan_status;
+        uint32_t epx = 0u, esl = kSlotIdentity;            // what stands in front of this workgroup: pixels, transfer from the image's start
+        if (blk != 0u) {
+            if (lane == 0) granule_store(&st[gb], scan_word(p, kScanAgg, bpx, bsl));
+            // Every workgroup of a lone frame starts at about the same time, so the words in front of one are aggregates, not inclusive
+            // prefixes, nearly all the way back: the look-back of the image's last workgroup is blk / 64 windows deep, and taken one
+            // after the other each was a round trip through the L2 (20 us for this kernel on a 4K frame).  Up to kScanWin windows are
+            // asked for together; a window that holds a word not yet written is asked for again.
+            constexpr int kScanWin = 8;
+            uint32_t look = blk;                           // the words of blocks [look, blk) are in (epx, esl)
+            bool done = (QOIMI_SCAN_EXP & 2) != 0;
+            while (!done) {
+                u64 w[kScanWin];
+#pragma unroll
+                for (int k = 0; k < kScanWin; ++k) {
+                    const int idx = (int)look - 64 * (k + 1) + (int)lane;                     // window k, lane 63: the nearest block not yet looked at
+                    w[k] = idx >= 0 ? granule_load(&st[first_blk + (uint32_t)idx]) : scan_word(p, kScanIncl, 0u, kSlotIdentity);   // in front of the image: nothing
+                }
+#pragma unroll
+                for (int k = 0; k < kScanWin; ++k) {
+                    if (done) break;
+                    const bool ok = ((uint32_t)(w[k] >> 46) & 0xFFFFu) == (p.epoch & 0xFFFFu) && (w[k] >> 62) != 0ull;
+                    const u64 incl = lanes_where(ok && (w[k] >> 62) == 2ull);
+                    const int stop = incl ? 63 - (int)__builtin_clzll(incl) : 0;              // nearest inclusive word (else: the whole window)
+                    if (lanes_where(!ok && (int)lane >= stop) != 0ull) { __builtin_amdgcn_s_sleep(1); break; }   // a word this block must add is not there yet: its writer has started (ticket); ask again from this window on
+                    const bool mine_w = (int)lane >= stop;
+                    uint32_t vpx = mine_w ? (uint32_t)w[k] & kScanPxCap : 0u, vsl = mine_w ? scan_word_slots(w[k]) : kSlotIdentity;
+                    wave_scan_px_slots(vpx, vsl, lane);
+                    const uint32_t wp = read_lane(vpx, 63), ws = read_lane(vsl, 63);
+                    epx = scan_sat(wp, epx); esl = slots_then(ws, esl);                        // the window first, then what was looked at before
+                    if (incl) done = true;
+                    else look -= 64u;                                                         // (no inclusive word among 64: all 64 were real blocks)
+                }
+            }
+        }
+        if (lane == 0) {
+            granule_store(&st[gb], scan_word(p, kScanIncl, scan_sat(epx, bpx), slots_then(esl, bsl)));
+            s_epx = epx; s_esl = esl;
+        }
+    }
+    __syncthreads();
+    // ---- every segment: pixels in front of it, speculated slot / alpha at its entry (S2: from the start pixel's hash and alpha)
+    const uint32_t epx = s_epx, esl = s_esl;
+    const uint32_t before = scan_sat(scan_sat(epx, wpx), from_lane_below(ipx, 0u));
+    const uint32_t my_off = min(before, im.npx);
+    uint32_t slot = hash_px(kInitPx), alpha = kInitPx >> 24;
+    slot_apply(slot_unpack(slots_then(slots_then(esl, wsl), from_lane_below(isl, kSlotIdentity))), slot, alpha);
+    if (have) { p.px_off[q] = my_off; p.slot_in[q] = (uint8_t)slot; p.alpha_in[q] = (uint8_t)alpha; p.slot_rec[q] = mine_r; }
+    // n_active: segments that start before the pixel limit.  Offsets never fall, so only the wavefront that holds the last such segment reports.
+    const u64 act = lanes_where(have && my_off < im.npx);
+    if (act != 0ull) {
+        const int top = 63 - (int)__builtin_clzll(act);
+        const uint32_t j_top = q0 + wave * 64u + (uint32_t)top - im.seg_base;
+        const uint32_t after = scan_sat(scan_sat(epx, wpx), read_lane(ipx, 63));              // pixels in front of the next wavefront's first segment
+        const bool boundary = top < 63 || j_top + 1u >= im.nseg || after >= im.npx;
+        if (boundary && lane == 0) atomicMax(&p.images[img].n_active, j_top + 1u);
+    }
+    if (threadIdx.x == 0 && q0 + kScanSegs >= im.seg_base + im.nseg) p.images[img].total_px = min(scan_sat(epx, bpx), im.npx);     // the image's last workgroup
 }
 
 // Source / mask codes of the symbolic table as BYTES, laid out so that a wavefront's access to 64 different rows is free
@@ -2223,7 +2381,7 @@ __global__ __launch_bounds__(64) void dec_sequential(DecParams p) {
 // TRUE exit state of its predecessor; the others are finished.  Counts pending images.
 __device__ __forceinline__ void prepare_restart(const DecParams& p, uint32_t img, uint32_t lane) {
     const DecImage im = p.images[img];
-    const uint32_t fb = p.first_bad[img];
+    const uint32_t fb = __hip_atomic_load(&p.first_bad[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (fb == 0xFFFFFFFFu) {
         if (lane == 0) p.images[img].start_seg = im.n_active;    // done
         return;
@@ -2247,7 +2405,19 @@ template <int OCH>
 __global__ __launch_bounds__(256) void dec_fill(DecParams p) {
     const uint32_t img = blockIdx.x / kFillSlices, slice = blockIdx.x % kFillSlices;
     const DecImage im = p.images[img];
-    if (slice == 0u && threadIdx.x < 64u && p.total_segs != 0u) prepare_restart(p, img, threadIdx.x);
+    if (p.tail_fused) {
+        // calls of a few images: the launch's first wavefront prepares every image's restart and leaves the round's counters in pinned HOST
+        // words (system-scope stores; the host waits for the stream and reads them - no copy back: 4 of a 4K frame's 205 us)
+        if (blockIdx.x == 0u && threadIdx.x < 64u) {
+            for (uint32_t i = 0; i < p.n_images; ++i) prepare_restart(p, i, threadIdx.x);
+            if (threadIdx.x == 0u) {
+                const uint32_t pend = __hip_atomic_load(p.pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), redo = __hip_atomic_load(p.redo_segs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&p.host_result[1], redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&p.host_result[2], *p.sync_fails, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&p.host_result[0], pend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    } else if (slice == 0u && threadIdx.x < 64u && p.total_segs != 0u) prepare_restart(p, img, threadIdx.x);
     if (blockIdx.x == 0u && threadIdx.x == 64u) *p.run_queue_n = 0u;        // the round's run descriptors are written out (dec_expand_runs ran before this launch)
     if (im.total_px >= im.npx) return;
     const uint32_t px = im.n_active ? im.final_px : kInitPx;
@@ -2278,6 +2448,26 @@ void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
     tm->mark(kT_dec_chain_parse, st);
 }
 
+// Calls of a few images (DecParams::fused): dec_transcode<0>, then everything P3 needs from ONE kernel (dec_scan_entry)
+void launch_decode_fused_front(const DecParams& p, hipStream_t st, KernelTimer* tm) {
+    tm->mark(kT_begin, st);
+    hipLaunchKernelGGL(dec_transcode<0>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
+    tm->mark(kT_dec_slot_walk, st);
+    hipLaunchKernelGGL(dec_scan_entry, dim3(p.total_segs / kScanSegs), dim3(kScanSegs), 0, st, p);
+    tm->mark(kT_dec_chain_slots, st);
+}
+// ... and where dec_transcode<0> could not synchronise every segment (the host reads sync_fails behind the round): the rest of
+// launch_decode_parse on the same records; the round that follows is the three-level one
+void launch_decode_parse_rest(const DecParams& p, hipStream_t st, KernelTimer* tm) {
+    tm->mark(kT_begin, st);
+    hipLaunchKernelGGL(dec_parse_fine, dim3((p.total_segs * p.fine_per_seg + 255u) / 256u), dim3(256), 0, st, p);
+    tm->mark(kT_dec_parse, st);
+    hipLaunchKernelGGL(dec_chain_parse_l1, dim3(p.total_grps), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(dec_chain_parse_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
+    hipLaunchKernelGGL(dec_chain_parse_l3, dim3(p.total_grps), dim3(64), 0, st, p);
+    tm->mark(kT_dec_chain_parse, st);
+}
+
 void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipStream_t st, KernelTimer* tm) {
     if (!p.total_segs) return;
     const uint32_t b64 = (p.total_segs + 63u) / 64u;
@@ -2302,13 +2492,15 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
             if (it + 1u < inner) chain_state();
         }
     } else {
-        hipLaunchKernelGGL(dec_transcode<1>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
-        hipLaunchKernelGGL(dec_slot_tails, dim3(b64), dim3(64), 0, st, p);
-        tm->mark(kT_dec_slot_walk, st);
-        hipLaunchKernelGGL(dec_chain_slots_l1, dim3(p.total_grps), dim3(64), 0, st, p);
-        hipLaunchKernelGGL(dec_chain_slots_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
-        hipLaunchKernelGGL(dec_chain_slots_l3, dim3(p.total_grps), dim3(64), 0, st, p);
-        tm->mark(kT_dec_chain_slots, st);
+        if (!p.fused) {                       // (fused: dec_scan_entry has left slot_in / alpha_in)
+            hipLaunchKernelGGL(dec_transcode<1>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
+            hipLaunchKernelGGL(dec_slot_tails, dim3(b64), dim3(64), 0, st, p);
+            tm->mark(kT_dec_slot_walk, st);
+            hipLaunchKernelGGL(dec_chain_slots_l1, dim3(p.total_grps), dim3(64), 0, st, p);
+            hipLaunchKernelGGL(dec_chain_slots_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
+            hipLaunchKernelGGL(dec_chain_slots_l3, dim3(p.total_grps), dim3(64), 0, st, p);
+            tm->mark(kT_dec_chain_slots, st);
+        }
         hipLaunchKernelGGL(dec_summarize_rec<false>, dim3(b64), dim3(64), 0, st, p);
         tm->mark(kT_dec_summarize, st);
     }

@@ -94,6 +94,8 @@ struct Carver {   // hands out 256-byte aligned pieces of an arena
 struct qoimi_ctx {
     int device = 0;
     Arena enc_ws, dec_ws;       // kernel workspaces
+    Arena dec_scan;             // look-back words of dec_scan_entry (calls of a few images): tagged with dec_epoch, zeroed when allocated / when the tag wraps
+    uint32_t dec_epoch = 0;     // number of the last such call (16 bits are compared)
     Arena io_a, io_b, io_c;     // staging for the host-pointer (drop-in) path
     uint32_t* host_word = nullptr;   // pinned words for read-backs
     hipStream_t own_stream = nullptr; // private non-blocking stream: self-test at creation, the drop-in entry points' work
@@ -246,7 +248,7 @@ extern "C" void qoimi_ctx_destroy(qoimi_ctx* c) {
     DeviceGuard guard(c->device);
     (void)hipDeviceSynchronize();       // calls still in flight write to the arenas and to the pinned words freed below
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-    c->enc_ws.release(); c->dec_ws.release(); c->io_a.release(); c->io_b.release(); c->io_c.release();
+    c->enc_ws.release(); c->dec_ws.release(); c->dec_scan.release(); c->io_a.release(); c->io_b.release(); c->io_c.release();
     if (c->host_word) (void)hipHostFree(c->host_word);
     if (c->pin_buf) (void)hipHostFree(c->pin_buf);
     if (c->enc_pin_buf) (void)hipHostFree(c->enc_pin_buf);
@@ -772,6 +774,10 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     int och = 0;
     std::vector<DecImage> imgs((size_t)n_images);
     uint64_t total = 0, total_g = 0, flat_total = 0;
+    // Calls of a few images take the single-pass look-back kernel for pixel offsets and speculated slots (dec_scan_entry: one launch
+    // where the three-level chains take ten); every image then begins on a multiple of kScanSegs segments.  Needs dec_transcode<0> (the
+    // 128-byte piece parse's segment sizes) and falls back to the chains by itself where that pass cannot synchronise every segment.
+    const bool fused_layout = c->dec_fused && n_images <= 4 && B % 128u == 0u && ((B / 128u == 1u) || (B / 128u >= 8u && B / 128u <= 64u)) && ((B / 128u) & (B / 128u - 1u)) == 0u && c->dec_fine;
     for (int i = 0; i < n_images; ++i) {
         if (sizes[i] < kHeaderBytes + kTrailerBytes) return fail(QOIMI_E_ARG, "stream shorter than 22 bytes (qoi.h:500)");
         if (!desc_ok(&descs[i])) return fail(QOIMI_E_ARG, "descriptor rejected (qoi.h:513-521 rules)");
@@ -786,6 +792,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         im.stream_off = (size_t)i * stream_stride;
         im.chunks_end = (uint32_t)(sizes[i] - kTrailerBytes);
         im.npx = (uint32_t)npx;
+        if (fused_layout) { total = (total + kScanSegs - 1u) / kScanSegs * kScanSegs; total_g = total / 64u; }
         im.seg_base = (uint32_t)total;
         im.nseg = (im.chunks_end - kHeaderBytes + B - 1u) / B;
         im.grp_base = (uint32_t)total_g;
@@ -795,12 +802,14 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         total += im.nseg;
         total_g += im.ngrp;
     }
+    if (fused_layout) { total = (total + kScanSegs - 1u) / kScanSegs * kScanSegs; total_g = total / 64u; }
     if (total > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (segment index overflows 32 bits)");
     DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
 
     DecParams p;
     memset(&p, 0, sizeof p);
+    bool fused = fused_layout && total != 0;
     p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
     p.rec_rows = rec_rows_of(B);
@@ -856,6 +865,20 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.recs = w.take<uint32_t>(((Q + 63u) / 64u) * p.rec_rows * 256u);
         if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }
     }
+    if (fused) {
+        const size_t words = (size_t)(total / kScanSegs) + 64u;
+        const unsigned gen = c->dec_scan.gen;
+        if (c->dec_scan.reserve(words * sizeof(u64)) != QOIMI_OK) fused = false;          // (no memory for a few KB: the chains will do)
+        else {
+            c->dec_epoch = (c->dec_epoch + 1u) & 0xFFFFu;
+            if (gen != c->dec_scan.gen || c->dec_epoch == 0u) {                           // a new arena, or the tag wraps: no word may carry a tag from before
+                HIP_TRY(hipMemsetAsync(c->dec_scan.base, 0, c->dec_scan.cap, st));
+                if (c->dec_epoch == 0u) c->dec_epoch = 1u;
+            }
+            p.fused = 1u; p.epoch = c->dec_epoch; p.scan_status = (u64*)c->dec_scan.base; p.scan_ticket = p.pending + 5;
+            p.host_result = &c->host_word[20];
+        }
+    }
     {   // image table through pinned staging: no synchronisation (every decode call ends with one, so the staging buffer is free
         // again when the next call fills it).  The four counter words in front of it (pending, redo_segs, sync_fails: the
         // arena's first 256 bytes, the table follows them) travel zeroed in the same copy: no memset launches in round one.
@@ -873,7 +896,8 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         HIP_TRY(hipMemcpyAsync(p.pending, c->pin_buf, bytes, hipMemcpyHostToDevice, st));
     }
 
-    launch_decode_parse(p, st, &c->timer);
+    if (fused) launch_decode_fused_front(p, st, &c->timer);
+    else launch_decode_parse(p, st, &c->timer);
     long long rounds = 0, stats_seq = 0;
     // A round that re-opens nearly as many segments as the one before it is not getting anywhere (a stream built against the
     // speculation: one verified segment per image and round): two such rounds in a row and the rest goes to the sequential
@@ -882,6 +906,8 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     for (;;) {
         if (rounds > 0) HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
         p.l2_tag_base = (uint32_t)rounds * 65536u + 1u;            // (a round launches S3 1 + first_inner / refine_inner times: far fewer than 65536)
+        // the first round of a call of a few images: dec_fill leaves the round's counters in pinned host words (no copy back)
+        p.tail_fused = (p.fused && rounds == 0) ? 1u : 0u;
         launch_decode_round(p, och, rounds > 0 && c->dec_refine, st, &c->timer);
         ++rounds;
         // pixels the chunks never reach (cheap; redone if the round has to be repeated) - before the read-back,
@@ -889,9 +915,24 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         launch_decode_fill(p, och, st, &c->timer);
         c->timer.mark(kT_dec_total, st);
         if (!p.total_segs) { HIP_TRY(hipStreamSynchronize(st)); break; }
-        HIP_TRY(hipMemcpyAsync(c->host_word, p.pending, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (p.tail_fused) {
+            HIP_TRY(hipStreamSynchronize(st));
+            c->host_word[0] = c->host_word[20]; c->host_word[1] = c->host_word[21]; c->host_word[2] = c->host_word[22];
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->host_word, p.pending, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
         timer_collect(c);
+        if (p.fused && c->host_word[2] != 0u) {
+            // dec_transcode<0> could not synchronise every segment (runs of equally long multi-byte chunks: noise): dec_scan_entry and
+            // everything behind it returned at once.  The five-phase parse, the three-level chains and the round again, on the records
+            // that stand (the flagged segments are transcoded by dec_transcode<1>).
+            p.fused = 0u; fused = false;
+            rounds = 0;
+            launch_decode_parse_rest(p, st, &c->timer);
+            continue;
+        }
+        p.fused = 0u;                                       // (rounds after a failed check are the three-level ones, from the image's first bad segment)
         if (c->host_word[0] == 0) break;
         {
             const uint32_t open_now = c->host_word[1] - redo_cum;

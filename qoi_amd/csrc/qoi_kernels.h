@@ -198,10 +198,25 @@ struct DecParams {
     uint32_t sync_all;         // 1: no look-back synchronisation - every segment takes the full parse (segment sizes the 128-byte piece parse does not cover)
     uint32_t* sync_fails;      // [1] segments whose look-back synchronisation failed in dec_transcode (they take the full parse)
     uint8_t*  sync_fail;       // [total_segs + 1] 1: the segment's entry position is not known yet (dec_transcode<0>)
+    // calls of a few images (round 6): pixel offsets and speculated slot / alpha of every segment by ONE single-pass look-back kernel
+    // (dec_scan_entry) instead of dec_parse_fine + S1 x 3 + dec_transcode<1> + dec_slot_tails + S2 x 3.  Every image's seg_base is a multiple
+    // of kScanSegs then (padding segments in between belong to no image), so a workgroup's segments lie in one image.
+    uint32_t  fused;           // 1: that path (the launcher's choice, qoimi_decode_batch)
+    uint32_t  epoch;           // the context's number of this call (16 bits are compared): the tag of the look-back words below
+    u64*      scan_status;     // [total_segs / kScanSegs] one tagged 8-byte word per workgroup of dec_scan_entry (aggregate / inclusive prefix);
+                               // lives in an arena of its own that is zeroed when it is allocated and when the tag wraps, never per call
+    uint32_t* scan_ticket;     // [1] workgroups take their place in start order (word 5 of the zeroed counter header)
+    // ... and the round's counters straight into pinned HOST words from dec_fill (which then prepares every image's restart in its first
+    // wavefront): no copy back behind the round, the host waits for the stream and reads them
+    uint32_t  tail_fused;      // 1: that form
+    uint32_t* host_result;     // pinned host words: [0] pending, [1] redo_segs, [2] sync_fails
 };
+constexpr uint32_t kScanSegs = 256;      // segments per workgroup of dec_scan_entry
 
 void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm);
 void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipStream_t st, KernelTimer* tm);
+void launch_decode_fused_front(const DecParams& p, hipStream_t st, KernelTimer* tm);      // dec_transcode<0> + dec_scan_entry
+void launch_decode_parse_rest(const DecParams& p, hipStream_t st, KernelTimer* tm);       // what launch_decode_parse runs behind dec_transcode<0>
 void launch_decode_fill(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);
 void launch_decode_sequential(const DecParams& p, int out_channels, hipStream_t st, KernelTimer* tm);
 constexpr int kMaxSpecRounds = 24;   // speculation rounds before the images still open are finished sequentially

@@ -7,6 +7,9 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import libsel  # noqa: E402
+libsel.use_env_library()            # QOIMI_TOOLS_LIB=<path>: the build under test
 import torch  # noqa: E402
 from qoi_amd import api, synth  # noqa: E402
 
