@@ -836,22 +836,56 @@ __device__ __forceinline__ sym_t gather_sym(sym_t tabv, sym_t pxv, uint32_t src)
     const uint32_t lo = gather_lane((uint32_t)tabv, src & 63u), hi = gather_lane((uint32_t)(tabv >> 32), src & 63u);
     return src == 64u ? pxv : ((sym_t)lo | ((sym_t)hi << 32));
 }
+// The PIXEL word of a record is the same in every lane (all 64 load rec[65 k + 64]) and so is the running pixel word: its step is
+// done once, on the scalar side - the word made known as wave-uniform (readfirstlane), its source read with v_readlane (a scalar lane
+// index: no trip through the LDS crossbar as ds_bpermute takes) and composed in SGPRs.  A step of the S3 chains was two table gathers
+// and two pixel gathers + twice the arithmetic in every lane (0.17 us per step, 188 dependent steps on a lone 4K frame); the pixel
+// half now rides along with the table half.
+__device__ __forceinline__ sym_t uniform_sym(sym_t v) {
+    return (sym_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((sym_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
+__device__ __forceinline__ sym_t read_sym_lane(sym_t tabv, sym_t pxv_u, uint32_t src_u) {       // src_u: wave-uniform
+    const uint32_t lo = read_lane_dyn((uint32_t)tabv, src_u & 63u), hi = read_lane_dyn((uint32_t)(tabv >> 32), src_u & 63u);
+    return src_u == 64u ? pxv_u : ((sym_t)lo | ((sym_t)hi << 32));
+}
 
 // The two loops of the S3 kernels.  A record is 65 symbolic words (lane k holds word k, the pixel word is read by
 // every lane); a step needs the state the previous step left, so the loop is a dependent chain of gathers - but the
 // RECORDS do not depend on it: they are fetched kChainBatch steps ahead, two batches in registers (with one record
 // of look-ahead a step cost a memory round trip, 0.4 us; the chain itself is a third of that).
+// (Round 6: batches of 32 - a group's 64 records all asked for when its chain starts - made these kernels SLOWER (l1 14.8 -> 17.1 us on
+// a lone 4K frame, the 1024-thread l2 kernels spill): a step is its own dependent chain of a gather and a dozen vector instructions,
+// 0.17 us, not a wait for records.  The pixel words of a batch travel in ONE load - lane i holds record i's - and are read with
+// v_readlane at the step.)
 constexpr int kChainBatch = 8;
-struct SymBatch { sym_t tab[kChainBatch], px[kChainBatch]; };
+struct SymBatch { sym_t tab[kChainBatch]; sym_t px; };
 // records first .. first+kChainBatch-1 of rec[0..count), indices clamped to the last record: always kChainBatch
 // loads, so the compiler can count them (loads under a branch made every wait a wait for ALL outstanding loads,
 // the prefetched batch included)
 __device__ __forceinline__ void sym_batch_load(SymBatch& b, const sym_t* __restrict__ rec, uint32_t first, uint32_t count, uint32_t lane) {
+    b.px = rec[(size_t)min(first + lane, count - 1u) * 65u + 64u];
 #pragma unroll
     for (int i = 0; i < kChainBatch; ++i) {
         const uint32_t k = min(first + (uint32_t)i, count - 1u);
-        b.tab[i] = rec[(size_t)k * 65u + lane]; b.px[i] = rec[(size_t)k * 65u + 64u];
+        b.tab[i] = rec[(size_t)k * 65u + lane];
     }
+}
+__device__ __forceinline__ sym_t batch_px(const SymBatch& b, int i) {           // record i's pixel word, wave-uniform
+    return (sym_t)read_lane((uint32_t)b.px, i) | ((sym_t)read_lane((uint32_t)(b.px >> 32), i) << 32);
+}
+// one step of a symbolic chain: P <- c o P.  c_px_u, P_px and the result's pixel word are wave-uniform.
+__device__ __forceinline__ void sym_chain_step(sym_t c_tab, sym_t c_px_u, sym_t& P_tab, sym_t& P_px) {
+    const sym_t n_tab = sym_compose(c_tab, gather_sym(P_tab, P_px, sym_src(c_tab)));
+    const sym_t n_px = sym_compose(c_px_u, read_sym_lane(P_tab, P_px, sym_src(c_px_u)));
+    P_tab = n_tab; P_px = n_px;
+}
+// one step of a concrete sweep: (tabv, pxv) <- c applied to (tabv, pxv).  c_px_u and pxv are wave-uniform.
+__device__ __forceinline__ void sym_sweep_step(sym_t c_tab, sym_t c_px_u, uint32_t& tabv, uint32_t& pxv) {
+    const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px_u);
+    const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = read_lane_dyn(tabv, src_p & 63u);
+    const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
+    const uint32_t npx = sym_eval(c_px_u, src_p == 64u ? pxv : g_p);
+    tabv = ntab; pxv = npx;
 }
 // P <- rec[count-1] o ... o rec[0] o P  (symbolic composition)
 __device__ __forceinline__ void sym_compose_range(const sym_t* __restrict__ rec, uint32_t count, uint32_t lane, sym_t& P_tab, sym_t& P_px) {
@@ -863,12 +897,7 @@ __device__ __forceinline__ void sym_compose_range(const sym_t* __restrict__ rec,
         sym_batch_load(nxt, rec, g + kChainBatch, count, lane);
 #pragma unroll
         for (int i = 0; i < kChainBatch; ++i) {
-            if ((uint32_t)i < n) {
-                const sym_t c_tab = cur.tab[i], c_px = cur.px[i];
-                const sym_t n_tab = sym_compose(c_tab, gather_sym(P_tab, P_px, sym_src(c_tab)));
-                const sym_t n_px = sym_compose(c_px, gather_sym(P_tab, P_px, sym_src(c_px)));
-                P_tab = n_tab; P_px = n_px;
-            }
+            if ((uint32_t)i < n) sym_chain_step(cur.tab[i], batch_px(cur, i), P_tab, P_px);
         }
         cur = nxt;
     }
@@ -877,6 +906,7 @@ __device__ __forceinline__ void sym_compose_range(const sym_t* __restrict__ rec,
 __device__ __forceinline__ void sym_sweep_range(const sym_t* __restrict__ rec, uint32_t count, uint32_t lane, uint32_t& tabv, uint32_t& pxv,
                                                 uint32_t* __restrict__ out, uint32_t first_out) {
     if (count == 0u) return;
+    pxv = (uint32_t)__builtin_amdgcn_readfirstlane((int)pxv);               // (the same in every lane: say so, the pixel half of a step is scalar work)
     SymBatch cur, nxt;
     sym_batch_load(cur, rec, 0u, count, lane);
     for (uint32_t g = 0; g < count; g += kChainBatch) {
@@ -889,12 +919,7 @@ __device__ __forceinline__ void sym_sweep_range(const sym_t* __restrict__ rec, u
                     out[(size_t)(g + i) * 65u + lane] = tabv;
                     if (lane == 0) out[(size_t)(g + i) * 65u + 64u] = pxv;
                 }
-                const sym_t c_tab = cur.tab[i], c_px = cur.px[i];
-                const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px);
-                const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = gather_lane(tabv, src_p & 63u);
-                const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
-                const uint32_t npx = sym_eval(c_px, src_p == 64u ? pxv : g_p);
-                tabv = ntab; pxv = npx;
+                sym_sweep_step(cur.tab[i], batch_px(cur, i), tabv, pxv);
             }
         }
         cur = nxt;
@@ -934,16 +959,11 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2(DecParams p)
     if (wave == 0) {   // B: concrete entry state of every share
         const size_t q0 = (size_t)im.seg_base + im.start_seg;
         uint32_t tabv = p.entry[q0 * 65u + lane];        // concrete entry state of start_seg is given
-        uint32_t pxv = p.entry[q0 * 65u + 64u];
+        uint32_t pxv = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.entry[q0 * 65u + 64u]);
         for (uint32_t c = 0; c < kL2Waves; ++c) {
             s_ent[c][lane] = tabv;
             if (lane == 0) s_ent[c][64] = pxv;
-            const sym_t c_tab = s_sum[c][lane], c_px = s_sum[c][64];
-            const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px);
-            const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = gather_lane(tabv, src_p & 63u);
-            const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
-            const uint32_t npx = sym_eval(c_px, src_p == 64u ? pxv : g_p);
-            tabv = ntab; pxv = npx;
+            sym_sweep_step(s_sum[c][lane], uniform_sym(s_sum[c][64]), tabv, pxv);
         }
     }
     __syncthreads();
@@ -993,27 +1013,18 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2m(DecParams p
         // B2: concrete state at this workgroup's entry, then at every share's entry
         const size_t q0 = (size_t)im.seg_base + im.start_seg;
         uint32_t tabv = p.entry[q0 * 65u + lane];        // concrete entry state of start_seg is given
-        uint32_t pxv = p.entry[q0 * 65u + 64u];
+        uint32_t pxv = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.entry[q0 * 65u + 64u]);
         for (uint32_t c = 0; c < k; ++c) {
             while (__hip_atomic_load(&p.l2_flag[img * W + c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(2);
             const sym_t* in = p.l2_sum + (size_t)(img * W + c) * 65u;
             const sym_t c_tab = __hip_atomic_load(&in[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const sym_t c_px = __hip_atomic_load(&in[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px);
-            const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = gather_lane(tabv, src_p & 63u);
-            const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
-            const uint32_t npx = sym_eval(c_px, src_p == 64u ? pxv : g_p);
-            tabv = ntab; pxv = npx;
+            sym_sweep_step(c_tab, uniform_sym(c_px), tabv, pxv);
         }
         for (uint32_t c = 0; c < kL2Waves; ++c) {
             s_ent[c][lane] = tabv;
             if (lane == 0) s_ent[c][64] = pxv;
-            const sym_t c_tab = s_sum[c][lane], c_px = s_sum[c][64];
-            const uint32_t src_t = sym_src(c_tab), src_p = sym_src(c_px);
-            const uint32_t g_t = gather_lane(tabv, src_t & 63u), g_p = gather_lane(tabv, src_p & 63u);
-            const uint32_t ntab = sym_eval(c_tab, src_t == 64u ? pxv : g_t);
-            const uint32_t npx = sym_eval(c_px, src_p == 64u ? pxv : g_p);
-            tabv = ntab; pxv = npx;
+            sym_sweep_step(s_sum[c][lane], uniform_sym(s_sum[c][64]), tabv, pxv);
         }
     }
     __syncthreads();
@@ -1033,6 +1044,54 @@ __global__ __launch_bounds__(64) void dec_chain_state_l3(DecParams p) {
     // start_seg's entry state is given, never rewritten
     sym_sweep_range(p.summary + (size_t)(im.seg_base + lo) * 65u, hi - lo, lane, tabv, pxv,
                     p.entry + (size_t)(im.seg_base + lo) * 65u, lo == im.start_seg ? 1u : 0u);
+}
+
+// The group levels with FOUR wavefronts per group (calls of a few images, round 6).  A step of these chains is a dependent gather + a
+// dozen vector instructions, 0.17 us whatever is done about its loads, and a lone 4K frame's decode spent 64 of them in l1 and 64 in l3
+// one after the other (15 + 16 us).  Here a wavefront composes / sweeps a QUARTER of the group: l1 = 16 steps + 4 to compose the
+// quarters, l3 = up to 3 steps over the quarters in front + 16 - the same function of the summaries, a third of the depth.
+__global__ __launch_bounds__(256) void dec_chain_state_l1q(DecParams p) {
+    __shared__ sym_t s_q[4][65];
+    const uint32_t G = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t img = find_image_by_group(p.images, p.n_images, G);
+    const DecImage im = p.images[img];
+    const uint32_t j0 = (G - im.grp_base) * kGrp;
+    if (j0 + kGrp <= im.start_seg || j0 >= im.n_active) return;
+    const uint32_t lo = max(j0, im.start_seg), hi = min(j0 + kGrp, im.n_active);
+    const uint32_t wlo = max(lo, j0 + 16u * wave), whi = min(hi, j0 + 16u * wave + 16u);
+    sym_t P_tab = sym_make(0u, lane, 0u), P_px = sym_make(0u, 64u, 0u);          // identity
+    sym_compose_range(p.summary + (size_t)(im.seg_base + wlo) * 65u, whi > wlo ? whi - wlo : 0u, lane, P_tab, P_px);
+    sym_t* const qs = p.qtr_summary + ((size_t)G * 4u + wave) * 65u;
+    qs[lane] = P_tab; s_q[wave][lane] = P_tab;
+    if (lane == 0) { qs[64] = P_px; s_q[wave][64] = P_px; }
+    __syncthreads();
+    if (wave != 0u) return;
+    P_tab = sym_make(0u, lane, 0u); P_px = sym_make(0u, 64u, 0u);
+    sym_compose_range(&s_q[0][0], 4u, lane, P_tab, P_px);
+    p.grp_summary[(size_t)G * 65u + lane] = P_tab;
+    if (lane == 0) p.grp_summary[(size_t)G * 65u + 64u] = P_px;
+}
+__global__ __launch_bounds__(256) void dec_chain_state_l3q(DecParams p) {
+    const uint32_t G = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t img = find_image_by_group(p.images, p.n_images, G);
+    const DecImage im = p.images[img];
+    const uint32_t j0 = (G - im.grp_base) * kGrp;
+    if (j0 + kGrp <= im.start_seg || j0 >= im.n_active) return;
+    const uint32_t lo = max(j0, im.start_seg), hi = min(j0 + kGrp, im.n_active);
+    const uint32_t wlo = max(lo, j0 + 16u * wave), whi = min(hi, j0 + 16u * wave + 16u);
+    if (whi <= wlo) return;
+    uint32_t tabv = p.grp_entry[(size_t)G * 65u + lane], pxv = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.grp_entry[(size_t)G * 65u + 64u]);
+    sym_t qt[3], qp[3];                                       // the quarters in front of this wavefront's (all three asked for: the loads do not wait for each other)
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        const sym_t* qs = p.qtr_summary + ((size_t)G * 4u + min(k, wave ? wave - 1u : 0u)) * 65u;
+        qt[k] = qs[lane]; qp[k] = qs[64];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) if (k < wave) sym_sweep_step(qt[k], uniform_sym(qp[k]), tabv, pxv);
+    // start_seg's entry state is given, never rewritten
+    sym_sweep_range(p.summary + (size_t)(im.seg_base + wlo) * 65u, whi - wlo, lane, tabv, pxv,
+                    p.entry + (size_t)(im.seg_base + wlo) * 65u, wlo == im.start_seg ? 1u : 0u);
 }
 
 // =====================================================================================
@@ -1238,8 +1297,20 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     __syncthreads();
     const uint32_t q = blockIdx.x * kTrThreads + threadIdx.x;
     bool have = q < p.total_segs;
-    const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
-    const DecImage im = p.images[img];
+    uint32_t img;
+    DecImage im;
+    if (MODE == 0 && p.tab_in_args) {
+        // the table travels in the kernel arguments (calls of a few images): this launch reads it from there, its first lanes leave the
+        // device copy for the kernels that follow
+        const uint32_t qq = have ? q : 0u;
+        img = (p.n_images > 1u && qq >= p.tab4[1].seg_base ? 1u : 0u) + (p.n_images > 2u && qq >= p.tab4[2].seg_base ? 1u : 0u) + (p.n_images > 3u && qq >= p.tab4[3].seg_base ? 1u : 0u);
+        im = img == 0u ? p.tab4[0] : img == 1u ? p.tab4[1] : img == 2u ? p.tab4[2] : p.tab4[3];
+        if (blockIdx.x == 0u && threadIdx.x < p.n_images)
+            p.images[threadIdx.x] = threadIdx.x == 0u ? p.tab4[0] : threadIdx.x == 1u ? p.tab4[1] : threadIdx.x == 2u ? p.tab4[2] : p.tab4[3];
+    } else {
+        img = find_image(p.images, p.n_images, have ? q : 0u);
+        im = p.images[img];
+    }
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
     if (MODE == 1) have = have && j >= im.start_seg && j < im.n_active && (p.sync_all || p.sync_fail[q] != 0u);
     if (MODE == 0 && have && j >= im.nseg) {               // a padding segment between two images (DecParams::fused): nothing to read, nothing flagged
@@ -1253,14 +1324,18 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     PipeReaderT<MODE == 0> R;                 // MODE 0: requests through a descriptor; MODE 1 (rare): plain pointers, reaches anything
     uint32_t pos;
     bool failed = false;
-    const uint8_t* dummy16 = reinterpret_cast<const uint8_t*>(p.images);        // any 16 readable bytes: what lanes without a request load
+    const uint8_t* dummy16 = reinterpret_cast<const uint8_t*>(p.sync_fail);     // any 16 readable bytes: what lanes without a request load
     if (MODE == 1) {
         pos = base + (have ? p.entry_phase[q] : 0u);
         R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes, dummy16);
     } else {
         // ---- look-back synchronisation ------------------------------------------------------------------------------
-        const bool from_start = base <= (uint32_t)kHeaderBytes + kSyncBytes;      // the stream's first chunk is in reach: one chain from byte 14
-        const uint32_t t0 = from_start ? (uint32_t)kHeaderBytes : base - kSyncBytes;
+        // (segments of up to 256 bytes - calls of a few images - start their chains 32 bytes back: the chains of natural content meet within a
+        // dozen bytes, those of noise never do, and at 128-byte segments the 64-byte run-up was a third of the lane's walk; a lane whose
+        // chains have not met takes the five-phase parse as ever)
+        const uint32_t back = p.seg_bytes <= 256u ? kSyncBytes / 2u : kSyncBytes;
+        const bool from_start = base <= (uint32_t)kHeaderBytes + back;            // the stream's first chunk is in reach: one chain from byte 14
+        const uint32_t t0 = from_start ? (uint32_t)kHeaderBytes : base - back;
         // the wavefront's descriptor: from the stream of its first segment to the last granule of the stream of its last one
         const uint8_t* const my_stream = p.streams + im.stream_off;
         const u64 hv = lanes_where(have);
@@ -1400,7 +1475,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     pos = rp + R.aoff;
     if (have && !failed) {
         p.rec_gran[q] = roff >> 10;                                     // granules written
-        SlotRec r; r.hc = 0; r.h_rel = 0; r.h_alpha = 0; r.a_abs = (uint8_t)a_abs; r.ac = (uint8_t)a_last;      // dec_slot_tails completes it
+        SlotRec r; r.hc = 0; r.h_rel = 0; r.h_alpha = 0; r.a_abs = (uint8_t)a_abs; r.ac = (uint8_t)a_last;      // dec_slot_tails / dec_scan_entry completes it
         p.slot_rec[q] = r;
         if (MODE == 0) {
             // parse record for S1: the same whatever entry phase S1 asks for - it only ever asks for the true one
@@ -1503,6 +1578,9 @@ __global__ __launch_bounds__(64) void dec_slot_tails(DecParams p) {
 //   word: bits 0..28 pixels (saturating at 2^29 - 1 > QOI_PIXELS_MAX), 29..45 slot transfer, 46..61 tag, 62..63 state
 // ---------------------------------------------------------------------------------
 constexpr u64 kScanAgg = 1ull << 62, kScanIncl = 2ull << 62;
+// (the tail walk in dec_transcode<0>'s epilogue instead - the lane reads its own last rows back - moved its 6.5 us there: 31.3 + 19.6 us
+// became 38.2 + 13.5, profiles/r06_s2: the wavefronts of a lone frame are alone on their SIMDs and end together, nothing hides it)
+constexpr bool kTailsInTranscoder = false;
 constexpr uint32_t kScanPxCap = (1u << 29) - 1u;
 __device__ __forceinline__ uint32_t scan_sat(uint32_t a, uint32_t b) { const uint32_t s = sat_add(a, b); return s < kScanPxCap ? s : kScanPxCap; }
 __device__ __forceinline__ uint32_t slots_then(uint32_t a, uint32_t b) { return slot_pack(slot_compose(slot_unpack(a), slot_unpack(b))); }     // b after a, packed
@@ -1552,7 +1630,7 @@ __global__ __launch_bounds__(kScanSegs) void dec_scan_entry(DecParams p) {
     TailState t; tail_init(t);
     t.found = (have && S.n_gran != 0u) ? 0u : 1u;
     const bool empty = have && S.n_gran == 0u;
-    const uint32_t most = wave_max_u32(S.n_gran);
+    const uint32_t most = kTailsInTranscoder ? 0u : wave_max_u32(S.n_gran);     // (dec_transcode<0> has walked the tails: slot_rec is complete)
     for (uint32_t i = 0; i < most && lanes_where(t.found == 0u) != 0 && !(QOIMI_SCAN_EXP & 1); i += 4u) {              // four rows in flight (a lane's anchor is a few records back)
         u32x4 v[4];
 #pragma unroll
@@ -1562,7 +1640,7 @@ __global__ __launch_bounds__(kScanSegs) void dec_scan_entry(DecParams p) {
             if (i + k < S.n_gran) { tail_step(t, v[k].w, in.a_abs, in.ac); tail_step(t, v[k].z, in.a_abs, in.ac); tail_step(t, v[k].y, in.a_abs, in.ac); tail_step(t, v[k].x, in.a_abs, in.ac); }
     }
     if (empty) t.found = 0u;
-    const SlotRec mine_r = tail_finish(t, in.a_abs, in.ac);
+    const SlotRec mine_r = kTailsInTranscoder ? in : tail_finish(t, in.a_abs, in.ac);
     const uint32_t mine = have ? slot_pack(mine_r) : kSlotIdentity;
     // ---- scan inside the workgroup
     uint32_t ipx = npix, isl = mine;
@@ -1636,6 +1714,32 @@ __global__ __launch_bounds__(kScanSegs) void dec_scan_entry(DecParams p) {
         if (boundary && lane == 0) atomicMax(&p.images[img].n_active, j_top + 1u);
     }
     if (threadIdx.x == 0 && q0 + kScanSegs >= im.seg_base + im.nseg) p.images[img].total_px = min(scan_sat(epx, bpx), im.npx);     // the image's last workgroup
+}
+
+// A wavefront's 64 x 64 table of dwords in the LDS ([row][lane], row stride 256 bytes) transposed IN PLACE: lane l swaps A[l + d][l]
+// with A[l][l + d] for d = 1..31 (every lane) and d = 32 (lanes 0..31) - every pair once; an instruction's 64 accesses lie in 64
+// different columns: no bank conflict.  What P3 / P4 keep per segment lives [slot][segment] in the LDS (a lane owns a column = a bank) and
+// [segment][slot] in memory (a segment's 65 words in one piece): the lane-wise copy between the two was 65 instructions of 64 scattered
+// 4 / 8-byte accesses 260 / 520 bytes apart - at 128-byte segments 7 us of dec_summarize_rec's 30 and 8 of dec_segments_rec's 39 on a
+// lone 4K frame (profiles/r06_s4_state_io.txt).  Transposed, a row is a segment and leaves / arrives as one contiguous piece per instruction.
+__device__ __forceinline__ void lds_transpose64(uint32_t base0, uint32_t lane) {       // base0: LDS byte address of A[0][0]
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (uint32_t d = 1; d < 32u; ++d) {
+        const uint32_t c = (lane + d) & 63u;
+        lds_u32* const a = (lds_u32*)(base0 + c * 256u + lane * 4u);
+        lds_u32* const b = (lds_u32*)(base0 + lane * 256u + c * 4u);
+        const uint32_t x = *a, y = *b;
+        *a = y; *b = x;
+    }
+    if (lane < 32u) {
+        const uint32_t c = lane + 32u;
+        lds_u32* const a = (lds_u32*)(base0 + c * 256u + lane * 4u);
+        lds_u32* const b = (lds_u32*)(base0 + lane * 256u + c * 4u);
+        const uint32_t x = *a, y = *b;
+        *a = y; *b = x;
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Source / mask codes of the symbolic table as BYTES, laid out so that a wavefront's access to 64 different rows is free
@@ -1876,19 +1980,24 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
         ring[2u * d] = S.granule_nt(2u * (blk + kDepth)); ring[2u * d + 1u] = S.granule_nt(2u * (blk + kDepth) + 1u);
       }
     }
-    if (have) {
-        sym_t* dst = p.summary + (size_t)q * 65u;
-        if (plain) {                                                          // never left the plain form: code and constants share the word
-            for (uint32_t k = 0; k < 64u; ++k) {
-                const uint32_t w = *(const lds_u32*)(tc_base + k * 256u);
-                dst[k] = (sym_t)(w & 0x00FFFFFFu) | ((sym_t)sym_code_expand(plain_code_general(w >> 24)) << 32);
-            }
-            dst[64] = (sym_t)(ppc & 0x00FFFFFFu) | ((sym_t)sym_code_expand(plain_code_general(ppc >> 24)) << 32);
-        } else {
-            for (uint32_t k = 0; k < 64u; ++k)
-                dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)sym_code_expand(*(const lds_u8*)symcode_addr(tm_lane, k)) << 32);
-            dst[64] = (sym_t)pc | ((sym_t)sym_code_expand(ph) << 32);
+    if (plain) {
+        // never left the plain form (code and constants share the word): the table is turned in the LDS and leaves segment by segment,
+        // 512 contiguous bytes per instruction (lds_transpose64)
+        const u64 hv = lanes_where(have);
+        const uint32_t base0 = tc_base - lane * 4u;
+        lds_transpose64(base0, lane);
+        sym_t* const blk = p.summary + (size_t)blockIdx.x * 64u * 65u;
+        for (uint32_t sgm = 0; sgm < 64u; ++sgm) {
+            if (!((hv >> sgm) & 1ull)) continue;
+            const uint32_t w = *(const lds_u32*)(base0 + sgm * 256u + lane * 4u);
+            blk[(size_t)sgm * 65u + lane] = (sym_t)(w & 0x00FFFFFFu) | ((sym_t)sym_code_expand(plain_code_general(w >> 24)) << 32);
         }
+        if (have) blk[(size_t)lane * 65u + 64u] = (sym_t)(ppc & 0x00FFFFFFu) | ((sym_t)sym_code_expand(plain_code_general(ppc >> 24)) << 32);
+    } else if (have) {
+        sym_t* dst = p.summary + (size_t)q * 65u;
+        for (uint32_t k = 0; k < 64u; ++k)
+            dst[k] = (sym_t)*(const lds_u32*)(tc_base + k * 256u) | ((sym_t)sym_code_expand(*(const lds_u8*)symcode_addr(tm_lane, k)) << 32);
+        dst[64] = (sym_t)pc | ((sym_t)sym_code_expand(ph) << 32);
     }
 }
 
@@ -2075,6 +2184,8 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     const uint32_t* __restrict__ ent = p.entry + (size_t)(have ? q : 0u) * 65u;
     uint32_t px = 0, stash = 0;
     if (have) {
+        // (read as whole segments in contiguous pieces and turned in the LDS - lds_transpose64, as dec_summarize_rec writes its summaries -
+        // this kernel got SLOWER, 39.2 -> 44.4 us on a lone 4K frame: the two turns cost more than the 65 + 65 scattered loads, profiles/r06_s5)
         for (uint32_t k0 = 0; k0 < 64u; k0 += 16u) {          // 16 loads in flight, then 16 LDS writes
             uint32_t v[16];
 #pragma unroll
@@ -2261,10 +2372,9 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                 fx[64] = px;
                 atomicMin(&p.first_bad[img], j + 1u);
             }
-        } else {
-            p.images[img].final_px = px;     // pixel repeated when the stream ends early (qoi.h:544)
         }
     }
+    if (have && j + 1u >= im.n_active) p.images[img].final_px = px;     // pixel repeated when the stream ends early (qoi.h:544)
 }
 
 // The run descriptors of a round, written out.  A wavefront takes the queued segments wave-th, wave + N-th, ... (N wavefronts in the
@@ -2410,15 +2520,21 @@ __global__ __launch_bounds__(256) void dec_fill(DecParams p) {
         // words (system-scope stores; the host waits for the stream and reads them - no copy back: 4 of a 4K frame's 205 us)
         if (blockIdx.x == 0u && threadIdx.x < 64u) {
             for (uint32_t i = 0; i < p.n_images; ++i) prepare_restart(p, i, threadIdx.x);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t pend = __hip_atomic_load(p.pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), redo = __hip_atomic_load(p.redo_segs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t sf = *p.sync_fails;
             if (threadIdx.x == 0u) {
-                const uint32_t pend = __hip_atomic_load(p.pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), redo = __hip_atomic_load(p.redo_segs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&p.host_result[1], redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&p.host_result[2], *p.sync_fails, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&p.host_result[2], sf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&p.host_result[0], pend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            // The call is complete (no image to restart, every segment synchronised): the counter header as the context's NEXT call wants to
+            // find it - that call then needs no copy in front of its first kernel.  Nothing of this launch looks at these words any more.
+            if (pend == 0u && sf == 0u) p.pending[threadIdx.x] = 0u;
+            else if (threadIdx.x == 3u) p.pending[3] = 0u;                     // run_queue_n (dec_expand_runs ran before this launch)
         }
     } else if (slice == 0u && threadIdx.x < 64u && p.total_segs != 0u) prepare_restart(p, img, threadIdx.x);
-    if (blockIdx.x == 0u && threadIdx.x == 64u) *p.run_queue_n = 0u;        // the round's run descriptors are written out (dec_expand_runs ran before this launch)
+    if (blockIdx.x == 0u && threadIdx.x == 64u && !p.tail_fused) *p.run_queue_n = 0u;        // the round's run descriptors are written out (dec_expand_runs ran before this launch)
     if (im.total_px >= im.npx) return;
     const uint32_t px = im.n_active ? im.final_px : kInitPx;
     uint8_t* out = p.pixels + (size_t)img * p.pixel_stride;
@@ -2474,10 +2590,12 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     tm->mark(kT_begin, st);
     uint32_t l2_seq = 0;
     auto chain_state = [&]() {
-        hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
+        if (p.qtr_summary) hipLaunchKernelGGL(dec_chain_state_l1q, dim3(p.total_grps), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
         if (p.l2_wgs > 1u) hipLaunchKernelGGL(dec_chain_state_l2m, dim3(p.n_images * p.l2_wgs), dim3(64 * kL2Waves), 0, st, p, p.l2_tag_base + l2_seq++);
         else hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
-        hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);
+        if (p.qtr_summary) hipLaunchKernelGGL(dec_chain_state_l3q, dim3(p.total_grps), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);
         tm->mark(kT_dec_chain_state, st);
     };
     if (refine) {

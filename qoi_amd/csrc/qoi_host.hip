@@ -96,6 +96,7 @@ struct qoimi_ctx {
     Arena enc_ws, dec_ws;       // kernel workspaces
     Arena dec_scan;             // look-back words of dec_scan_entry (calls of a few images): tagged with dec_epoch, zeroed when allocated / when the tag wraps
     uint32_t dec_epoch = 0;     // number of the last such call (16 bits are compared)
+    struct { void* at = nullptr; unsigned gen = 0; bool valid = false; } dec_hdr_zero;   // the counter header the last decode call's dec_fill left zeroed (arena base + generation)
     Arena io_a, io_b, io_c;     // staging for the host-pointer (drop-in) path
     uint32_t* host_word = nullptr;   // pinned words for read-backs
     hipStream_t own_stream = nullptr; // private non-blocking stream: self-test at creation, the drop-in entry points' work
@@ -857,6 +858,8 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.grp_slot = w.take<SlotRec>(NG); p.grp_slot_in = w.take<uint8_t>(NG); p.grp_alpha_in = w.take<uint8_t>(NG);
         p.grp_summary = w.take<u64>(NG * 65); p.grp_entry = w.take<uint32_t>(NG * 65);
         p.l2_sum = w.take<u64>((size_t)n_images * p.l2_wgs * 65);
+        p.qtr_summary = w.take<u64>(n_images <= 4 && c->dec_fused ? NG * 4u * 65u : 0);       // calls of a few images: four wavefronts per group in the state chain
+        if (!(n_images <= 4 && c->dec_fused)) p.qtr_summary = nullptr;
         p.rec_gran = w.take<uint32_t>(Q);
         p.run_cnt = w.take<uint32_t>((flat_total || p.desc_all) ? Q : 0);
         p.run_queue = w.take<uint32_t>((flat_total || p.desc_all) ? Q : 0);
@@ -879,6 +882,14 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
             p.host_result = &c->host_word[20];
         }
     }
+    // Calls of a few images whose predecessor on this context left the counter header zeroed (its dec_fill, see there): the table rides in
+    // dec_transcode<0>'s kernel arguments - no copy at all in front of the first kernel.
+    const bool hdr_clean = c->dec_hdr_zero.valid && c->dec_hdr_zero.at == (void*)p.pending && c->dec_hdr_zero.gen == c->dec_ws.gen;
+    c->dec_hdr_zero.valid = false;
+    if (fused && hdr_clean && n_images <= 4) {
+        p.tab_in_args = 1u;
+        for (int i = 0; i < n_images; ++i) p.tab4[i] = imgs[(size_t)i];
+    } else
     {   // image table through pinned staging: no synchronisation (every decode call ends with one, so the staging buffer is free
         // again when the next call fills it).  The four counter words in front of it (pending, redo_segs, sync_fails: the
         // arena's first 256 bytes, the table follows them) travel zeroed in the same copy: no memset launches in round one.
@@ -918,6 +929,8 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         if (p.tail_fused) {
             HIP_TRY(hipStreamSynchronize(st));
             c->host_word[0] = c->host_word[20]; c->host_word[1] = c->host_word[21]; c->host_word[2] = c->host_word[22];
+            // (that dec_fill left the header zeroed; good for the next call if nothing else of this call touches it: no further round)
+            c->dec_hdr_zero.at = (void*)p.pending; c->dec_hdr_zero.gen = c->dec_ws.gen; c->dec_hdr_zero.valid = c->host_word[0] == 0u && c->host_word[2] == 0u;
         } else {
             HIP_TRY(hipMemcpyAsync(c->host_word, p.pending, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));

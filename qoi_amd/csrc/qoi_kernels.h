@@ -208,6 +208,13 @@ struct DecParams {
     uint32_t* scan_ticket;     // [1] workgroups take their place in start order (word 5 of the zeroed counter header)
     // ... and the round's counters straight into pinned HOST words from dec_fill (which then prepares every image's restart in its first
     // wavefront): no copy back behind the round, the host waits for the stream and reads them
+    u64*      qtr_summary;     // [total_grps][4][65] calls of a few images: symbolic summary of every quarter (16 segments) of a group - the group levels of the
+                               // state chain run as four wavefronts per group (dec_chain_state_l1q / _l3q); nullptr: one wavefront per group
+    // ... and the image table in the KERNEL ARGUMENTS of dec_transcode<0> (at most four images), which writes the device copy for the kernels
+    // behind it: no host-to-device copy in front of the call (its API call and its blit kernel were 8 of a 4K frame's 182 us).  The counter
+    // header is then zeroed by the dec_fill of the context's previous call (qoimi_decode_batch keeps track).
+    uint32_t  tab_in_args;     // 1: tab4 holds the table
+    DecImage  tab4[4];
     uint32_t  tail_fused;      // 1: that form
     uint32_t* host_result;     // pinned host words: [0] pending, [1] redo_segs, [2] sync_fails
 };

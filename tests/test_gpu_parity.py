@@ -492,6 +492,10 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_ENC_TREE_TICKET": "0"},                       # tree placement with its units by workgroup index (the drop-in qoi_encode's form; tickets are the default)
     {"QOIMI_DEC_RUN_DESC": "0"},                          # every long run written lane by lane
     {"QOIMI_DEC_RUN_DESC": "1"},                          # run descriptors for flat images only
+    {"QOIMI_DEC_FUSED": "0"},                             # calls of a few images through the three-level chains of the batch path (default: dec_scan_entry + four wavefronts per group in the state chain)
+    {"QOIMI_DEC_FUSED": "0", "QOIMI_SEG_BYTES": "128"},
+    {"QOIMI_SEG_BYTES": "128"},                           # the single-pass look-back at the lone frame's segment size (the noise image makes the call fall back to the chains)
+    {"QOIMI_SEG_BYTES": "1024"},
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""
@@ -522,6 +526,62 @@ def test_selectable_paths(api, oracle, env):
                 del os.environ[k]
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("seg", ["", "128", "1024"])
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_small_calls_single_pass_lookback(api, oracle, seg, fused):
+    """Calls of one to four images take dec_scan_entry (pixel offsets + speculated slots by a single-pass look-back over tagged words,
+    every image on a multiple of 256 segments) and a state chain of four wavefronts per group - round 6.  Images of different shapes whose
+    streams all synchronise (photographs, UI frames, a constant frame, soft-alpha sprites), a 1 x 1 image, a stream cut short (the
+    pixels the chunks never reach repeat the last pixel, qoi.h:544) and a stream too long for its image; the same calls again on the same
+    context (the look-back words carry the call's number, the counter header is zeroed by the call before), 3- and 4-channel output,
+    against the reference decoder.  QOIMI_DEC_FUSED=0: the same through the three-level chains."""
+    import torch
+    from qoi_amd import synth
+    env = {"QOIMI_DEC_FUSED": fused}
+    if seg:
+        env["QOIMI_SEG_BYTES"] = seg
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = api.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    shapes = [("photo", 1280, 720), ("uiflat", 640, 400), ("sprite_alpha", 333, 251), ("constant", 64, 64), ("photo_hard", 1, 1), ("photo", 97, 3), ("photo_hard", 800, 600)]
+    streams, descs = [], []
+    for i, (kind, w, h) in enumerate(shapes):
+        px = synth.frame_rgba(kind, w, h, 70 + i)
+        st = oracle.encode(px, w, h, 4)
+        streams.append(st); descs.append((w, h))
+    # a stream cut short inside its chunks and one that goes on behind its image's last pixel (another image's chunks appended)
+    cut = streams[0][:len(streams[0]) // 3] + streams[0][-8:]
+    streams.append(cut); descs.append(descs[0])
+    long_s = streams[1][:-8] + streams[5][14:]
+    streams.append(long_s); descs.append(descs[1])
+    stride_s = (max(len(s) for s in streams) + 255) // 256 * 256
+    stride_p = (max(w * h for w, h in descs) * 4 + 255) // 256 * 256
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(5)
+    for rep in range(6):
+        n = int(rng.integers(1, 5))
+        pick = [int(x) for x in rng.choice(len(streams), size=n, replace=False)]
+        for och in (4, 3):
+            d_s = torch.zeros(n * stride_s, dtype=torch.uint8, device="cuda")
+            d_p = torch.full((n * stride_p,), 0xA5, dtype=torch.uint8, device="cuda")
+            for k, i in enumerate(pick):
+                d_s[k * stride_s:k * stride_s + len(streams[i])] = torch.frombuffer(bytearray(streams[i]), dtype=torch.uint8).cuda()
+            c.decode_batch(d_s.data_ptr(), stride_s, [len(streams[i]) for i in pick], [api.QoiDesc(descs[i][0], descs[i][1], 4, 0) for i in pick],
+                           och, d_p.data_ptr(), stride_p, stream)
+            for k, i in enumerate(pick):
+                want, _ = oracle.decode(streams[i], och)
+                got = d_p[k * stride_p:k * stride_p + descs[i][0] * descs[i][1] * och].cpu().numpy()
+                assert np.array_equal(got, want), (seg, fused, rep, och, i)
+    c.close()
 
 
 def test_differential_fuzz(api, oracle):
