@@ -65,6 +65,38 @@ def _latest_traffic_file() -> str:
 TRAFFIC_FILE = _latest_traffic_file()
 
 
+def _latest_kernel_stats_file() -> str:
+    """The most recent committed rocprofv3 --kernel-trace --stats summary (profiles/rNN_sM_kernel_stats.csv)."""
+    import glob
+    import re
+    best, key = "", (-1, -1)
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_s*_kernel_stats.csv")):
+        m = re.search(r"r(\d+)_s(\d+)_kernel_stats\.csv$", f)
+        if m and (int(m.group(1)), int(m.group(2))) > key:
+            best, key = f, (int(m.group(1)), int(m.group(2)))
+    return best
+
+
+def rocprof_average_ms(kernel_substr: str):
+    """Average launch duration (ms) of the kernel whose name contains `kernel_substr` in the latest committed rocprofv3 summary, and
+    the file's name - an EARLIER session's profile of this command (1024 frames per launch), shown beside the HIP-event figure of the
+    run at hand so that the band between the two clocks is visible in one line."""
+    import csv
+    f = _latest_kernel_stats_file()
+    if not f:
+        return None, None
+    try:
+        best = None
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Name"] and (best is None or float(r["TotalDurationNs"]) > float(best["TotalDurationNs"])):
+                best = r
+        if best is None:
+            return None, None
+        return float(best["AverageNs"]) / 1e6, "profiles/" + os.path.basename(f)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def measured_traffic(kernel_prefix: str, scale: float = 1.0):
     """HBM bytes per launch of the dominant kernel, EXTRAPOLATED from the latest committed rocprofv3 PMC passes of this
     command (tools/measure/session.sh: separate FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-cpu ...`; the counters cannot
@@ -214,6 +246,31 @@ def equal_batches(torch, a, b, F, stride, nbytes) -> bool:
 
 
 def dropin_path(torch, api, ctx, pixels, w, h, dev) -> dict:
+    """The default (qoi_encode returns the reference's worst-case allocation, qoi.h:374-379) and, from a fresh thread - a calling thread's
+    context reads the setting when it is created - the opt-in tight buffer (QOIMI_ENCODE_TIGHT_BUFFER=1) beside it."""
+    import threading
+    out = _dropin_path(torch, api, ctx, pixels, w, h, dev)
+    res = {}
+
+    def run():
+        os.environ["QOIMI_ENCODE_TIGHT_BUFFER"] = "1"
+        try:
+            torch.cuda.set_device(dev)
+            res["tight"] = _dropin_path(torch, api, ctx, pixels, w, h, dev)
+        except Exception as e:                                          # a report, not a gate
+            res["tight"] = {"error": repr(e)}
+        finally:
+            os.environ.pop("QOIMI_ENCODE_TIGHT_BUFFER", None)
+    t = threading.Thread(target=run)
+    t.start(); t.join()
+    tight = res.get("tight", {})
+    out["encode_buffer"] = "the reference's capacity, w*h*(channels+1)+22 bytes (qoi.h:374-379), only the pages the stream touches populated"
+    out["tight_buffer_opt_in"] = {k: tight.get(k) for k in ("encode_ms", "results_kept_ms", "encode_mpixels_per_s", "round_trip_exact", "error") if k in tight}
+    out["tight_buffer_opt_in"]["note"] = "QOIMI_ENCODE_TIGHT_BUFFER=1: qoi_encode's malloc sized by the calling thread's previous stream (+ 1/8)"
+    return out
+
+
+def _dropin_path(torch, api, ctx, pixels, w, h, dev) -> dict:
     """qoi_encode / qoi_decode of the C ABI (include/qoi_mi355x.h, = qoi.h:278/289) on malloc'ed host memory, one 4K frame."""
     import ctypes
     lib = api.load_library()
@@ -282,6 +339,128 @@ def dropin_path(torch, api, ctx, pixels, w, h, dev) -> dict:
             "frac_of_copies": {"encode": round(c_enc / t_enc, 3), "decode": round(c_dec / t_dec, 3)},
             "pcie_bytes": {"encode": npx * 4 + len(stream_bytes), "decode": npx * 4 + len(stream_bytes)},
             "round_trip_exact": ok}
+
+
+def mixed_directory_leg(torch, api, synth, ctx, pixels, streams, decoded, lens, stream, timed) -> dict:
+    """qoibench.c:491-555 walks a directory: images of different shapes and contents.  288 images, 64 distinct shapes between 48 x 48
+    and 2048 x 1536, the six content classes interleaved, device-resident: ONE qoimi_encode_images (order-free placement, per-image
+    table) and ONE qoimi_decode_batch; every stream hashed on the device, 72 of them against the reference encoder's."""
+    from oracle import oracle_py
+    lib = oracle_py.load_ref()
+    checker = "reference"
+    if lib is None:
+        lib, checker = oracle_py.load_port(), "port"
+    rng = np.random.default_rng(2026)
+    kinds = ["photo", "noise", "uiflat", "constant", "photo_hard", "sprite_alpha"]
+    shapes = set()
+    while len(shapes) < 64:
+        shapes.add((int(rng.integers(48, 2049)), int(rng.integers(48, 1537))))
+    shapes = sorted(shapes)
+    M = 288
+    items = [(shapes[(i * 7) % len(shapes)], kinds[i % len(kinds)]) for i in range(M)]
+    po, off = [], 0
+    for (iw, ih), _ in items:
+        po.append(off)
+        off += (iw * ih * 4 + 255) // 256 * 256
+    ss_m = (max(api.encode_bound(iw, ih, 4) for (iw, ih), _ in items) + 255) // 256 * 256
+    ps_m = (max(iw * ih * 4 for (iw, ih), _ in items) + 255) // 256 * 256
+    if off > pixels.numel() or M * ss_m > streams.numel() or M * ps_m > decoded.numel():
+        return {"skipped": "the benchmark's buffers are too small for this leg (run with the default --frames)"}
+    descs = [api.QoiDesc(iw, ih, 4, api.QOI_SRGB) for (iw, ih), _ in items]
+    for i, ((iw, ih), kind) in enumerate(items):
+        ctx.synth_frames(synth.KIND_ID[kind], synth.DEFAULT_SEED, 40000 + i, 1, iw, ih, pixels.data_ptr() + po[i], iw * ih * 4, stream)
+    so = [i * ss_m for i in range(M)]
+    enc = lambda: ctx.encode_images(pixels.data_ptr(), po, descs, streams.data_ptr(), so, lens.data_ptr(), stream)
+    enc(); ctx.encode_status(stream)
+    sizes = [int(x) for x in lens[:M].cpu().numpy()]
+    dec = lambda: ctx.decode_batch(streams.data_ptr(), ss_m, sizes, descs, 4, decoded.data_ptr(), ps_m, stream)
+    dec()
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < 0.3:
+        enc(); dec()
+    te, td = timed(enc, 3), timed(dec, 3)
+    ctx.encode_status(stream)
+    rounds = ctx.decode_stats()["rounds"]
+    ctx.set_profiling(True)
+    enc(); dec()
+    kprof = {k: round(v[0], 3) for k, v in ctx.get_profile(stream).items() if v[1] and v[0] > 0.02}
+    ctx.set_profiling(False)
+    ok = all(bool(torch.equal(decoded[i * ps_m:i * ps_m + items[i][0][0] * items[i][0][1] * 4], pixels[po[i]:po[i] + items[i][0][0] * items[i][0][1] * 4])) for i in range(M))
+    hashes = torch.zeros(M, dtype=torch.int64, device=pixels.device)
+    ctx.hash_streams(streams.data_ptr(), ss_m, lens.data_ptr(), M, hashes.data_ptr(), stream)
+    torch.cuda.synchronize()
+    mine = hashes.cpu().numpy().view(np.uint64)
+    sample = list(range(0, M, 4))
+    bad = []
+    for i in sample:
+        (iw, ih), kind = items[i]
+        px = pixels[po[i]:po[i] + iw * ih * 4].cpu().numpy()
+        if int(mine[i]) != synth.stream_hash64(lib.encode(px, iw, ih, 4)):
+            bad.append(i)
+    npx_total = float(sum(iw * ih for (iw, ih), _ in items))
+    sbytes = float(sum(sizes))
+    return {"workload": f"{M} images, {len(set(sh for sh, _ in items))} distinct shapes from 48x48 to 2048x1536, classes {'/'.join(kinds)} interleaved, device-resident: "
+                        "one qoimi_encode_images + one qoimi_decode_batch (qoibench.c:491-555: a directory of images)",
+            "images": M, "distinct_shapes": len(set(sh for sh, _ in items)), "mpixels": round(npx_total / 1e6, 1),
+            "encode_ms": round(te * 1e3, 3), "decode_ms": round(td * 1e3, 3),
+            "encode_mpixels_per_s": round(npx_total / te / 1e6, 1), "decode_mpixels_per_s": round(npx_total / td / 1e6, 1),
+            "mpixels_per_s": round(npx_total / (te + td) / 1e6, 1),
+            "roofline_encode_frac": round(npx_total * 4 / te / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline_decode_frac": round((npx_total * 4 + sbytes) / td / 1e9 / HBM_PEAK_GBS, 4),
+            "stream_bytes_per_px": round(sbytes / npx_total, 4), "decode_rounds": rounds, "verified_bit_exact": bool(ok), "kernel_ms_per_call": kprof,
+            "hash_check": {"checker": checker, "streams_hashed_on_device": M, "checked_against_reference": len(sample), "mismatches": bad[:8], "all_equal": not bad},
+            "note": "wall clock of 3 calls each; fractions against SURVEY.md 8d's bytes and the 8 TB/s peak"}
+
+
+def alternating_leg(torch, api, synth, ctx, pixels, streams, decoded, lens, stream, timed, w, h, pstride, sstride, desc) -> dict:
+    """photo / uiflat / photo_hard batches of 128 4K frames in rotation on one context, no priming between them, beside the same calls
+    repeated on their own class (the state in which every other leg of this file times a class)."""
+    A, classes = 128, ["photo", "uiflat", "photo_hard"]
+    npx = w * h
+    descs = [desc] * A
+    sizes = {}
+    for ci, k in enumerate(classes):
+        ctx.synth_frames(synth.KIND_ID[k], synth.DEFAULT_SEED, 50000 + ci * A, A, w, h, pixels.data_ptr() + ci * A * pstride, pstride, stream)
+    enc = lambda ci: ctx.encode_batch(pixels.data_ptr() + ci * A * pstride, pstride, desc, A, streams.data_ptr() + ci * A * sstride, sstride, lens.data_ptr() + ci * A * 4, stream)
+    dec = lambda ci: ctx.decode_batch(streams.data_ptr() + ci * A * sstride, sstride, sizes[ci], descs, 4, decoded.data_ptr() + ci * A * pstride, pstride, stream)
+    first = {}
+    for ci, k in enumerate(classes):
+        enc(ci); ctx.encode_status(stream)
+        sizes[ci] = [int(x) for x in lens[ci * A:(ci + 1) * A].cpu().numpy()]
+        hs = torch.zeros(A, dtype=torch.int64, device=pixels.device)
+        ctx.hash_streams(streams.data_ptr() + ci * A * sstride, sstride, lens.data_ptr() + ci * A * 4, A, hs.data_ptr(), stream)
+        first[ci] = hs.cpu().numpy().copy()
+        dec(ci)
+    primed = {}
+    for ci, k in enumerate(classes):
+        for _ in range(3):
+            enc(ci); dec(ci)
+        primed[k] = (timed(lambda: enc(ci), 3) * 1e3, timed(lambda: dec(ci), 3) * 1e3)
+    rot = {k: ([], []) for k in classes}
+    same = True
+    for r in range(5):                       # the first rotation is not counted (it follows the primed calls of photo_hard)
+        for ci, k in enumerate(classes):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            enc(ci)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            dec(ci)
+            t2 = time.perf_counter()
+            if r:
+                rot[k][0].append((t1 - t0) * 1e3); rot[k][1].append((t2 - t1) * 1e3)
+            hs = torch.zeros(A, dtype=torch.int64, device=pixels.device)
+            ctx.hash_streams(streams.data_ptr() + ci * A * sstride, sstride, lens.data_ptr() + ci * A * 4, A, hs.data_ptr(), stream)
+            same = same and bool(np.array_equal(hs.cpu().numpy(), first[ci]))
+    ctx.encode_status(stream)
+    ok = all(bool(torch.equal(decoded[ci * A * pstride:(ci + 1) * A * pstride].view(A, pstride)[:, :npx * 4], pixels[ci * A * pstride:(ci + 1) * A * pstride].view(A, pstride)[:, :npx * 4])) for ci in range(len(classes)))
+    per = {}
+    for k in classes:
+        e, d = float(np.mean(rot[k][0])), float(np.mean(rot[k][1]))
+        per[k] = {"encode_ms": round(e, 3), "decode_ms": round(d, 3), "primed_encode_ms": round(primed[k][0], 3), "primed_decode_ms": round(primed[k][1], 3),
+                  "encode_vs_primed": round(e / primed[k][0], 3), "decode_vs_primed": round(d / primed[k][1], 3)}
+    return {"workload": f"batches of {A} x {w}x{h} frames, {' / '.join(classes)} in rotation on one context (4 counted rotations, every call timed with a wait before and after), "
+                        "beside the same call repeated on its own class",
+            "per_class": per, "streams_equal_first_encode_every_time": bool(same), "verified_bit_exact": bool(ok),
+            "note": "primed_* = the call repeated on its own class (3 warm calls, then 3 timed back to back); *_vs_primed > 1.10 would mean a call-to-call heuristic costs an alternating workload more than a tenth"}
 
 
 def main() -> None:
@@ -472,9 +651,21 @@ def main() -> None:
         dt = timed(lambda: (enc1(), dec1()), 50)
         dt_e = timed(enc1, 50)
         dt_d = timed(dec1, 50)
+        # the same encode with its units handed out by workgroup index (qoimi_set_encode_small_call_order: what the drop-in qoi_encode
+        # takes; a caller of the device API must then ask qoimi_encode_status before reading the streams)
+        ctx.set_encode_small_call_order(True)
+        for _ in range(20):
+            enc1()
+        dt_e_idx = timed(enc1, 50)
+        ctx.encode_status(stream)
+        ctx.set_encode_small_call_order(False)
+        enc1(); ctx.encode_status(stream)
         single = {"workload": f"1 x {w}x{h} RGBA frame, encode + decode, device-resident, wall clock incl. launches (Infinity-Cache resident on repeat runs)",
                   "ms": round(dt * 1e3, 4), "mpixels_per_s": round(npx / dt / 1e6, 1),
                   "encode_ms": round(dt_e * 1e3, 4), "decode_ms": round(dt_d * 1e3, 4),
+                  "encode_ms_units_by_workgroup_index": round(dt_e_idx * 1e3, 4),
+                  "placement_note": "encode_ms: the default, units by ticket (start order: safe when launches of several streams share the device); "
+                                    "by workgroup index: opt-in (qoimi_set_encode_small_call_order), qoimi_encode_status then is mandatory",
                   "roofline": {"bound": "hbm", "kernel": "whole single-frame encode (all launches)", "achieved": round(npx * 4 / dt_e / 1e9, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(npx * 4 / dt_e / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                                "algorithmic_bytes_per_launch": npx * 4, "ms_per_launch": round(dt_e * 1e3, 4),
@@ -580,6 +771,9 @@ def main() -> None:
             ctx.encode_status(stream)
             s2 = [int(x) for x in lens[:F2].cpu().numpy()]
             chk = check_against_reference(torch, pixels, ps2, streams, ss2, s2, w2, h2, [0, F2 - 1])
+            hc2 = hash_check_against_reference(torch, ctx, pixels, ps2, streams, ss2, lens, F2, w2, h2, 4, stream)
+            hc2.pop("device_hashes", None)
+            chk["hash_check"] = hc2
             slabs_ms = sum(p2[k][0] for k in ("enc_slabs", "enc_slabs_generic", "enc_slab_summary", "enc_scan_groups", "enc_scan_images") if k in p2) / 10
             tot_ms = p2["encode_total"][0] / 10 if p2.get("encode_total", (0, 0))[1] else dt * 1e3
             cfg2 = {"workload": f"BASELINE configs[2]: {F2} x {w2}x{h2} RGBA frames (photo), encode only, HBM-resident ({F2 * n2 * 4 / 1e9:.2f} GB of pixels per launch)",
@@ -616,6 +810,23 @@ def main() -> None:
                     "roofline_encode_total": {"bound": "hbm", "kernel": "whole qoimi_encode_batch (all kernels, wall clock)", "achieved": round(n3 * 4 / dte / 1e9, 1), "peak": HBM_PEAK_GBS,
                                               "unit": "GB/s", "frac": round(n3 * 4 / dte / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": n3 * 4, "ms_per_launch": round(dte * 1e3, 3)}}
 
+    # What the reference's own harness walks (qoibench.c:491-555): a DIRECTORY of images of different shapes and contents, here one
+    # qoimi_encode_images + one qoimi_decode_batch over 288 images of 64 shapes, the six content classes interleaved.
+    mixed = None
+    if world == 1 and rank == 0 and not args.no_others and not args.encode_only:
+        try:
+            mixed = mixed_directory_leg(torch, api, synth, ctx, pixels, streams, decoded, lens, stream, timed)
+        except Exception as e:                                                  # a report, not a gate
+            mixed = {"error": repr(e)}
+    # ... and batches of different content in rotation on ONE context, nothing primed: what the call-to-call heuristics (set size by the
+    # previous batch's bytes per pixel, pass selection by the previous batch's flagged images) cost a workload that alternates
+    alternating = None
+    if world == 1 and rank == 0 and not args.no_others and not args.encode_only and F >= 384 and (w, h) == (3840, 2160):
+        try:
+            alternating = alternating_leg(torch, api, synth, ctx, pixels, streams, decoded, lens, stream, timed, w, h, pstride, sstride, desc)
+        except Exception as e:
+            alternating = {"error": repr(e)}
+
     # RCCL: counters only (max elapsed; summed pixels / stream bytes / verified ranks)
     # synthetic frame ids this rank coded in a step: its whole share when every pass refills the buffer, else the resident frames
     # (passes > 1 always refills; with one pass the resident frames ARE the share)
@@ -624,6 +835,8 @@ def main() -> None:
     st_coded = bytes_coded[0] if regen else float(sum(sizes)) * launches
     elapsed_mine = elapsed
     elapsed_min = qdist.reduce_min(elapsed_mine, cdev)               # the fastest rank (skew between ranks = max - min)
+    free_mine, total_mine = torch.cuda.mem_get_info(dev)
+    peak_max, (peak_sum,) = qdist.reduce_counters(float(total_mine - free_mine), [float(total_mine - free_mine)], cdev)   # every rank's device: the largest, and the sum
     elapsed, (total_px, total_stream_bytes, n_ok, frames_coded, frame_id_sum, synth_ms_max) = qdist.reduce_counters(
         elapsed, [px_coded, st_coded, float(ok), float(len(my_frames)), float(sum(my_frames)), float(synth_ms)], cdev)
 
@@ -684,8 +897,14 @@ def main() -> None:
             "decode_rounds": dstats["rounds"], "decode_redo_segments": dstats["redo_segments"], "decode_sync_fallback_segments": dstats.get("sync_fallback_segments"),
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
             "roofline": roof("enc_sets (+ entry-state passes)", alg_bytes, per_launch_ms, traffic=traffic, traffic_source=traffic_src,
-                             note="the kernel of the north star's 4K-encode roofline target; the kernel with the largest share of the step is in roofline_dominant"),
+                             note="the kernel of the north star's 4K-encode roofline target; the kernel with the largest share of the step is in roofline_dominant; "
+                                  "ms_per_launch / frac: HIP events on the launch stream in THIS run; rocprof_*: the latest committed rocprofv3 summary of this command "
+                                  "(another session, another box): the two clocks bracket the figure, 0.326-0.341 over round 5's sessions"),
         }
+        if args.kind == "photo" and (w, h) == (3840, 2160) and frames_per_launch == 1024:
+            rp_ms, rp_src = rocprof_average_ms("enc_sets<4, 1, 1, false, false>")
+            if rp_ms:
+                out["roofline"].update({"rocprof_ms_per_launch": round(rp_ms, 4), "rocprof_frac": round(gbs(alg_bytes, rp_ms) / HBM_PEAK_GBS, 4), "rocprof_source": rp_src})
         if not args.encode_only:
             # PMC traffic of the kernel's largest launch (a sub-batch of the decode call), scaled to the average launch by segments
             seg_traffic = seg_src = None
@@ -722,6 +941,8 @@ def main() -> None:
                                                    "record_cap_24g": capped},
                                 "bench_buffers_bytes": int(pixels.numel() + streams.numel() + decoded.numel()),
                                 "peak_device_bytes": int(total_b - free_b), "device_total_bytes": int(total_b),
+                                "peak_device_bytes_per_rank": {"max": int(peak_max), "sum_over_ranks": int(peak_sum), "ranks": world,
+                                                               "note": "device total - free on each rank's own GPU when its timed region ended (before rank 0's side legs); every rank must fit ITS 288 GB"},
                                 "note": "peak_device_bytes = device total - free at the end of the run (all processes on the device; the library's arenas and torch's caching allocator only grow)"}
         out["scaling_note"] = ("single GPU" if world == 1 else f"{world} ranks") + "; no multi-GPU scaling curve has been measured for this repository (gpurun exposes one GPU) - the driver computes efficiency from its own per-N runs"
         if single:
@@ -732,6 +953,10 @@ def main() -> None:
             out["encode_1080p_batch"] = cfg2
         if cfg3:
             out["single_16k"] = cfg3
+        if mixed:
+            out["mixed_directory"] = mixed
+        if alternating:
+            out["alternating"] = alternating
         if other:
             out["other_content"] = other
         if rgb:

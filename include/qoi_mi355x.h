@@ -145,6 +145,15 @@ long long qoimi_encode_suspect_calls(qoimi_ctx *ctx);
  * call this before reading the streams. */
 int qoimi_encode_status(qoimi_ctx *ctx, void *stream);
 
+/* How qoimi_encode_batch hands out the work units of calls of fewer than 8 images (tree placement, where a set waits for the byte
+ * counts of lower-numbered sets).  by_workgroup_index = 0 (default): by one ticket per workgroup, i.e. in START order - whatever a set
+ * waits for is running or done, on a shared device too; a caller that only synchronises its stream reads complete streams.
+ * by_workgroup_index = 1: by workgroup index - 4 us less per 4K frame, correct only as long as the dispatcher starts lower-numbered
+ * workgroups no later than higher ones (true of one launch on an idle device); its waits are bounded, a wait that gives up ends the
+ * launch's waits and leaves an error flag, and the caller MUST call qoimi_encode_status before reading the streams (it encodes the
+ * call again order-free).  The drop-in qoi_encode uses this form and does that by itself.  Returns QOIMI_OK or QOIMI_E_ARG. */
+int qoimi_set_encode_small_call_order(qoimi_ctx *ctx, int by_workgroup_index);
+
 /* Calls of this context that qoimi_encode_status encoded again order-free because a placement wait had given up (0: never). */
 long long qoimi_encode_retries(qoimi_ctx *ctx);
 

@@ -35,7 +35,7 @@ EXPORTS = (
     "qoimi_ctx_create", "qoimi_ctx_destroy", "qoimi_last_error", "qoimi_encode_bound",
     "qoimi_encode_batch", "qoimi_encode_status", "qoimi_decode_batch", "qoimi_synth_frames",
     "qoimi_decode_stats", "qoimi_version", "qoimi_set_profiling", "qoimi_get_profile", "qoimi_kernel_name",
-    "qoimi_encode_suspect_calls", "qoimi_encode_retries", "qoimi_workspace_bytes", "qoimi_set_decode_record_cap", "qoimi_hash_streams", "qoimi_encode_images",
+    "qoimi_encode_suspect_calls", "qoimi_encode_retries", "qoimi_set_encode_small_call_order", "qoimi_workspace_bytes", "qoimi_set_decode_record_cap", "qoimi_hash_streams", "qoimi_encode_images",
 )
 
 
@@ -105,6 +105,8 @@ def load_library() -> ctypes.CDLL:
     lib.qoimi_workspace_bytes.argtypes = [vp, ctypes.POINTER(sz)]
     lib.qoimi_encode_suspect_calls.restype = ctypes.c_longlong
     lib.qoimi_encode_suspect_calls.argtypes = [vp]
+    lib.qoimi_set_encode_small_call_order.restype = ci
+    lib.qoimi_set_encode_small_call_order.argtypes = [vp, ci]
     lib.qoimi_encode_retries.restype = ctypes.c_longlong
     lib.qoimi_encode_retries.argtypes = [vp]
     lib.qoimi_encode_images.restype = ci
@@ -247,6 +249,11 @@ class Context:
     def encode_suspect_calls(self) -> int:
         """Encode calls of this context made with the exchange probe since the last passed LDS-order check when a repeat failed (0: never)."""
         return int(self._lib.qoimi_encode_suspect_calls(self._h))
+
+    def set_encode_small_call_order(self, by_workgroup_index: bool) -> None:
+        """Calls of fewer than 8 images: units by ticket (default, safe on a shared device) or by workgroup index (4 us less per 4K
+        frame; then ``encode_status`` must be called before the streams are read)."""
+        self._check(self._lib.qoimi_set_encode_small_call_order(self._h, 1 if by_workgroup_index else 0), "qoimi_set_encode_small_call_order")
 
     def encode_retries(self) -> int:
         """Calls ``encode_status`` encoded again order-free because a placement wait had given up (0: never)."""

@@ -140,6 +140,7 @@ struct qoimi_ctx {
     int enc_adapt = 1;                  // env QOIMI_ENC_ADAPT=0: the set size ignores what the previous call's streams looked like
     uint32_t enc_hint_images = 0;       // images of the batch call whose count of flagged images stands in host_word[13]
     uint32_t enc_hint_npx = 0;          // pixels per image of the batch call whose first stream length stands in host_word[12] (0: none)
+    bool enc_heavy_before = false, enc_flagged_before = false;   // what the batch BEFORE the previous one looked like: a hint acts only when two batches in a row agree
     struct { const void* px; size_t ps; qoi_desc desc; int n; void* out; size_t os; int* len; void* st; bool valid = false; } last_enc;   // the last qoimi_encode_batch (qoimi_encode_status re-encodes it order-free if a wait gave up)
     int enc_spread = 1;                 // env QOIMI_ENC_SPREAD: the wavefronts of a workgroup take their tickets from consecutive images (0: all four from one image)
     int enc_pipe = 0;                   // env QOIMI_ENC_PIPE=1 (experiment, with QOIMI_ENC_PERSIST): next set's loads ahead of the current set's placement
@@ -321,6 +322,11 @@ extern "C" const char* qoimi_kernel_name(int i) {
 
 extern "C" long long qoimi_encode_suspect_calls(qoimi_ctx* c) { return c ? c->enc_suspect_calls : 0; }
 extern "C" long long qoimi_encode_retries(qoimi_ctx* c) { return c ? c->enc_retries : 0; }
+extern "C" int qoimi_set_encode_small_call_order(qoimi_ctx* c, int by_workgroup_index) {
+    if (!c) return fail(QOIMI_E_ARG, "ctx is NULL");
+    c->enc_tree_ticket = by_workgroup_index ? 0 : 1;
+    return QOIMI_OK;
+}
 
 // device memory the context holds: [0] encode workspace, [1] decode workspace, [2] staging of the host-pointer entry points
 extern "C" void qoimi_workspace_bytes(qoimi_ctx* c, size_t out[3]) {
@@ -416,8 +422,14 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
         // photographs of 1.2 B/px lose 10 % at two).  What the content looks like is taken from the previous batch call of the context:
         // the length of its first stream, copied to a pinned word behind that call (read here without a wait: a stale or missing
         // value only picks the other set size, the streams are the same bytes either way).
-        if (c->enc_adapt && place == 1 && r == 3u && c->enc_hint_npx != 0u && c->host_word[12] != 0u &&
-            (double)c->host_word[12] > 1.4 * (double)c->enc_hint_npx) r = 2u;
+        // (round 6: only when the TWO batches before this one were both that heavy.  Photographs behind a batch of 2.1 B/px lost 23 % to the
+        // two-slab sets their predecessor had earned, bench.py "alternating", profiles/r06_s8; a workload that alternates now never takes a
+        // hint, one that stays with its content takes it from its third batch on)
+        if (c->enc_adapt && place == 1 && n_images >= 8) {
+            const bool heavy = c->enc_hint_npx != 0u && c->host_word[12] != 0u && (double)c->host_word[12] > 1.4 * (double)c->enc_hint_npx;
+            if (r == 3u && heavy && c->enc_heavy_before) r = 2u;
+            c->enc_heavy_before = heavy;
+        }
         if (c->enc_set_slabs > 0) r = (uint32_t)c->enc_set_slabs;
         if (r > kEncMaxSetSlabs) r = kEncMaxSetSlabs;
         p.set_slabs = r;
@@ -453,7 +465,11 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     // an image's first flat stretch within microseconds and every other set of the image has nothing to do but to see the flag - one
     // workgroup per four sets is 345 000 workgroups that start and end for 512 4K frames, 0.5 ms of dispatch.  A sixteenth of them, each
     // looking at sixteen units, sees the same flags (photographs pay 7-9 % with several sets per wavefront: the hint is gone after one call).
-    all_flagged_before = c->enc_adapt && place == 1 && n_images >= 8 && c->enc_hint_images != 0u && c->host_word[13] >= c->enc_hint_images;
+    if (c->enc_adapt && place == 1 && n_images >= 8) {
+        const bool flagged = c->enc_hint_images != 0u && c->host_word[13] >= c->enc_hint_images;
+        all_flagged_before = flagged && c->enc_flagged_before;                  // (two batches in a row, as the set size above)
+        c->enc_flagged_before = flagged;
+    }
     if (all_flagged_before && p.persist == 0u) p.persist = 0xFFFFFFFFu;            // resolved below, once the units are known
     // ... or not at all (QOIMI_ENC_ALL_G2, default on): the pass over flagged images takes EVERY image of this call, and counts the images in
     // which some set had to walk the groups in front of its tail - the same statistic, so a batch of photographs behind flat batches
@@ -737,9 +753,14 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
             all_flat = sizes[i] > 22 && descs[i].width != 0 && dec_image_is_flat((uint32_t)sizes[i] - 8u, (uint32_t)((uint64_t)descs[i].width * descs[i].height));
             bytes += (uint64_t)(sizes[i] > 0 ? sizes[i] : 0);
         }
-        if (all_flat)
-            for (uint32_t cand = 4096u; cand >= 256u; cand >>= 1)
+        // (round 6: not below 512 bytes - 128 UI frames, 36 MB of streams, took 256 and with it rounds that re-open nearly everything: the
+        // stall rule sent them to the sequential pass, 147 ms where 512-byte segments take 5.2, profiles/r06_s9_uiflat_mid_batch.txt; a call
+        // with streams for a quarter of those lanes still takes 512, smaller ones the general model)
+        if (all_flat) {
+            for (uint32_t cand = 4096u; cand >= 512u; cand >>= 1)
                 if (bytes / cand >= 131072u) { B = cand; break; }
+            if (B == 0 && bytes / 512u >= 32768u) B = 512u;
+        }
     }
     if (B == 0) {
         // One lane decodes one segment.  Two costs pull in opposite directions (constants measured on MI355X):
@@ -950,7 +971,9 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         {
             const uint32_t open_now = c->host_word[1] - redo_cum;
             redo_cum = c->host_word[1];
-            stalled = (rounds >= 3 && (uint64_t)open_now * 16u > (uint64_t)open_prev * 15u) ? stalled + 1 : 0;
+            // (a round that closes less than a 64th of what was open; round 5 asked for a 16th and sent UI frames at small segments - slow
+            // but steady, a few per cent per round - to the sequential pass: 30 x the time of the rounds they still needed)
+            stalled = (rounds >= 4 && (uint64_t)open_now * 64u > (uint64_t)open_prev * 63u) ? stalled + 1 : 0;
             open_prev = open_now;
         }
         if (rounds >= c->dec_max_rounds || stalled >= 2) {

@@ -64,3 +64,55 @@ def test_two_rank_gloo(tmp_path):
     assert out["tot_px"] == 6 * 96 * 64 and out["tot_bytes"] == want_bytes
     assert out["n_ok"] == 2.0 and out["fsum"] == sum(range(6))      # ranks own disjoint frames 0..5
     assert out["cover"] == list(range(11))
+
+
+WORKER8 = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import torch
+    from qoi_amd import dist as qdist
+    rank, world, local = qdist.env_world()
+    qdist.init("gloo")
+    # BASELINE configs[4], literally: 8192 x 4K frames over 8 GPUs.  Weak: 1024 frames per rank whatever the world size; strong: the
+    # 8192 frames divided.  No frame is coded here (the arithmetic of the sharding and of the counters is what runs on eight ranks).
+    TOTAL, F, npx = 8192, 1024, 3840 * 2160
+    weak = qdist.shard_frames(rank, world, F)
+    strong = qdist.shard_range(TOTAL, rank, world)
+    odd = qdist.shard_range(8191, rank, world)                # a total the ranks do not divide
+    elapsed = 0.050 + 0.001 * ((rank * 5) %% world)            # every rank its own clock: max and min must come from different ranks
+    peak = float((150 + rank) << 30)                            # per-rank peak device bytes, as bench.py gathers them
+    mx, (px, frames, fsum, fsum_strong, n_odd, peak_sum) = qdist.reduce_counters(
+        elapsed, [float(len(weak) * npx), float(len(weak)), float(sum(weak)), float(sum(strong)), float(len(odd)), peak])
+    mn = qdist.reduce_min(elapsed)
+    peak_max, _ = qdist.reduce_counters(peak, [])
+    if rank == 0:
+        print(json.dumps({"world": world, "max": mx, "min": mn, "px": px, "frames": frames, "fsum": fsum, "fsum_strong": fsum_strong,
+                          "n_odd": n_odd, "peak_sum": peak_sum, "peak_max": peak_max,
+                          "strong_first": [strong.start, strong.stop], "weak_first": [weak[0], weak[-1]]}))
+    qdist.barrier()
+    torch.distributed.destroy_process_group()
+""") % ROOT
+
+
+def test_eight_rank_gloo_configs4_arithmetic(tmp_path):
+    """World size 8 on the CPU with the literal numbers of BASELINE configs[4] (the driver's 8-GPU run cannot be rehearsed on hardware
+    here): weak scaling = 1024 frames per rank, 8192 in total, disjoint frame ids; strong scaling = shard_range over 8192 (and over a
+    total the ranks do not divide); the reduced counters - pixels, frames, frame-id sums, max / min elapsed, per-rank peak device bytes
+    (max and sum) - are what bench.py prints at N = 8."""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["world"] == 8
+    assert out["frames"] == 8192 and out["px"] == 8192 * 3840 * 2160
+    assert out["fsum"] == sum(range(8192)) == out["fsum_strong"]            # both partitions cover frames 0..8191 exactly once
+    assert out["n_odd"] == 8191
+    assert out["strong_first"] == [0, 1024] and out["weak_first"] == [0, 1023]
+    assert abs(out["max"] - 0.057) < 1e-9 and abs(out["min"] - 0.050) < 1e-9
+    assert out["peak_max"] == float(157 << 30) and out["peak_sum"] == float(sum((150 + r) << 30 for r in range(8)))
+    # eight ranks of the headline shard at once: 8 x 170 GB of 288 GB each is per GPU, not per node - every rank's peak must fit ITS device
+    assert out["peak_max"] < 288e9

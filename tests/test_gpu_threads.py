@@ -56,4 +56,19 @@ def test_concurrent_device_frames_under_waiting_placements():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress_threads.py"), "--threads", "6", "--calls", "12"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "no spin bound tripped" in r.stdout
+    assert "no placement wait gave up" in r.stdout
+
+
+@pytest.mark.gpu
+def test_single_frames_beside_whole_batches():
+    """Round 5's review, 3c: three contexts on three streams run single-frame encodes (the library's default placement: tickets) WHILE a
+    fourth context round-trips whole batches on a stream of its own - thousands of workgroups of the batch's kernels between the small
+    calls' workgroups.  Every stream equals the reference's, every batch hashes like the first, no placement wait gives up
+    (qoimi_encode_retries stays 0).  The 1024-frame campaign: profiles/r06_stress_batches.txt."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress_threads.py"), "--threads", "3", "--calls", "60",
+                        "--batch-frames", "96", "--default-placement"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "no placement wait gave up" in r.stdout and "batches of 96 frames" in r.stdout
