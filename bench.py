@@ -640,9 +640,10 @@ def main() -> None:
     # Cache on repeat runs and bound by launch latency, not by HBM - reported next to the batch figure, never as it)
     single = None
     if not args.encode_only and not args.no_single and rank == 0:
-        one = [sizes[0]]
+        one = (ctypes.c_int * 1)(sizes[0])                 # the C caller's arguments as C arrays (int sizes[1], qoi_desc descs[1]): no per-call list conversion in the binding
+        one_desc = (api.QoiDesc * 1)(desc)
         enc1 = lambda: ctx.encode_batch(pixels.data_ptr(), pstride, desc, 1, streams.data_ptr(), sstride, lens.data_ptr(), stream)
-        dec1 = lambda: ctx.decode_batch(streams.data_ptr(), sstride, one, [desc], 4, decoded.data_ptr(), pstride, stream)
+        dec1 = lambda: ctx.decode_batch(streams.data_ptr(), sstride, one, one_desc, 4, decoded.data_ptr(), pstride, stream)
         # (the reference checks above keep the host busy and the GPU idle for seconds: its clocks have dropped, and 20 launches of 40 us
         # do not bring them back - 0.3 s of the same calls first, then the timed ones)
         t_warm = time.perf_counter()

@@ -264,10 +264,13 @@ class Context:
         n = len(sizes)
         if len(descs) != n:
             raise QoiError(f"decode_batch: {n} sizes but {len(descs)} descriptors")
-        if n > 1 and any(int(sz) > stream_stride for sz in sizes):
-            raise QoiError("decode_batch: a stream is longer than stream_stride")
-        c_sizes = (ctypes.c_int * n)(*[int(s) for s in sizes])
-        c_descs = (QoiDesc * n)(*descs)
+        if isinstance(sizes, ctypes.Array) and isinstance(descs, ctypes.Array):
+            c_sizes, c_descs = sizes, descs               # the caller's own C arrays (int[n], qoi_desc[n]): handed through as they are
+        else:
+            if n > 1 and any(int(sz) > stream_stride for sz in sizes):
+                raise QoiError("decode_batch: a stream is longer than stream_stride")
+            c_sizes = (ctypes.c_int * n)(*[int(s) for s in sizes])
+            c_descs = (QoiDesc * n)(*descs)
         self._check(self._lib.qoimi_decode_batch(self._h, d_streams, stream_stride, c_sizes, c_descs, n, channels,
                                                  d_pixels, pixel_stride, stream), "qoimi_decode_batch")
 

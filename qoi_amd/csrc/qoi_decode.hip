@@ -1071,6 +1071,51 @@ __global__ __launch_bounds__(256) void dec_chain_state_l1q(DecParams p) {
     p.grp_summary[(size_t)G * 65u + lane] = P_tab;
     if (lane == 0) p.grp_summary[(size_t)G * 65u + 64u] = P_px;
 }
+// The per-image level for those calls as PREFIXES (round 6): dec_chain_state_l2m composed its shares, handed a summary from workgroup to
+// workgroup (flags, spins), applied 16 shares and swept its share - 59 dependent steps + waits, 19.5 us on a lone 4K frame.  Here a
+// wavefront composes its share and STORES the inclusive prefix after every step, the first wavefront does the same over the workgroup's 16
+// shares: 26 steps, nothing waits.  The group's entry state is then the image's start state pushed through (workgroups in front)(shares in
+// front, one prefix)(groups in front, one prefix) - in dec_chain_state_l3q, every group for itself.
+constexpr uint32_t kL2pWgs = 8;
+__device__ __forceinline__ void sym_compose_range_prefix(const sym_t* __restrict__ rec, uint32_t count, uint32_t lane, sym_t& P_tab, sym_t& P_px, sym_t* __restrict__ out) {
+    if (count == 0u) return;
+    SymBatch cur, nxt;
+    sym_batch_load(cur, rec, 0u, count, lane);
+    for (uint32_t g = 0; g < count; g += kChainBatch) {
+        const uint32_t n = min(count - g, (uint32_t)kChainBatch);
+        sym_batch_load(nxt, rec, g + kChainBatch, count, lane);
+#pragma unroll
+        for (int i = 0; i < kChainBatch; ++i) {
+            if ((uint32_t)i < n) {
+                sym_chain_step(cur.tab[i], batch_px(cur, i), P_tab, P_px);
+                out[(size_t)(g + i) * 65u + lane] = P_tab;
+                if (lane == 0) out[(size_t)(g + i) * 65u + 64u] = P_px;
+            }
+        }
+        cur = nxt;
+    }
+}
+__global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2p(DecParams p) {
+    __shared__ sym_t s_sum[kL2Waves][65];
+    const uint32_t img = blockIdx.x / kL2pWgs, k = blockIdx.x % kL2pWgs, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const DecImage im = p.images[img];
+    if (im.start_seg >= im.n_active) return;
+    const uint32_t gfirst = im.start_seg / kGrp, gend = (im.n_active + kGrp - 1u) / kGrp;
+    const uint32_t per = (gend - gfirst + kL2pWgs * kL2Waves - 1u) / (kL2pWgs * kL2Waves);
+    const uint32_t lo = min(gfirst + (k * kL2Waves + wave) * per, gend), hi = min(lo + per, gend);
+    {
+        sym_t P_tab = sym_make(0u, lane, 0u), P_px = sym_make(0u, 64u, 0u);          // identity
+        sym_compose_range_prefix(p.grp_summary + (size_t)(im.grp_base + lo) * 65u, hi - lo, lane, P_tab, P_px, p.grp_prefix + (size_t)(im.grp_base + lo) * 65u);
+        s_sum[wave][lane] = P_tab;
+        if (lane == 0) s_sum[wave][64] = P_px;
+    }
+    __syncthreads();
+    if (wave != 0u) return;
+    sym_t P_tab = sym_make(0u, lane, 0u), P_px = sym_make(0u, 64u, 0u);
+    sym_compose_range_prefix(&s_sum[0][0], kL2Waves, lane, P_tab, P_px, p.share_prefix + (size_t)((img * kL2pWgs + k) * kL2Waves) * 65u);
+    p.l2_sum[(size_t)(img * kL2pWgs + k) * 65u + lane] = P_tab;
+    if (lane == 0) p.l2_sum[(size_t)(img * kL2pWgs + k) * 65u + 64u] = P_px;
+}
 __global__ __launch_bounds__(256) void dec_chain_state_l3q(DecParams p) {
     const uint32_t G = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t img = find_image_by_group(p.images, p.n_images, G);
@@ -1080,7 +1125,31 @@ __global__ __launch_bounds__(256) void dec_chain_state_l3q(DecParams p) {
     const uint32_t lo = max(j0, im.start_seg), hi = min(j0 + kGrp, im.n_active);
     const uint32_t wlo = max(lo, j0 + 16u * wave), whi = min(hi, j0 + 16u * wave + 16u);
     if (whi <= wlo) return;
-    uint32_t tabv = p.grp_entry[(size_t)G * 65u + lane], pxv = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.grp_entry[(size_t)G * 65u + 64u]);
+    uint32_t tabv, pxv;
+    if (p.grp_prefix) {
+        // the group's entry state from the image's start state (given at start_seg) and the prefixes dec_chain_state_l2p left
+        const uint32_t gfirst = im.start_seg / kGrp, gend = (im.n_active + kGrp - 1u) / kGrp, g = G - im.grp_base;
+        const uint32_t per = (gend - gfirst + kL2pWgs * kL2Waves - 1u) / (kL2pWgs * kL2Waves);
+        const uint32_t sh = (g - gfirst) / per, k = sh / kL2Waves, c = sh % kL2Waves, i = (g - gfirst) - sh * per;
+        const size_t q0 = (size_t)im.seg_base + im.start_seg;
+        tabv = p.entry[q0 * 65u + lane]; pxv = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.entry[q0 * 65u + 64u]);
+        sym_t rt[kL2pWgs + 1u], rp[kL2pWgs + 1u];               // all asked for at once: workgroups 0..k-1 (k <= 7), the share prefix, the group prefix
+#pragma unroll
+        for (uint32_t m = 0; m < kL2pWgs - 1u; ++m) {
+            const sym_t* r = p.l2_sum + (size_t)(img * kL2pWgs + min(m, k ? k - 1u : 0u)) * 65u;
+            rt[m] = r[lane]; rp[m] = r[64];
+        }
+        {   const sym_t* r = p.share_prefix + (size_t)((img * kL2pWgs + k) * kL2Waves + (c ? c - 1u : 0u)) * 65u;
+            rt[kL2pWgs - 1u] = r[lane]; rp[kL2pWgs - 1u] = r[64]; }
+        {   const sym_t* r = p.grp_prefix + (size_t)(G - (i ? 1u : 0u)) * 65u;
+            rt[kL2pWgs] = r[lane]; rp[kL2pWgs] = r[64]; }
+#pragma unroll
+        for (uint32_t m = 0; m < kL2pWgs - 1u; ++m) if (m < k) sym_sweep_step(rt[m], uniform_sym(rp[m]), tabv, pxv);
+        if (c != 0u) sym_sweep_step(rt[kL2pWgs - 1u], uniform_sym(rp[kL2pWgs - 1u]), tabv, pxv);
+        if (i != 0u) sym_sweep_step(rt[kL2pWgs], uniform_sym(rp[kL2pWgs]), tabv, pxv);
+    } else {
+        tabv = p.grp_entry[(size_t)G * 65u + lane]; pxv = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.grp_entry[(size_t)G * 65u + 64u]);
+    }
     sym_t qt[3], qp[3];                                       // the quarters in front of this wavefront's (all three asked for: the loads do not wait for each other)
 #pragma unroll
     for (uint32_t k = 0; k < 3u; ++k) {
@@ -1279,7 +1348,12 @@ struct LdsLutT { uint2 e[260]; };
 // from the entry phase S1 then knows.
 // MODE 1 - segments flagged by MODE 0 (all active ones if DecParams::sync_all), entry phase from S1.
 constexpr uint32_t kSyncBytes = 64;
-template <int MODE>
+// TRACK (round 6 experiment, not instantiated by default - kTailsInTranscoder): the lane also keeps the slot / alpha transfer of its
+// segment as it goes (SlotRec: what the chunk that last named a slot absolutely left + the hash shifts behind it), four vector
+// instructions per record, so that dec_scan_entry needs no tail walk.  Measured: what the scan saves the transcoder pays (see there).
+// SPLIT (round 6, DecParams::tr_split): two lanes per segment, each walks half of it from a run-up of its own; the even lane writes
+// the segment's outputs (the odd lane's values come over by a lane shift).
+template <int MODE, bool TRACK = false, bool SPLIT = false>
 __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     __shared__ uint32_t s_ring[QOIMI_TR_WAVES][TransReader::kSlots * 64];
     __shared__ LdsLutT s_lut;
@@ -1295,7 +1369,8 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     }
     if (threadIdx.x < 4u) s_lut.e[256u + threadIdx.x] = make_uint2(0u, 0u);
     __syncthreads();
-    const uint32_t q = blockIdx.x * kTrThreads + threadIdx.x;
+    const uint32_t T = blockIdx.x * kTrThreads + threadIdx.x;
+    const uint32_t q = SPLIT ? T >> 1 : T, half = SPLIT ? T & 1u : 0u;
     bool have = q < p.total_segs;
     uint32_t img;
     DecImage im;
@@ -1314,12 +1389,15 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
     if (MODE == 1) have = have && j >= im.start_seg && j < im.n_active && (p.sync_all || p.sync_fail[q] != 0u);
     if (MODE == 0 && have && j >= im.nseg) {               // a padding segment between two images (DecParams::fused): nothing to read, nothing flagged
-        p.sync_fail[q] = 0; p.rec_gran[q] = 0u;
+        if (half == 0u) { p.sync_fail[q] = 0; p.rec_gran[q] = 0u; }
         have = false;
     }
+    const uint32_t sbase = (uint32_t)kHeaderBytes + j * p.seg_bytes;        // the segment
+    const uint32_t hbytes = SPLIT ? p.seg_bytes >> 1 : p.seg_bytes;
+    const uint32_t base = sbase + half * hbytes;                            // this lane's part of it
+    if (SPLIT && have && base >= im.chunks_end) have = false;              // the stream ends in the segment's first half (the even lane always has bytes: j < nseg)
     if (!lanes_where(have)) return;
-    const uint32_t base = (uint32_t)kHeaderBytes + j * p.seg_bytes;
-    const uint32_t end = min(base + p.seg_bytes, im.chunks_end);
+    const uint32_t end = min(base + hbytes, im.chunks_end);
     const uint32_t lut_base = lds_addr_of(&s_lut.e[0]);
     PipeReaderT<MODE == 0> R;                 // MODE 0: requests through a descriptor; MODE 1 (rare): plain pointers, reaches anything
     uint32_t pos;
@@ -1379,10 +1457,14 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
             R.template turn<2>(m); sync_steps();
         }
         failed = have && (!merged || !reach);
+        if (SPLIT) {                                          // either half: the whole segment takes the five-phase parse
+            const int other = __shfl_xor((int)failed, 1);     // (every lane asks: a lane that skipped the exchange would hand its neighbour nothing)
+            failed = failed || other != 0;
+        }
         pos = m;                                              // merged: the first chunk start at or behind the segment start
         // the ring was refilled for the front position; the walk below continues the same byte stream
-        const u64 fails = lanes_where(failed);
-        if (have) p.sync_fail[q] = failed ? 1 : 0;
+        const u64 fails = lanes_where(failed && half == 0u);
+        if (have && half == 0u) p.sync_fail[q] = failed ? 1 : 0;
         if (fails != 0 && lane == (uint32_t)__builtin_ctzll(fails)) atomicAdd(p.sync_fails, (uint32_t)__builtin_popcountll(fails));
     }
     bool active = have && !failed && pos < end;
@@ -1400,14 +1482,17 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     {   const uint32_t i8 = byte0_times8(w32);
         const u32x2v te = *(lds_u32x2*)(lut_base + (active ? i8 : 2048u)); tpl = te.x; info = te.y; }
     uint32_t a_abs = 0u, a_last = 0u;            // a QOI_OP_RGBA occurred in the segment / the alpha of the last one (for dec_slot_tails)
+    uint32_t f_hc = 0u, f_rel = 1u, f_alpha = 0u, f_stash = 0u;      // TRACK: the transfer so far (slot_init: identity)
     uint32_t pend = 0u;                          // 1 / 2: the first record of the QOI_OP_RGBA / QOI_OP_RGB chunk under the cursor is out
     bool any_pend = false;
     uint32_t npix = 0u;
     // granule row g of this wavefront's 64 segments: one contiguous KiB.  Stored through a descriptor over the block's rows with a
     // 32-bit offset that moves on by a row per granule (the 64-bit address of every store was four vector instructions)
-    const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)(p.recs + (size_t)(blockIdx.x * QOIMI_TR_WAVES + wave) * p.rec_rows * 256u), 0,
+    const uint32_t rec_blk = SPLIT ? (blockIdx.x * kTrThreads + wave * 64u) >> 7 : blockIdx.x * QOIMI_TR_WAVES + wave;      // the block of 64 segments the wavefront's segments lie in
+    const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)(p.recs + (size_t)rec_blk * p.rec_rows * 256u), 0,
                                                                              (int)(p.rec_rows * 1024u), 0x00020000);
-    uint32_t roff = lane * 16u;                                          // byte offset of the lane's next granule
+    const uint32_t roff0 = (SPLIT ? (q & 63u) : lane) * 16u + (SPLIT ? half * p.tr_rows_half * 1024u : 0u);
+    uint32_t roff = roff0;                                               // byte offset of the lane's next granule
     auto granule_steps = [&]() {
         {
             const bool live = active;                                    // the granule holds at least one record of this lane
@@ -1450,8 +1535,23 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
                     }
                     any_pend = lanes_where(pend != 0u) != 0;
                     npix += cnt;
+                    if (TRACK) {                                         // the record as it goes out (tail_step's cases, forwards)
+                        const uint32_t cls = rec >> 30, pay = rec & 0x00FFFFFFu;
+                        const bool is_stash = cls == 2u && ((rec >> 24) & 63u) == kRecStash;
+                        const uint32_t lh = __builtin_amdgcn_udot4(pay, 0x00070503u, 0u, false);
+                        if (cls == 0u) f_hc += lh;
+                        else if (cls == 1u) { f_hc = rec & 63u; f_rel = 0u; f_alpha = 0u; }
+                        else if (is_stash) f_stash = pay;
+                        else if (cls == 2u) { f_hc = lh + (a_abs ? 11u * a_last : 0u); f_rel = 0u; f_alpha = a_abs ? 0u : 1u; }
+                        else { f_hc = __builtin_amdgcn_udot4(f_stash, 0x00070503u, 0u, false) + 11u * (rec & 0xFFu); f_rel = 0u; f_alpha = 0u; }
+                    }
                 } else {
                     add_dword_byte2(npix, c_info);                       // the chunk's pixels straight from the table word
+                    if (TRACK) {                                         // relative (RUN and the null record: nothing added) or INDEX
+                        const bool idx = rec >= 0x40000000u;
+                        f_hc = idx ? rec : f_hc + __builtin_amdgcn_udot4(rec & 0x00FFFFFFu, 0x00070503u, 0u, false);
+                        f_rel = idx ? 0u : f_rel; f_alpha = idx ? 0u : f_alpha;
+                    }
                 }
                 const uint32_t nrp = rp + adv;
                 uint32_t nw32; R.peek4_rel(nrp, nw32, b5hi, b5sh);
@@ -1473,13 +1573,28 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         R.template turn_rel<2>(rp); granule_steps();
     }
     pos = rp + R.aoff;
+    uint32_t gran_word = (roff - roff0) >> 10;                          // granules written
+    if (SPLIT) {
+        // the odd lane's half over to the even lane, which writes the segment's outputs (a lane that took no part holds nothing: no
+        // granules, no pixels, no QOI_OP_RGBA, and `pos` is not looked at)
+        const uint32_t n1 = (uint32_t)__shfl_down((int)(have ? gran_word : 0u), 1), px1 = (uint32_t)__shfl_down((int)(have ? npix : 0u), 1);
+        const uint32_t ab1 = (uint32_t)__shfl_down((int)(have ? a_abs : 0u), 1), al1 = (uint32_t)__shfl_down((int)a_last, 1);
+        const uint32_t pos1 = (uint32_t)__shfl_down((int)pos, 1), hv1 = (uint32_t)__shfl_down((int)(have ? 1u : 0u), 1);
+        if (half == 0u) {
+            gran_word |= n1 << 16; npix += px1;
+            a_last = ab1 ? al1 : a_last; a_abs |= ab1;
+            pos = hv1 ? pos1 : pos;
+        }
+        have = have && half == 0u;
+    }
     if (have && !failed) {
-        p.rec_gran[q] = roff >> 10;                                     // granules written
+        p.rec_gran[q] = gran_word;
         SlotRec r; r.hc = 0; r.h_rel = 0; r.h_alpha = 0; r.a_abs = (uint8_t)a_abs; r.ac = (uint8_t)a_last;      // dec_slot_tails / dec_scan_entry completes it
+        if (TRACK) { r.hc = (uint8_t)(f_hc & 63u); r.h_rel = (uint8_t)f_rel; r.h_alpha = (uint8_t)f_alpha; }
         p.slot_rec[q] = r;
         if (MODE == 0) {
             // parse record for S1: the same whatever entry phase S1 asks for - it only ever asks for the true one
-            const uint32_t nominal = base + p.seg_bytes;
+            const uint32_t nominal = sbase + p.seg_bytes;
             const uint32_t e = pos > nominal ? pos - nominal : 0u;      // bytes the last chunk reaches into the next segment
             ParseRec pr;
             pr.exit_phase = e * (1u | (1u << 3) | (1u << 6) | (1u << 9) | (1u << 12));
@@ -1510,17 +1625,22 @@ struct RecSource {
     __amdgpu_buffer_rsrc_t rs;
     uint32_t off;          // byte offset of the lane's column in a granule row
     uint32_t n_gran;       // granules of the lane
+    uint32_t n0, skip;     // DecParams::tr_split: granules [0, n0) lie in rows [0, n0), the rest `skip` bytes further on (rows from tr_rows_half)
     static constexpr uint32_t kNowhere = 0x7FFFFFF0u;
+    // grans: the segment's rec_gran word
     __device__ __forceinline__ void init(const DecParams& p, uint32_t block64, uint32_t lane, uint32_t grans) {
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.recs + (size_t)block64 * p.rec_rows * 256u), 0, (int)(p.rec_rows * 1024u), 0x00020000);
-        off = lane * 16u; n_gran = grans;
+        off = lane * 16u;
+        if (p.tr_split) { n0 = grans & 0xFFFFu; n_gran = n0 + (grans >> 16); skip = (p.tr_rows_half - n0) * 1024u; }
+        else { n0 = grans; n_gran = grans; skip = 0u; }
     }
+    __device__ __forceinline__ uint32_t row_off(uint32_t g) const { return g < n_gran ? off + 1024u * g + (g < n0 ? 0u : skip) : kNowhere; }
     __device__ __forceinline__ u32x4 granule(uint32_t g) const {
-        return __builtin_amdgcn_raw_buffer_load_b128(rs, g < n_gran ? off + 1024u * g : kNowhere, 0, QOIMI_REC_LOAD_AUX);
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, row_off(g), 0, QOIMI_REC_LOAD_AUX);
     }
     // the same as a streaming (non-temporal) load: dec_summarize_rec, -3 %; dec_segments_rec is 3 % slower with it
     __device__ __forceinline__ u32x4 granule_nt(uint32_t g) const {
-        return __builtin_amdgcn_raw_buffer_load_b128(rs, g < n_gran ? off + 1024u * g : kNowhere, 0, 2);
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, row_off(g), 0, 2);
     }
 };
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -1578,8 +1698,11 @@ __global__ __launch_bounds__(64) void dec_slot_tails(DecParams p) {
 //   word: bits 0..28 pixels (saturating at 2^29 - 1 > QOI_PIXELS_MAX), 29..45 slot transfer, 46..61 tag, 62..63 state
 // ---------------------------------------------------------------------------------
 constexpr u64 kScanAgg = 1ull << 62, kScanIncl = 2ull << 62;
-// (the tail walk in dec_transcode<0>'s epilogue instead - the lane reads its own last rows back - moved its 6.5 us there: 31.3 + 19.6 us
-// became 38.2 + 13.5, profiles/r06_s2: the wavefronts of a lone frame are alone on their SIMDs and end together, nothing hides it)
+// (Two ways of leaving the tail walk to dec_transcode<0> were built and measured, both a wash on a lone 4K frame: reading the lane's own
+// last rows back in its epilogue - 31.3 + 19.6 us became 38.2 + 13.5; keeping the transfer while walking (dec_transcode<0, TRACK>: four
+// vector instructions per record) - 32.4 + 19.8 became 38.5 + 13.8, profiles/r06_s12.  A wavefront that is alone on its SIMD issues one
+// instruction every ~8 cycles whatever depends on what: these kernels are bound by the instruction count of their longest wavefront, and
+// work moved from one to the other costs there what it saves here.)
 constexpr bool kTailsInTranscoder = false;
 constexpr uint32_t kScanPxCap = (1u << 29) - 1u;
 __device__ __forceinline__ uint32_t scan_sat(uint32_t a, uint32_t b) { const uint32_t s = sat_add(a, b); return s < kScanPxCap ? s : kScanPxCap; }
@@ -2463,9 +2586,10 @@ __global__ __launch_bounds__(64) void dec_sequential(DecParams p) {
     for (uint32_t j = im.start_seg; j < im.n_active && pos < limit; ++j) {
         const uint32_t q = im.seg_base + j;
         const uint32_t* col = p.recs + ((size_t)(q >> 6) * p.rec_rows * 64u + (q & 63u)) * 4u;      // granule g of this segment at col + g*256
-        const uint32_t n = p.rec_gran[q];
+        const uint32_t gw = p.rec_gran[q];
+        const uint32_t n0 = p.tr_split ? gw & 0xFFFFu : gw, n = p.tr_split ? n0 + (gw >> 16) : gw;      // (two-lane transcoder: RecSource)
         for (uint32_t g = 0; g < n && pos < limit; ++g) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(col + (size_t)g * 256u);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(col + (size_t)(g < n0 ? g : g - n0 + p.tr_rows_half) * 256u);
             const uint32_t rr[4] = {v.x, v.y, v.z, v.w};
             for (uint32_t k = 0; k < 4u && pos < limit; ++k) {
                 const uint32_t rec = rr[k], cls = rec_class(rec);
@@ -2524,9 +2648,13 @@ __global__ __launch_bounds__(256) void dec_fill(DecParams p) {
             const uint32_t pend = __hip_atomic_load(p.pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), redo = __hip_atomic_load(p.redo_segs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t sf = *p.sync_fails;
             if (threadIdx.x == 0u) {
+                uint32_t need_fill = 0u;                                      // some image's chunks end before its pixels do: this launch still has pixels to write
+                for (uint32_t i = 0; i < p.n_images; ++i) need_fill |= p.images[i].total_px < p.images[i].npx ? 1u : 0u;
                 __hip_atomic_store(&p.host_result[1], redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&p.host_result[2], sf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&p.host_result[0], pend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&p.host_result[3], need_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&p.host_result[4], p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // "the words above are this call's"
             }
             // The call is complete (no image to restart, every segment synchronised): the counter header as the context's NEXT call wants to
             // find it - that call then needs no copy in front of its first kernel.  Nothing of this launch looks at these words any more.
@@ -2567,7 +2695,8 @@ void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
 // Calls of a few images (DecParams::fused): dec_transcode<0>, then everything P3 needs from ONE kernel (dec_scan_entry)
 void launch_decode_fused_front(const DecParams& p, hipStream_t st, KernelTimer* tm) {
     tm->mark(kT_begin, st);
-    hipLaunchKernelGGL(dec_transcode<0>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
+    if (p.tr_split) hipLaunchKernelGGL((dec_transcode<0, kTailsInTranscoder, true>), dim3((2u * p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
+    else hipLaunchKernelGGL((dec_transcode<0, kTailsInTranscoder>), dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
     tm->mark(kT_dec_slot_walk, st);
     hipLaunchKernelGGL(dec_scan_entry, dim3(p.total_segs / kScanSegs), dim3(kScanSegs), 0, st, p);
     tm->mark(kT_dec_chain_slots, st);
@@ -2592,7 +2721,8 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     auto chain_state = [&]() {
         if (p.qtr_summary) hipLaunchKernelGGL(dec_chain_state_l1q, dim3(p.total_grps), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
-        if (p.l2_wgs > 1u) hipLaunchKernelGGL(dec_chain_state_l2m, dim3(p.n_images * p.l2_wgs), dim3(64 * kL2Waves), 0, st, p, p.l2_tag_base + l2_seq++);
+        if (p.grp_prefix) hipLaunchKernelGGL(dec_chain_state_l2p, dim3(p.n_images * kL2pWgs), dim3(64 * kL2Waves), 0, st, p);
+        else if (p.l2_wgs > 1u) hipLaunchKernelGGL(dec_chain_state_l2m, dim3(p.n_images * p.l2_wgs), dim3(64 * kL2Waves), 0, st, p, p.l2_tag_base + l2_seq++);
         else hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
         if (p.qtr_summary) hipLaunchKernelGGL(dec_chain_state_l3q, dim3(p.total_grps), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(dec_chain_state_l3, dim3(p.total_grps), dim3(64), 0, st, p);

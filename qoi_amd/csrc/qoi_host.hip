@@ -119,6 +119,7 @@ struct qoimi_ctx {
     bool dropin = false;                // the context of a thread's qoi_encode / qoi_decode calls (thread_ctx)
     int enc_tree_ticket = -1;           // -1: 1 for qoimi_encode_batch, 0 inside the drop-in qoi_encode.  1: tree placement hands its units out by one ticket per workgroup (start order: no assumption about the dispatcher); 0 (QOIMI_ENC_TREE_TICKET=0,
                                         // and always inside the drop-in qoi_encode, which encodes again by itself): by workgroup index, 4 us less per 4K frame
+    int dec_split = 1;                  // env QOIMI_DEC_SPLIT=0: one transcoder lane per segment in those calls too
     int dec_fused = 1;                  // env QOIMI_DEC_FUSED=0: calls of a few images take the three-level chains of the batch path instead of the single-pass look-back kernels
     uint32_t test_spin_bound = 0;       // env QOIMI_TEST_SPIN_BOUND (tests): polls before a placement wait gives up
     bool tight_buffer = false;          // env QOIMI_ENCODE_TIGHT_BUFFER=1 (read once, at creation): qoi_encode sizes its result by the thread's previous stream instead of
@@ -147,6 +148,7 @@ struct qoimi_ctx {
     int enc_persist = 0;                // env QOIMI_ENC_PERSIST: workgroups of the first encode pass (0: one per unit)
     int enc_lookback = -1;              // 1: sets place their bytes themselves (decoupled look-back); 2: the same by the tree of byte counts; 0: order-free (scratch slots + enc_offsets + enc_compact); -1: by the call's shape
     std::string enc_debug_dump;         // env QOIMI_ENC_DEBUG_DUMP: file that receives the entry-state arrays of every encode call
+    std::string dec_debug_dump;         // env QOIMI_DEC_DEBUG_DUMP: file that receives the per-segment arrays (granule counts, parse records, pixel offsets) of every decode call
     int dec_refine = 1;                 // 0: rounds after a failed check re-speculate from scratch (no alpha hints)
     int dec_fine = 1;                   // 0: lane-per-segment P1/P2 even where the 128-byte piece kernels apply
     int dec_p3_plain = 1, dec_inner = 8, dec_inner1 = 3;   // env QOIMI_P3_PLAIN, QOIMI_DEC_INNER, QOIMI_DEC_INNER1 (read once, at creation)
@@ -221,6 +223,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         knob("QOIMI_ENC_TICKET", c->enc_ticket); knob("QOIMI_ENC_SET_SLABS", c->enc_set_slabs); knob("QOIMI_ENC_WARM", c->enc_warm);
         knob("QOIMI_ENC_LOOKBACK", c->enc_lookback);
         if (const char* e = getenv("QOIMI_ENC_DEBUG_DUMP")) c->enc_debug_dump = e;
+        if (const char* e = getenv("QOIMI_DEC_DEBUG_DUMP")) c->dec_debug_dump = e;
         flag("QOIMI_ENC_SPREAD", c->enc_spread); flag("QOIMI_ENC_TREE_TICKET", c->enc_tree_ticket); flag("QOIMI_ENC_ADAPT", c->enc_adapt);
         flag("QOIMI_ENC_G2", c->enc_g2); flag("QOIMI_ENC_ALL_G2", c->enc_all_g2); flag("QOIMI_ENC_PREZERO", c->enc_prezero); flag("QOIMI_ENC_UNI", c->enc_uni);
         flag("QOIMI_ENC_PIPE", c->enc_pipe);
@@ -231,7 +234,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         if (const char* e = getenv("QOIMI_DEC_INNER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner = v; }
         if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
         knob("QOIMI_DEC_L2M", c->dec_l2_wgs); knob("QOIMI_DEC_RUN_DESC", c->dec_run_desc); knob("QOIMI_DEC_FLAT_SEG", c->dec_flat_seg);
-        knob("QOIMI_DEC_FUSED", c->dec_fused);
+        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split);
         if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
         if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
         if (const char* e = getenv("QOIMI_SEG_BYTES")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v; }
@@ -785,6 +788,13 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
             const double t = (cand / 1.2) * 0.6 * rounds + ((double)largest / cand / 64.0 / 8.0 + 16.0) * 0.5;
             if (t < best) { best = t; B = cand; }
         }
+        // A call that MIXES flat images with others (a directory of screenshots and photographs, bench.py "mixed_directory"): the flat
+        // ones' streams are a few hundred KB - a few dozen lanes at the 4 KiB the photographs' bytes ask for - and the symbolic pass walks
+        // them several times (refinement passes): 4.8 of that leg's 9.3 ms.  Not above 1 KiB then (photographs lose a few per cent, 4 x
+        // the lanes for the flat images' passes).
+        if (B > 1024u && c->dec_run_desc)
+            for (int i = 0; i < n_images; ++i)
+                if (sizes[i] > 22 && descs[i].width != 0 && dec_image_is_flat((uint32_t)sizes[i] - 8u, (uint32_t)((uint64_t)descs[i].width * descs[i].height))) { B = 1024u; break; }
     }
     return B;
 }
@@ -835,8 +845,11 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
     p.rec_rows = rec_rows_of(B);
+    if (fused && B == 128u && c->dec_split) {          // two transcoder lanes per segment (dec_transcode<0, .., SPLIT>): rows for two halves
+        p.tr_split = 1u; p.tr_rows_half = rec_rows_of(B / 2u); p.rec_rows = 2u * p.tr_rows_half;
+    }
     p.flat_segs = (uint32_t)flat_total;
-    p.desc_cap = rec_max_records(B) / 2u + 2u;              // a run ends with the record behind it: every second record at most
+    p.desc_cap = (p.tr_split ? 2u * rec_max_records(B / 2u) : rec_max_records(B)) / 2u + 2u;              // a run ends with the record behind it: every second record at most
     // descriptors for the long runs of the other images as well - not for calls of a few images without a flat one (one more launch
     // on a path that counts them)
     p.desc_all = (c->dec_run_desc >= 2 && (n_images > 4 || flat_total != 0)) ? 1u : 0u;
@@ -879,8 +892,13 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.grp_slot = w.take<SlotRec>(NG); p.grp_slot_in = w.take<uint8_t>(NG); p.grp_alpha_in = w.take<uint8_t>(NG);
         p.grp_summary = w.take<u64>(NG * 65); p.grp_entry = w.take<uint32_t>(NG * 65);
         p.l2_sum = w.take<u64>((size_t)n_images * p.l2_wgs * 65);
-        p.qtr_summary = w.take<u64>(n_images <= 4 && c->dec_fused ? NG * 4u * 65u : 0);       // calls of a few images: four wavefronts per group in the state chain
-        if (!(n_images <= 4 && c->dec_fused)) p.qtr_summary = nullptr;
+        // calls of a few images: four wavefronts per group in the state chain (quarter summaries), prefixes instead of a chain of workgroups
+        // at the per-image level
+        const bool few = n_images <= 4 && c->dec_fused != 0;
+        p.qtr_summary = w.take<u64>(few ? NG * 4u * 65u : 0);
+        p.grp_prefix = w.take<u64>(few ? NG * 65u : 0); p.share_prefix = w.take<u64>(few ? (size_t)n_images * 8u * 16u * 65u : 0);
+        if (few && p.l2_wgs < 8u) p.l2_sum = w.take<u64>((size_t)n_images * 8u * 65u);                  // (l2_sum above was sized for l2_wgs workgroups)
+        if (!few) { p.qtr_summary = nullptr; p.grp_prefix = nullptr; p.share_prefix = nullptr; }
         p.rec_gran = w.take<uint32_t>(Q);
         p.run_cnt = w.take<uint32_t>((flat_total || p.desc_all) ? Q : 0);
         p.run_queue = w.take<uint32_t>((flat_total || p.desc_all) ? Q : 0);
@@ -892,7 +910,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     if (fused) {
         const size_t words = (size_t)(total / kScanSegs) + 64u;
         const unsigned gen = c->dec_scan.gen;
-        if (c->dec_scan.reserve(words * sizeof(u64)) != QOIMI_OK) fused = false;          // (no memory for a few KB: the chains will do)
+        if (c->dec_scan.reserve(words * sizeof(u64)) != QOIMI_OK) { fused = false; p.tr_split = 0u; }          // (no memory for a few KB: the chains will do)
         else {
             c->dec_epoch = (c->dec_epoch + 1u) & 0xFFFFu;
             if (gen != c->dec_scan.gen || c->dec_epoch == 0u) {                           // a new arena, or the tag wraps: no word may carry a tag from before
@@ -948,7 +966,19 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         c->timer.mark(kT_dec_total, st);
         if (!p.total_segs) { HIP_TRY(hipStreamSynchronize(st)); break; }
         if (p.tail_fused) {
-            HIP_TRY(hipStreamSynchronize(st));
+            // dec_fill's first wavefront writes the round's counters into pinned words when everything in front of it - every pixel of the
+            // call: dec_segments_rec has ended - is done.  Where no image needs filling (word 23) the call may return on seeing them: the
+            // rest of that launch writes nothing.  A few microseconds earlier than the stream's completion signal; after 2 ms of looking (or
+            // with per-kernel timing on) the stream is waited for as ever.
+            volatile uint32_t* const hw = c->host_word;
+            bool seen = false;
+            if (!c->timer.on) {
+                for (uint32_t spin = 0; spin < 400000u; ++spin) {
+                    if (hw[24] == p.epoch) { seen = true; break; }
+                    __builtin_ia32_pause();
+                }
+            }
+            if (!seen || hw[23] != 0u) HIP_TRY(hipStreamSynchronize(st));
             c->host_word[0] = c->host_word[20]; c->host_word[1] = c->host_word[21]; c->host_word[2] = c->host_word[22];
             // (that dec_fill left the header zeroed; good for the next call if nothing else of this call touches it: no further round)
             c->dec_hdr_zero.at = (void*)p.pending; c->dec_hdr_zero.gen = c->dec_ws.gen; c->dec_hdr_zero.valid = c->host_word[0] == 0u && c->host_word[2] == 0u;
@@ -988,6 +1018,16 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     }
     HIP_TRY(hipGetLastError());
     timer_collect(c);
+    if (const char* dump = c->dec_debug_dump.empty() ? nullptr : c->dec_debug_dump.c_str()) {                // diagnostics: per-segment arrays of this call, raw
+        (void)hipStreamSynchronize(st);
+        if (FILE* fo = fopen(dump, "wb")) {
+            auto put = [&](const void* d, size_t bytes) { std::vector<uint8_t> h(bytes); (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost); fwrite(h.data(), 1, bytes, fo); };
+            const uint64_t hdr[4] = {total, (uint64_t)p.tr_split, (uint64_t)p.rec_rows, (uint64_t)B};
+            fwrite(hdr, 8, 4, fo);
+            put(p.rec_gran, total * 4); put(p.parse, total * sizeof(ParseRec)); put(p.px_off, total * 4); put(p.sync_fail, total);
+            fclose(fo);
+        }
+    }
     stats[0] = rounds;
     stats[1] = p.total_segs ? c->host_word[1] : 0;
     stats[2] = (long long)total;

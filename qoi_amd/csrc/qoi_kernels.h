@@ -215,8 +215,17 @@ struct DecParams {
     // header is then zeroed by the dec_fill of the context's previous call (qoimi_decode_batch keeps track).
     uint32_t  tab_in_args;     // 1: tab4 holds the table
     DecImage  tab4[4];
+    u64*      grp_prefix;      // [total_grps][65] ... and the per-image level without a chain of workgroups (dec_chain_state_l2p): inside every share of groups the
+    u64*      share_prefix;    // [n_images * 8 * 16][65] symbolic INCLUSIVE prefixes, likewise over the 16 shares of a workgroup; dec_chain_state_l3q applies
+                               // "workgroups in front, shares in front, groups in front" to the image's start state itself: a dozen steps instead of a wait
+    // ... and dec_transcode<0> with TWO lanes per segment (128-byte segments only): a lone frame's wavefronts are alone on their SIMDs,
+    // each one instruction every ~8 cycles; twice the wavefronts of 60 % the length (32 bytes of run-up + 64 of walk instead of 32 + 128)
+    // fill the issue slots.  The halves' records lie in the segment's rows [0, n0) and [tr_rows_half, tr_rows_half + n1);
+    // rec_gran = n0 | n1 << 16 (a segment dec_transcode<1> wrote: n1 = 0) - RecSource maps a granule number to its row.
+    uint32_t  tr_split;        // 1: that form
+    uint32_t  tr_rows_half;    // rows reserved per half
     uint32_t  tail_fused;      // 1: that form
-    uint32_t* host_result;     // pinned host words: [0] pending, [1] redo_segs, [2] sync_fails
+    uint32_t* host_result;     // pinned host words: [0] pending, [1] redo_segs, [2] sync_fails, [3] 1: some image is still being filled, [4] the call's number (written last)
 };
 constexpr uint32_t kScanSegs = 256;      // segments per workgroup of dec_scan_entry
 

@@ -9,6 +9,6 @@ ulimit -c 0
 R=$PWD
 for L in qoi_amd/lib build/exp_p4x; do
   (cd /tmp && QOIMI_TOOLS_LIB=$R/$L/libqoi_mi355x.so timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/$OUT/trace" -o t -- python "$R/tools/measure/single_trace.py" 60 dec) > "$OUT/trace.log" 2>&1
-  python tools/measure/trace_timeline.py "$OUT/trace" "dec_transcode<0>" 40 | grep -E "dec_summarize|dec_segments|chain_state" | sed "s|^|$L |"
+  python tools/measure/trace_timeline.py "$OUT/trace" "dec_transcode<0" 40 | grep -E "dec_summarize|dec_segments|chain_state" | sed "s|^|$L |"
   rm -rf "$OUT/trace"
 done | tee "$OUT/state_io.txt"
