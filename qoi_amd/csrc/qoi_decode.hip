@@ -1050,27 +1050,6 @@ __global__ __launch_bounds__(64) void dec_chain_state_l3(DecParams p) {
 // dozen vector instructions, 0.17 us whatever is done about its loads, and a lone 4K frame's decode spent 64 of them in l1 and 64 in l3
 // one after the other (15 + 16 us).  Here a wavefront composes / sweeps a QUARTER of the group: l1 = 16 steps + 4 to compose the
 // quarters, l3 = up to 3 steps over the quarters in front + 16 - the same function of the summaries, a third of the depth.
-__global__ __launch_bounds__(256) void dec_chain_state_l1q(DecParams p) {
-    __shared__ sym_t s_q[4][65];
-    const uint32_t G = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t img = find_image_by_group(p.images, p.n_images, G);
-    const DecImage im = p.images[img];
-    const uint32_t j0 = (G - im.grp_base) * kGrp;
-    if (j0 + kGrp <= im.start_seg || j0 >= im.n_active) return;
-    const uint32_t lo = max(j0, im.start_seg), hi = min(j0 + kGrp, im.n_active);
-    const uint32_t wlo = max(lo, j0 + 16u * wave), whi = min(hi, j0 + 16u * wave + 16u);
-    sym_t P_tab = sym_make(0u, lane, 0u), P_px = sym_make(0u, 64u, 0u);          // identity
-    sym_compose_range(p.summary + (size_t)(im.seg_base + wlo) * 65u, whi > wlo ? whi - wlo : 0u, lane, P_tab, P_px);
-    sym_t* const qs = p.qtr_summary + ((size_t)G * 4u + wave) * 65u;
-    qs[lane] = P_tab; s_q[wave][lane] = P_tab;
-    if (lane == 0) { qs[64] = P_px; s_q[wave][64] = P_px; }
-    __syncthreads();
-    if (wave != 0u) return;
-    P_tab = sym_make(0u, lane, 0u); P_px = sym_make(0u, 64u, 0u);
-    sym_compose_range(&s_q[0][0], 4u, lane, P_tab, P_px);
-    p.grp_summary[(size_t)G * 65u + lane] = P_tab;
-    if (lane == 0) p.grp_summary[(size_t)G * 65u + 64u] = P_px;
-}
 // The per-image level for those calls as PREFIXES (round 6): dec_chain_state_l2m composed its shares, handed a summary from workgroup to
 // workgroup (flags, spins), applied 16 shares and swept its share - 59 dependent steps + waits, 19.5 us on a lone 4K frame.  Here a
 // wavefront composes its share and STORES the inclusive prefix after every step, the first wavefront does the same over the workgroup's 16
@@ -1095,8 +1074,28 @@ __device__ __forceinline__ void sym_compose_range_prefix(const sym_t* __restrict
         cur = nxt;
     }
 }
+// the same over words other workgroups of THIS launch have written (through to memory, complete before their arrival was counted): read past the caches
+__device__ __forceinline__ void sym_compose_range_prefix_coherent(const sym_t* rec, uint32_t count, uint32_t lane, sym_t& P_tab, sym_t& P_px, sym_t* out) {
+    for (uint32_t g = 0; g < count; g += 8u) {
+        sym_t t[8], x[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) {
+            const uint32_t k = min(g + i, count - 1u);
+            t[i] = granule_load(&rec[(size_t)k * 65u + lane]); x[i] = granule_load(&rec[(size_t)k * 65u + 64u]);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) {
+            if (g + i < count) {
+                sym_chain_step(t[i], uniform_sym(x[i]), P_tab, P_px);
+                granule_store(&out[(size_t)(g + i) * 65u + lane], P_tab);
+                if (lane == 0) granule_store(&out[(size_t)(g + i) * 65u + 64u], P_px);
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2p(DecParams p) {
     __shared__ sym_t s_sum[kL2Waves][65];
+    if (p.tr_scan && *p.sync_fails != 0u) return;
     const uint32_t img = blockIdx.x / kL2pWgs, k = blockIdx.x % kL2pWgs, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const DecImage im = p.images[img];
     if (im.start_seg >= im.n_active) return;
@@ -1116,7 +1115,63 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2p(DecParams p
     p.l2_sum[(size_t)(img * kL2pWgs + k) * 65u + lane] = P_tab;
     if (lane == 0) p.l2_sum[(size_t)(img * kL2pWgs + k) * 65u + 64u] = P_px;
 }
+__global__ __launch_bounds__(256) void dec_chain_state_l1q(DecParams p) {
+    __shared__ sym_t s_q[4][65];
+    if (p.tr_scan && *p.sync_fails != 0u) return;
+    const uint32_t G = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t img = find_image_by_group(p.images, p.n_images, G);
+    const DecImage im = p.images[img];
+    const uint32_t j0 = (G - im.grp_base) * kGrp;
+    if (j0 + kGrp <= im.start_seg || j0 >= im.n_active) return;
+    const uint32_t lo = max(j0, im.start_seg), hi = min(j0 + kGrp, im.n_active);
+    const uint32_t wlo = max(lo, j0 + 16u * wave), whi = min(hi, j0 + 16u * wave + 16u);
+    sym_t P_tab = sym_make(0u, lane, 0u), P_px = sym_make(0u, 64u, 0u);          // identity
+    sym_compose_range(p.summary + (size_t)(im.seg_base + wlo) * 65u, whi > wlo ? whi - wlo : 0u, lane, P_tab, P_px);
+    sym_t* const qs = p.qtr_summary + ((size_t)G * 4u + wave) * 65u;
+    qs[lane] = P_tab; s_q[wave][lane] = P_tab;
+    if (lane == 0) { qs[64] = P_px; s_q[wave][64] = P_px; }
+    __syncthreads();
+    if (wave != 0u) return;
+    P_tab = sym_make(0u, lane, 0u); P_px = sym_make(0u, 64u, 0u);
+    sym_compose_range(&s_q[0][0], 4u, lane, P_tab, P_px);
+    if (!p.s3_ctr) {
+        p.grp_summary[(size_t)G * 65u + lane] = P_tab;
+        if (lane == 0) p.grp_summary[(size_t)G * 65u + 64u] = P_px;
+        return;
+    }
+    // ---- the per-image level on this launch (round 6): what dec_chain_state_l2p does in a launch of its own (10 us on a lone 4K frame, half
+    // of it the launch).  The group's summary goes THROUGH to memory and is complete (vmcnt 0) before the group's arrival is counted; the
+    // last group of a share to arrive composes the share's inclusive prefixes from the words in memory, counts the share's arrival, and
+    // the last share of a workgroup's sixteen does the same one level up.  Nobody waits: whoever arrives last finds everything there.
+    granule_store(&p.grp_summary[(size_t)G * 65u + lane], P_tab);
+    if (lane == 0) granule_store(&p.grp_summary[(size_t)G * 65u + 64u], P_px);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t gfirst = im.start_seg / kGrp, gend = (im.n_active + kGrp - 1u) / kGrp, g = G - im.grp_base;
+    const uint32_t per = (gend - gfirst + kL2pWgs * kL2Waves - 1u) / (kL2pWgs * kL2Waves);
+    const uint32_t sh = (g - gfirst) / per, k = sh / kL2Waves;
+    const uint32_t slo = gfirst + sh * per, shi = min(slo + per, gend);                     // the share's groups
+    uint32_t* const ctr = p.s3_ctr + (size_t)(img * kL2pWgs + k) * (kL2Waves + 1u);            // [0..15] the shares of workgroup k, [16] the workgroup
+    uint32_t t = 0u;
+    if (lane == 0) t = atomicAdd(&ctr[sh % kL2Waves], 1u);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)t) + 1u != shi - slo) return;
+    P_tab = sym_make(0u, lane, 0u); P_px = sym_make(0u, 64u, 0u);
+    sym_compose_range_prefix_coherent(p.grp_summary + (size_t)(im.grp_base + slo) * 65u, shi - slo, lane, P_tab, P_px, p.grp_prefix + (size_t)(im.grp_base + slo) * 65u);
+    sym_t* const ss = p.share_sum + (size_t)((img * kL2pWgs + k) * kL2Waves) * 65u;
+    granule_store(&ss[(size_t)(sh % kL2Waves) * 65u + lane], P_tab);
+    if (lane == 0) granule_store(&ss[(size_t)(sh % kL2Waves) * 65u + 64u], P_px);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // shares of this workgroup that hold groups at all (the image's last workgroup may hold fewer than sixteen)
+    const uint32_t wlo_g = gfirst + k * kL2Waves * per;
+    const uint32_t nshares = wlo_g >= gend ? 0u : min((uint32_t)kL2Waves, (gend - wlo_g + per - 1u) / per);
+    if (lane == 0) t = atomicAdd(&ctr[kL2Waves], 1u);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)t) + 1u != nshares) return;
+    P_tab = sym_make(0u, lane, 0u); P_px = sym_make(0u, 64u, 0u);
+    sym_compose_range_prefix_coherent(ss, nshares, lane, P_tab, P_px, p.share_prefix + (size_t)((img * kL2pWgs + k) * kL2Waves) * 65u);
+    granule_store(&p.l2_sum[(size_t)(img * kL2pWgs + k) * 65u + lane], P_tab);
+    if (lane == 0) granule_store(&p.l2_sum[(size_t)(img * kL2pWgs + k) * 65u + 64u], P_px);
+}
 __global__ __launch_bounds__(256) void dec_chain_state_l3q(DecParams p) {
+    if (p.tr_scan && *p.sync_fails != 0u) return;
     const uint32_t G = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t img = find_image_by_group(p.images, p.n_images, G);
     const DecImage im = p.images[img];
@@ -1348,17 +1403,132 @@ struct LdsLutT { uint2 e[260]; };
 // from the entry phase S1 then knows.
 // MODE 1 - segments flagged by MODE 0 (all active ones if DecParams::sync_all), entry phase from S1.
 constexpr uint32_t kSyncBytes = 64;
+constexpr u64 kScanAgg = 1ull << 62, kScanIncl = 2ull << 62;
+// (Two ways of leaving the tail walk to dec_transcode<0> were built and measured, both a wash on a lone 4K frame: reading the lane's own
+// last rows back in its epilogue - 31.3 + 19.6 us became 38.2 + 13.5; keeping the transfer while walking (dec_transcode<0, TRACK>: four
+// vector instructions per record) - 32.4 + 19.8 became 38.5 + 13.8, profiles/r06_s12.  A wavefront that is alone on its SIMD issues one
+// instruction every ~8 cycles whatever depends on what: these kernels are bound by the instruction count of their longest wavefront, and
+// work moved from one to the other costs there what it saves here.)
+constexpr bool kTailsInTranscoder = false;
+constexpr uint32_t kScanPxCap = (1u << 29) - 1u;
+__device__ __forceinline__ uint32_t scan_sat(uint32_t a, uint32_t b) { const uint32_t s = sat_add(a, b); return s < kScanPxCap ? s : kScanPxCap; }
+__device__ __forceinline__ uint32_t slots_then(uint32_t a, uint32_t b) { return slot_pack(slot_compose(slot_unpack(a), slot_unpack(b))); }     // b after a, packed
+__device__ __forceinline__ u64 scan_word(const DecParams& p, u64 state, uint32_t px, uint32_t slots) {
+    const SlotRec r = slot_unpack(slots);
+    const uint32_t s17 = (uint32_t)r.hc | ((uint32_t)r.h_rel << 6) | ((uint32_t)r.h_alpha << 7) | ((uint32_t)r.a_abs << 8) | ((uint32_t)r.ac << 9);
+    return state | ((u64)(p.epoch & 0xFFFFu) << 46) | ((u64)s17 << 29) | (u64)(px < kScanPxCap ? px : kScanPxCap);
+}
+__device__ __forceinline__ uint32_t scan_word_slots(u64 w) {
+    const uint32_t s17 = (uint32_t)(w >> 29) & 0x1FFFFu;
+    SlotRec r; r.hc = s17 & 63u; r.h_rel = (s17 >> 6) & 1u; r.h_alpha = (s17 >> 7) & 1u; r.a_abs = (s17 >> 8) & 1u; r.ac = (s17 >> 9) & 0xFFu;
+    return slot_pack(r);
+}
+// both inclusive scans of dec_scan_entry in one loop (the two gathers of a round travel together)
+__device__ __forceinline__ void wave_scan_px_slots(uint32_t& px, uint32_t& sl, uint32_t lane) {
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up_p = gather_lane(px, lane - d), up_s = gather_lane(sl, lane - d);
+        if (lane >= d) { px = sat_add(up_p, px); sl = slot_pack(slot_compose(slot_unpack(up_s), slot_unpack(sl))); }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// dec_scan_entry's work as the EPILOGUE of dec_transcode<0, .., SPLIT, SCAN> (round 6, calls of a few images at 128-byte segments):
+// every lane - half a segment - walks the tail of the records it has just written (its own rows), the workgroup scans pixels and
+// slot / alpha transfers over its 256 halves, publishes, looks back over the workgroups in front of it (which took their tickets
+// before this one: they are running or done) and the even lanes leave px_off / slot_in / alpha_in of their segments.  One launch and
+// two dependent round trips fewer than with dec_scan_entry behind it (24.5 + 20.3 us on a lone 4K frame).
+// A call in which some segment did not synchronise is void as a whole: the kernels behind this one look at sync_fails and return.
+// ---------------------------------------------------------------------------------
+struct ScanShared { uint32_t wpx[4], wsl[4], epx, esl; };
+__device__ __forceinline__ void transcode_scan_tail(const DecParams& p, ScanShared& sh, uint32_t gb, uint32_t img, const DecImage& im, uint32_t q, uint32_t half,
+                                                    bool part, bool seg_even, uint32_t npix_half, uint32_t mine_half, uint32_t seg_pixels, uint32_t lane, uint32_t wave) {
+    const uint32_t per_blk = kTrThreads / 2u;                       // segments per workgroup
+    const uint32_t first_blk = im.seg_base / per_blk, blk = gb - first_blk;
+    const uint32_t j = q - im.seg_base;
+    if (blk == 0u && wave == 0u && im.nseg != 0u) {                // the decoder's start state (qoi.h:533-537) at the image's first segment
+        p.entry[(size_t)im.seg_base * 65u + lane] = 0u;
+        if (lane == 0) p.entry[(size_t)im.seg_base * 65u + 64u] = kInitPx;
+    }
+    uint32_t ipx = part ? npix_half : 0u, isl = part ? mine_half : kSlotIdentity;
+    wave_scan_px_slots(ipx, isl, lane);
+    if (lane == 63u) { sh.wpx[wave] = ipx; sh.wsl[wave] = isl; }
+    __syncthreads();
+    uint32_t wpx = 0u, wsl = kSlotIdentity, bpx = 0u, bsl = kSlotIdentity;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t a = sh.wpx[k], b = sh.wsl[k];
+        if (k < wave) { wpx = scan_sat(wpx, a); wsl = slots_then(wsl, b); }
+        bpx = scan_sat(bpx, a); bsl = slots_then(bsl, b);
+    }
+    if (wave == 0u) {
+        u64* const st = p.scan_status;
+        uint32_t epx = 0u, esl = kSlotIdentity;
+        if (blk != 0u) {
+            if (lane == 0) granule_store(&st[gb], scan_word(p, kScanAgg, bpx, bsl));
+            constexpr int kScanWin = 8;
+            uint32_t look = blk;
+            bool done = false;
+            while (!done) {
+                u64 w[kScanWin];
+#pragma unroll
+                for (int k = 0; k < kScanWin; ++k) {
+                    const int idx = (int)look - 64 * (k + 1) + (int)lane;
+                    w[k] = idx >= 0 ? granule_load(&st[first_blk + (uint32_t)idx]) : scan_word(p, kScanIncl, 0u, kSlotIdentity);
+                }
+#pragma unroll
+                for (int k = 0; k < kScanWin; ++k) {
+                    if (done) break;
+                    const bool ok = ((uint32_t)(w[k] >> 46) & 0xFFFFu) == (p.epoch & 0xFFFFu) && (w[k] >> 62) != 0ull;
+                    const u64 incl = lanes_where(ok && (w[k] >> 62) == 2ull);
+                    const int stop = incl ? 63 - (int)__builtin_clzll(incl) : 0;
+                    if (lanes_where(!ok && (int)lane >= stop) != 0ull) { __builtin_amdgcn_s_sleep(1); break; }
+                    const bool mine_w = (int)lane >= stop;
+                    uint32_t vpx = mine_w ? (uint32_t)w[k] & kScanPxCap : 0u, vsl = mine_w ? scan_word_slots(w[k]) : kSlotIdentity;
+                    wave_scan_px_slots(vpx, vsl, lane);
+                    epx = scan_sat(read_lane(vpx, 63), epx); esl = slots_then(read_lane(vsl, 63), esl);
+                    if (incl) done = true;
+                    else look -= 64u;
+                }
+            }
+        }
+        if (lane == 0) {
+            granule_store(&st[gb], scan_word(p, kScanIncl, scan_sat(epx, bpx), slots_then(esl, bsl)));
+            sh.epx = epx; sh.esl = esl;
+        }
+    }
+    __syncthreads();
+    const uint32_t epx = sh.epx, esl = sh.esl;
+    const uint32_t before = scan_sat(scan_sat(epx, wpx), from_lane_below(ipx, 0u));             // pixels in front of this half
+    const uint32_t my_off = min(before, im.npx);
+    uint32_t slot = hash_px(kInitPx), alpha = kInitPx >> 24;
+    slot_apply(slot_unpack(slots_then(slots_then(esl, wsl), from_lane_below(isl, kSlotIdentity))), slot, alpha);
+    if (seg_even) { p.px_off[q] = my_off; p.slot_in[q] = (uint8_t)slot; p.alpha_in[q] = (uint8_t)alpha; }
+    // n_active: the one segment that starts before the pixel limit while the segment behind it (if any) does not
+    const uint32_t next_off = scan_sat(before, seg_pixels);
+    if (seg_even && my_off < im.npx && (j + 1u >= im.nseg || next_off >= im.npx)) atomicMax(&p.images[img].n_active, j + 1u);
+    if (threadIdx.x == 0 && gb * per_blk + per_blk >= im.seg_base + im.nseg) p.images[img].total_px = min(scan_sat(epx, bpx), im.npx);     // the image's last workgroup
+}
+
 // TRACK (round 6 experiment, not instantiated by default - kTailsInTranscoder): the lane also keeps the slot / alpha transfer of its
 // segment as it goes (SlotRec: what the chunk that last named a slot absolutely left + the hash shifts behind it), four vector
 // instructions per record, so that dec_scan_entry needs no tail walk.  Measured: what the scan saves the transcoder pays (see there).
 // SPLIT (round 6, DecParams::tr_split): two lanes per segment, each walks half of it from a run-up of its own; the even lane writes
 // the segment's outputs (the odd lane's values come over by a lane shift).
-template <int MODE, bool TRACK = false, bool SPLIT = false>
+template <int MODE, bool TRACK = false, bool SPLIT = false, bool SCAN = false>
 __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     __shared__ uint32_t s_ring[QOIMI_TR_WAVES][TransReader::kSlots * 64];
     __shared__ LdsLutT s_lut;
+    __shared__ ScanShared s_scan;
+    __shared__ uint32_t s_gb;
+    static_assert(!SCAN || (SPLIT && MODE == 0), "the scan rides on the two-lane form of the first transcoder pass");
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (MODE == 1 && !p.sync_all && *p.sync_fails == 0u) return;
+    if (SCAN) {
+        // the workgroup's place in the call by ticket (start order: what its look-back waits for has started); the answer travels while the table is built
+        if (threadIdx.x == 0) s_gb = atomicAdd(p.scan_ticket, 1u);
+        if (blockIdx.x == 0u && threadIdx.x < p.n_images) p.first_bad[threadIdx.x] = 0xFFFFFFFFu;
+    }
     for (uint32_t b = threadIdx.x; b < 256u; b += kTrThreads) {
         uint32_t d, i; lut_entry(b, d, i);
         // the transcoder's own info word: bits 0..2 chunk length (0 for QOI_OP_RGBA: visited twice), bits 8..15 all ones for
@@ -1369,21 +1539,23 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     }
     if (threadIdx.x < 4u) s_lut.e[256u + threadIdx.x] = make_uint2(0u, 0u);
     __syncthreads();
-    const uint32_t T = blockIdx.x * kTrThreads + threadIdx.x;
+    const uint32_t gb = SCAN ? s_gb : blockIdx.x;          // (s_gb: written before the barrier above)
+    const uint32_t T = gb * kTrThreads + threadIdx.x;
     const uint32_t q = SPLIT ? T >> 1 : T, half = SPLIT ? T & 1u : 0u;
     bool have = q < p.total_segs;
     uint32_t img;
     DecImage im;
+    const uint32_t q_img = SCAN ? gb * (kTrThreads / 2u) : (have ? q : 0u);      // SCAN: one image per workgroup (every image begins on a multiple of 256 segments), the same for every lane
     if (MODE == 0 && p.tab_in_args) {
         // the table travels in the kernel arguments (calls of a few images): this launch reads it from there, its first lanes leave the
         // device copy for the kernels that follow
-        const uint32_t qq = have ? q : 0u;
+        const uint32_t qq = q_img;
         img = (p.n_images > 1u && qq >= p.tab4[1].seg_base ? 1u : 0u) + (p.n_images > 2u && qq >= p.tab4[2].seg_base ? 1u : 0u) + (p.n_images > 3u && qq >= p.tab4[3].seg_base ? 1u : 0u);
         im = img == 0u ? p.tab4[0] : img == 1u ? p.tab4[1] : img == 2u ? p.tab4[2] : p.tab4[3];
         if (blockIdx.x == 0u && threadIdx.x < p.n_images)
             p.images[threadIdx.x] = threadIdx.x == 0u ? p.tab4[0] : threadIdx.x == 1u ? p.tab4[1] : threadIdx.x == 2u ? p.tab4[2] : p.tab4[3];
     } else {
-        img = find_image(p.images, p.n_images, have ? q : 0u);
+        img = find_image(p.images, p.n_images, q_img);
         im = p.images[img];
     }
     const uint32_t j = (have ? q : im.seg_base) - im.seg_base;
@@ -1396,7 +1568,10 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     const uint32_t hbytes = SPLIT ? p.seg_bytes >> 1 : p.seg_bytes;
     const uint32_t base = sbase + half * hbytes;                            // this lane's part of it
     if (SPLIT && have && base >= im.chunks_end) have = false;              // the stream ends in the segment's first half (the even lane always has bytes: j < nseg)
-    if (!lanes_where(have)) return;
+    if (!lanes_where(have)) {
+        if (SCAN) transcode_scan_tail(p, s_scan, gb, img, im, q, half, false, false, 0u, kSlotIdentity, 0u, lane, wave);      // (the workgroup's barriers are met by every wavefront)
+        return;
+    }
     const uint32_t end = min(base + hbytes, im.chunks_end);
     const uint32_t lut_base = lds_addr_of(&s_lut.e[0]);
     PipeReaderT<MODE == 0> R;                 // MODE 0: requests through a descriptor; MODE 1 (rare): plain pointers, reaches anything
@@ -1488,7 +1663,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     uint32_t npix = 0u;
     // granule row g of this wavefront's 64 segments: one contiguous KiB.  Stored through a descriptor over the block's rows with a
     // 32-bit offset that moves on by a row per granule (the 64-bit address of every store was four vector instructions)
-    const uint32_t rec_blk = SPLIT ? (blockIdx.x * kTrThreads + wave * 64u) >> 7 : blockIdx.x * QOIMI_TR_WAVES + wave;      // the block of 64 segments the wavefront's segments lie in
+    const uint32_t rec_blk = SPLIT ? (gb * kTrThreads + wave * 64u) >> 7 : gb * QOIMI_TR_WAVES + wave;      // the block of 64 segments the wavefront's segments lie in
     const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)(p.recs + (size_t)rec_blk * p.rec_rows * 256u), 0,
                                                                              (int)(p.rec_rows * 1024u), 0x00020000);
     const uint32_t roff0 = (SPLIT ? (q & 63u) : lane) * 16u + (SPLIT ? half * p.tr_rows_half * 1024u : 0u);
@@ -1574,6 +1749,29 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     }
     pos = rp + R.aoff;
     uint32_t gran_word = (roff - roff0) >> 10;                          // granules written
+    const bool part = have && !failed;                                  // this lane walked its half
+    const uint32_t npix_half = npix;
+    uint32_t mine_half = kSlotIdentity;
+    if (SCAN) {
+        // the half's slot / alpha transfer from the tail of its own rows (tail_step; the rows are this lane's stores, acknowledged: vmcnt 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t n_rows = part ? gran_word : 0u;
+        TailState t; tail_init(t);
+        t.found = n_rows != 0u ? 0u : 1u;
+        uint32_t most = n_rows;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)most, o); most = v > most ? v : most; }
+        for (uint32_t i = 0; i < most && lanes_where(t.found == 0u) != 0; i += 4u) {
+            u32x4 v[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, i + k < n_rows ? roff0 + 1024u * (n_rows - 1u - i - k) : 0x7FFFFFF0u, 0, 0);
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+                if (i + k < n_rows) { tail_step(t, v[k].w, a_abs, a_last); tail_step(t, v[k].z, a_abs, a_last); tail_step(t, v[k].y, a_abs, a_last); tail_step(t, v[k].x, a_abs, a_last); }
+        }
+        if (n_rows == 0u) t.found = 0u;
+        if (part) mine_half = slot_pack(tail_finish(t, a_abs, a_last));
+    }
     if (SPLIT) {
         // the odd lane's half over to the even lane, which writes the segment's outputs (a lane that took no part holds nothing: no
         // granules, no pixels, no QOI_OP_RGBA, and `pos` is not looked at)
@@ -1605,6 +1803,7 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     } else if (have && MODE == 0) {
         p.rec_gran[q] = 0u;
     }
+    if (SCAN) transcode_scan_tail(p, s_scan, gb, img, im, q, half, part, have, npix_half, mine_half, npix, lane, wave);      // (have: now the even lane of a segment that exists)
 }
 
 // Record source of a P3 / P4 wavefront: lane l reads the granules of segment 64 * block + l through a raw buffer descriptor
@@ -1697,34 +1896,6 @@ __global__ __launch_bounds__(64) void dec_slot_tails(DecParams p) {
 // kernel returns at once, the host sees the counter behind the round and continues with the five-phase parse and the three-level chains.
 //   word: bits 0..28 pixels (saturating at 2^29 - 1 > QOI_PIXELS_MAX), 29..45 slot transfer, 46..61 tag, 62..63 state
 // ---------------------------------------------------------------------------------
-constexpr u64 kScanAgg = 1ull << 62, kScanIncl = 2ull << 62;
-// (Two ways of leaving the tail walk to dec_transcode<0> were built and measured, both a wash on a lone 4K frame: reading the lane's own
-// last rows back in its epilogue - 31.3 + 19.6 us became 38.2 + 13.5; keeping the transfer while walking (dec_transcode<0, TRACK>: four
-// vector instructions per record) - 32.4 + 19.8 became 38.5 + 13.8, profiles/r06_s12.  A wavefront that is alone on its SIMD issues one
-// instruction every ~8 cycles whatever depends on what: these kernels are bound by the instruction count of their longest wavefront, and
-// work moved from one to the other costs there what it saves here.)
-constexpr bool kTailsInTranscoder = false;
-constexpr uint32_t kScanPxCap = (1u << 29) - 1u;
-__device__ __forceinline__ uint32_t scan_sat(uint32_t a, uint32_t b) { const uint32_t s = sat_add(a, b); return s < kScanPxCap ? s : kScanPxCap; }
-__device__ __forceinline__ uint32_t slots_then(uint32_t a, uint32_t b) { return slot_pack(slot_compose(slot_unpack(a), slot_unpack(b))); }     // b after a, packed
-__device__ __forceinline__ u64 scan_word(const DecParams& p, u64 state, uint32_t px, uint32_t slots) {
-    const SlotRec r = slot_unpack(slots);
-    const uint32_t s17 = (uint32_t)r.hc | ((uint32_t)r.h_rel << 6) | ((uint32_t)r.h_alpha << 7) | ((uint32_t)r.a_abs << 8) | ((uint32_t)r.ac << 9);
-    return state | ((u64)(p.epoch & 0xFFFFu) << 46) | ((u64)s17 << 29) | (u64)(px < kScanPxCap ? px : kScanPxCap);
-}
-__device__ __forceinline__ uint32_t scan_word_slots(u64 w) {
-    const uint32_t s17 = (uint32_t)(w >> 29) & 0x1FFFFu;
-    SlotRec r; r.hc = s17 & 63u; r.h_rel = (s17 >> 6) & 1u; r.h_alpha = (s17 >> 7) & 1u; r.a_abs = (s17 >> 8) & 1u; r.ac = (s17 >> 9) & 0xFFu;
-    return slot_pack(r);
-}
-// both inclusive scans of dec_scan_entry in one loop (the two gathers of a round travel together)
-__device__ __forceinline__ void wave_scan_px_slots(uint32_t& px, uint32_t& sl, uint32_t lane) {
-#pragma unroll
-    for (uint32_t d = 1; d < 64u; d <<= 1) {
-        const uint32_t up_p = gather_lane(px, lane - d), up_s = gather_lane(sl, lane - d);
-        if (lane >= d) { px = sat_add(up_p, px); sl = slot_pack(slot_compose(slot_unpack(up_s), slot_unpack(sl))); }
-    }
-}
 __global__ __launch_bounds__(kScanSegs) void dec_scan_entry(DecParams p) {
     __shared__ uint32_t s_wpx[4], s_wsl[4], s_epx, s_esl, s_blk;
     const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1895,6 +2066,9 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     __shared__ uint8_t s_hint[REFINE ? 65 * 64 : 4];
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     const uint32_t lane = lane_id();
+    if (p.tr_scan && *p.sync_fails != 0u) return;          // (a call whose first pass could not synchronise every segment is void up to here: the host takes the chains)
+    if (p.s3_ctr && blockIdx.x == 0u)                      // the arrival counters of the state chain that follows this launch (dec_chain_state_l1q)
+        for (uint32_t i = lane; i < p.n_images * kL2pWgs * (kL2Waves + 1u); i += 64u) p.s3_ctr[i] = 0u;
     const uint32_t q = blockIdx.x * 64u + lane;
     bool have = q < p.total_segs;
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
@@ -2270,6 +2444,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     uint32_t* const s_tab = s_mem;
     uint32_t* const s_out = s_mem + kTabDw;
     const uint32_t lane = lane_id();
+    if (p.tr_scan && *p.sync_fails != 0u) return;
     if (QOIMI_SEGREC_PAD_DW && p.total_segs == 0xFFFFFFFFu) s_mem[kTabDw + kOutDw + lane] = 0u;     // keeps the padding (occupancy experiments)
     const uint32_t q = blockIdx.x * 64u + lane;
     bool have = q < p.total_segs;
@@ -2695,6 +2870,11 @@ void launch_decode_parse(const DecParams& p, hipStream_t st, KernelTimer* tm) {
 // Calls of a few images (DecParams::fused): dec_transcode<0>, then everything P3 needs from ONE kernel (dec_scan_entry)
 void launch_decode_fused_front(const DecParams& p, hipStream_t st, KernelTimer* tm) {
     tm->mark(kT_begin, st);
+    if (p.tr_scan) {                          // ... and the scan on the same launch
+        hipLaunchKernelGGL((dec_transcode<0, false, true, true>), dim3((2u * p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
+        tm->mark(kT_dec_slot_walk, st);
+        return;
+    }
     if (p.tr_split) hipLaunchKernelGGL((dec_transcode<0, kTailsInTranscoder, true>), dim3((2u * p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
     else hipLaunchKernelGGL((dec_transcode<0, kTailsInTranscoder>), dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
     tm->mark(kT_dec_slot_walk, st);
@@ -2721,7 +2901,8 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
     auto chain_state = [&]() {
         if (p.qtr_summary) hipLaunchKernelGGL(dec_chain_state_l1q, dim3(p.total_grps), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
-        if (p.grp_prefix) hipLaunchKernelGGL(dec_chain_state_l2p, dim3(p.n_images * kL2pWgs), dim3(64 * kL2Waves), 0, st, p);
+        if (p.grp_prefix && p.s3_ctr) { }                        // (the per-image level rode on dec_chain_state_l1q's launch)
+        else if (p.grp_prefix) hipLaunchKernelGGL(dec_chain_state_l2p, dim3(p.n_images * kL2pWgs), dim3(64 * kL2Waves), 0, st, p);
         else if (p.l2_wgs > 1u) hipLaunchKernelGGL(dec_chain_state_l2m, dim3(p.n_images * p.l2_wgs), dim3(64 * kL2Waves), 0, st, p, p.l2_tag_base + l2_seq++);
         else hipLaunchKernelGGL(dec_chain_state_l2, dim3(p.n_images), dim3(64 * kL2Waves), 0, st, p);
         if (p.qtr_summary) hipLaunchKernelGGL(dec_chain_state_l3q, dim3(p.total_grps), dim3(256), 0, st, p);

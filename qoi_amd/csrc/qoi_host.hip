@@ -119,6 +119,10 @@ struct qoimi_ctx {
     bool dropin = false;                // the context of a thread's qoi_encode / qoi_decode calls (thread_ctx)
     int enc_tree_ticket = -1;           // -1: 1 for qoimi_encode_batch, 0 inside the drop-in qoi_encode.  1: tree placement hands its units out by one ticket per workgroup (start order: no assumption about the dispatcher); 0 (QOIMI_ENC_TREE_TICKET=0,
                                         // and always inside the drop-in qoi_encode, which encodes again by itself): by workgroup index, 4 us less per 4K frame
+    int dec_tr_scan = 0;                // env QOIMI_DEC_TR_SCAN=1 (experiment, measured SLOWER: 46.6 us against 24.5 + 20.3 on a lone 4K frame, profiles/r06_s15): dec_scan_entry's
+                                        // work as the epilogue of the two-lane transcoder instead of a launch of its own
+    int dec_s3_ride = 0;                // env QOIMI_DEC_S3_RIDE=1 (experiment, measured: 21.6 -> 20.7 us for the two levels on a lone 4K frame, profiles/r06_s14): the per-image
+                                        // level of the state chain rides on the group level's launch (last arrivers) instead of dec_chain_state_l2p's own launch
     int dec_split = 1;                  // env QOIMI_DEC_SPLIT=0: one transcoder lane per segment in those calls too
     int dec_fused = 1;                  // env QOIMI_DEC_FUSED=0: calls of a few images take the three-level chains of the batch path instead of the single-pass look-back kernels
     uint32_t test_spin_bound = 0;       // env QOIMI_TEST_SPIN_BOUND (tests): polls before a placement wait gives up
@@ -234,7 +238,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         if (const char* e = getenv("QOIMI_DEC_INNER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner = v; }
         if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
         knob("QOIMI_DEC_L2M", c->dec_l2_wgs); knob("QOIMI_DEC_RUN_DESC", c->dec_run_desc); knob("QOIMI_DEC_FLAT_SEG", c->dec_flat_seg);
-        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split);
+        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split); knob("QOIMI_DEC_S3_RIDE", c->dec_s3_ride); knob("QOIMI_DEC_TR_SCAN", c->dec_tr_scan);
         if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
         if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
         if (const char* e = getenv("QOIMI_SEG_BYTES")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v; }
@@ -847,6 +851,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.rec_rows = rec_rows_of(B);
     if (fused && B == 128u && c->dec_split) {          // two transcoder lanes per segment (dec_transcode<0, .., SPLIT>): rows for two halves
         p.tr_split = 1u; p.tr_rows_half = rec_rows_of(B / 2u); p.rec_rows = 2u * p.tr_rows_half;
+        p.tr_scan = c->dec_tr_scan ? 1u : 0u;
     }
     p.flat_segs = (uint32_t)flat_total;
     p.desc_cap = (p.tr_split ? 2u * rec_max_records(B / 2u) : rec_max_records(B)) / 2u + 2u;              // a run ends with the record behind it: every second record at most
@@ -898,7 +903,9 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.qtr_summary = w.take<u64>(few ? NG * 4u * 65u : 0);
         p.grp_prefix = w.take<u64>(few ? NG * 65u : 0); p.share_prefix = w.take<u64>(few ? (size_t)n_images * 8u * 16u * 65u : 0);
         if (few && p.l2_wgs < 8u) p.l2_sum = w.take<u64>((size_t)n_images * 8u * 65u);                  // (l2_sum above was sized for l2_wgs workgroups)
-        if (!few) { p.qtr_summary = nullptr; p.grp_prefix = nullptr; p.share_prefix = nullptr; }
+        p.s3_ctr = w.take<uint32_t>(few ? (size_t)n_images * 8u * 17u : 0); p.share_sum = w.take<u64>(few ? (size_t)n_images * 8u * 16u * 65u : 0);
+        if (!few || !c->dec_s3_ride) { p.s3_ctr = nullptr; }
+        if (!few) { p.qtr_summary = nullptr; p.grp_prefix = nullptr; p.share_prefix = nullptr; p.share_sum = nullptr; }
         p.rec_gran = w.take<uint32_t>(Q);
         p.run_cnt = w.take<uint32_t>((flat_total || p.desc_all) ? Q : 0);
         p.run_queue = w.take<uint32_t>((flat_total || p.desc_all) ? Q : 0);
@@ -908,9 +915,9 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         if (!pass) { int rc = c->dec_ws.reserve(w.off + 256); if (rc) return rc; }
     }
     if (fused) {
-        const size_t words = (size_t)(total / kScanSegs) + 64u;
+        const size_t words = (size_t)(total / (kScanSegs / 2u)) + 64u;      // (a word per 128 segments where the scan rides on the two-lane transcoder)
         const unsigned gen = c->dec_scan.gen;
-        if (c->dec_scan.reserve(words * sizeof(u64)) != QOIMI_OK) { fused = false; p.tr_split = 0u; }          // (no memory for a few KB: the chains will do)
+        if (c->dec_scan.reserve(words * sizeof(u64)) != QOIMI_OK) { fused = false; p.tr_split = 0u; p.tr_scan = 0u; }          // (no memory for a few KB: the chains will do)
         else {
             c->dec_epoch = (c->dec_epoch + 1u) & 0xFFFFu;
             if (gen != c->dec_scan.gen || c->dec_epoch == 0u) {                           // a new arena, or the tag wraps: no word may carry a tag from before
@@ -991,12 +998,12 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
             // dec_transcode<0> could not synchronise every segment (runs of equally long multi-byte chunks: noise): dec_scan_entry and
             // everything behind it returned at once.  The five-phase parse, the three-level chains and the round again, on the records
             // that stand (the flagged segments are transcoded by dec_transcode<1>).
-            p.fused = 0u; fused = false;
+            p.fused = 0u; fused = false; p.tr_scan = 0u;         // (tr_scan off: the kernels of the chains must not return on sync_fails)
             rounds = 0;
             launch_decode_parse_rest(p, st, &c->timer);
             continue;
         }
-        p.fused = 0u;                                       // (rounds after a failed check are the three-level ones, from the image's first bad segment)
+        p.fused = 0u; p.tr_scan = 0u;                       // (rounds after a failed check are the three-level ones, from the image's first bad segment)
         if (c->host_word[0] == 0) break;
         {
             const uint32_t open_now = c->host_word[1] - redo_cum;

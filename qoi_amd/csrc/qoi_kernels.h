@@ -224,6 +224,11 @@ struct DecParams {
     // rec_gran = n0 | n1 << 16 (a segment dec_transcode<1> wrote: n1 = 0) - RecSource maps a granule number to its row.
     uint32_t  tr_split;        // 1: that form
     uint32_t  tr_rows_half;    // rows reserved per half
+    uint32_t  tr_scan;         // 1: dec_scan_entry's work rides on that launch too (transcode_scan_tail); the kernels behind it return where sync_fails != 0
+    uint32_t* s3_ctr;          // [n_images * 8 * 17] arrival counters of dec_chain_state_l1q (round 6): the LAST group of a share to arrive composes the share's
+                               // prefixes, the last share of a workgroup's sixteen the share prefixes - the per-image level rides on the group level's
+                               // launch (no dec_chain_state_l2p launch); zeroed by the dec_summarize_rec launch in front of every chain; nullptr: l2p
+    u64*      share_sum;       // [n_images * 8 * 16][65] the shares' summaries (written through, read by the last arriver)
     uint32_t  tail_fused;      // 1: that form
     uint32_t* host_result;     // pinned host words: [0] pending, [1] redo_segs, [2] sync_fails, [3] 1: some image is still being filled, [4] the call's number (written last)
 };

@@ -496,6 +496,11 @@ def test_16k_frame_stream_is_the_reference_stream(api, ctx, ref):
     {"QOIMI_DEC_FUSED": "0", "QOIMI_SEG_BYTES": "128"},
     {"QOIMI_SEG_BYTES": "128"},                           # the single-pass look-back at the lone frame's segment size (the noise image makes the call fall back to the chains)
     {"QOIMI_SEG_BYTES": "1024"},
+    {"QOIMI_DEC_SPLIT": "0", "QOIMI_SEG_BYTES": "128"},   # one transcoder lane per segment (default for 128-byte segments of small calls: two)
+    {"QOIMI_DEC_S3_RIDE": "1", "QOIMI_SEG_BYTES": "128"},  # experiment: the per-image level of the state chain on the group level's launch (last arrivers)
+    {"QOIMI_DEC_S3_RIDE": "1"},
+    {"QOIMI_DEC_TR_SCAN": "1", "QOIMI_SEG_BYTES": "128"},  # experiment: dec_scan_entry's work as the epilogue of the two-lane transcoder
+    {"QOIMI_DEC_TR_SCAN": "1"},
 ])
 def test_selectable_paths(api, oracle, env):
     """Every selectable kernel path gives the same bytes / pixels (mixed batch: photo, noise, uiflat, constant)."""

@@ -49,7 +49,7 @@ def test_encoder_hot_kernel_keeps_six_wavefronts_per_simd(kernels, ch, entry):
 
 
 def test_decoder_passes_keep_their_workgroups_per_cu(kernels):
-    tr = _one(kernels, "dec_transcodeILi0ELb0ELb0EE")
+    tr = _one(kernels, "dec_transcodeILi0ELb0ELb0ELb0EE")
     assert tr["vgpr"] <= 80 and 4 * tr["lds"] <= LDS_PER_CU, tr        # four workgroups of four wavefronts
     p3 = _one(kernels, "dec_summarize_recILb0E")
     assert 8 * p3["lds"] <= LDS_PER_CU and p3["vgpr"] <= 128, p3       # eight wavefronts (one per workgroup) per CU
