@@ -19,6 +19,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("QOIMI_TUNING", "1")      # the placement / segment-size knobs below are looked at only under it (qoi_host.hip)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
