@@ -166,8 +166,11 @@ long long qoimi_encode_retries(qoimi_ctx *ctx);
  *                  share the output channel count (channels, or their headers' when it is 0)
  *   channels       0, 3 or 4 — as qoi.h:289
  *   d_pixels       image i is written at d_pixels + i*pixel_stride
- * Synchronous with respect to `stream` (the exactness check of the speculative decoder
- * is read back before returning). */
+ * Synchronous: returns when every pixel is written and verified (the exactness check of the speculative decoder is read
+ * before returning).  For calls of a few images the call returns on result words its last launch writes to pinned memory
+ * when everything in front of it is done; that launch itself - it writes nothing a caller can see - may still be retiring on
+ * `stream` for a few microseconds.  Work the caller enqueues on `stream` is ordered behind it; the context's next call waits
+ * for it by itself if it comes on another stream. */
 int qoimi_decode_batch(qoimi_ctx *ctx, const void *d_streams, size_t stream_stride,
                        const int *sizes, const qoi_desc *descs, int n_images, int channels,
                        void *d_pixels, size_t pixel_stride, void *stream);

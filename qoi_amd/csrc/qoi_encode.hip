@@ -1650,8 +1650,8 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     // grid of the passes that usually have nothing to do: they return at once then (a few microseconds for 2048 workgroups).  When
     // there IS work - flat content - a grid-stride loop over few long-lived workgroups is the slow way to run enc_sets (a persistent
     // grid costs it 20 %, profiles/r04_s1_enc_knobs.txt): large calls get 1/32 of the full grid (256 flat 4K frames: 8.5 -> 7.3 ms;
-    // 1/8: 7.0 ms, but its empty launches cost the photographs 0.7 %; 1/32: 0.2 %).  QOIMI_ENC_GEN_GRID_DIV sets the divisor.
-    static const uint32_t gen_div = [] { const char* e = getenv("QOIMI_ENC_GEN_GRID_DIV"); const int v = e ? atoi(e) : 32; return (uint32_t)(v >= 1 ? v : 32); }();
+    // 1/8: 7.0 ms, but its empty launches cost the photographs 0.7 %; 1/32: 0.2 %).
+    const uint32_t gen_div = p.gen_small_div ? p.gen_small_div : 32u;            // (QOIMI_ENC_GEN_GRID_DIV, under QOIMI_TUNING: qoimi_ctx_create)
     uint32_t small = 2048u;
     { const uint32_t big = (p.n_units > slab_blocks ? p.n_units : slab_blocks) / gen_div; if (big > small) small = big; }
     tm->mark(kT_begin, st);

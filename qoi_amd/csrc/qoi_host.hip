@@ -96,7 +96,8 @@ struct qoimi_ctx {
     Arena enc_ws, dec_ws;       // kernel workspaces
     Arena dec_scan;             // look-back words of dec_scan_entry (calls of a few images): tagged with dec_epoch, zeroed when allocated / when the tag wraps
     uint32_t dec_epoch = 0;     // number of the last such call (16 bits are compared)
-    struct { void* at = nullptr; unsigned gen = 0; bool valid = false; } dec_hdr_zero;   // the counter header the last decode call's dec_fill left zeroed (arena base + generation)
+    struct { void* at = nullptr; unsigned gen = 0; bool valid = false; } dec_hdr_zero;
+    void* dec_tail_stream = nullptr; bool dec_tail_open = false;   // a decode call returned on its pinned result words while its last launch was still retiring on this stream   // the counter header the last decode call's dec_fill left zeroed (arena base + generation)
     Arena io_a, io_b, io_c;     // staging for the host-pointer (drop-in) path
     uint32_t* host_word = nullptr;   // pinned words for read-backs
     hipStream_t own_stream = nullptr; // private non-blocking stream: self-test at creation, the drop-in entry points' work
@@ -131,6 +132,7 @@ struct qoimi_ctx {
     int enc_gen_slabs = 0;              // env QOIMI_ENC_GEN_SLABS (1..16): slabs per set of the pass over flagged images; 0: kEncGenSetSlabs, twice that for
                                         // calls of 3 x 65536 slabs and more (8 / 12 / 16 slabs, 1024 frames: constant 7.69 / 7.34 / 6.75 ms, uiflat 20.62 / 20.49 / 20.34,
                                         // 512 sprites 8.86 / 8.70 / 8.76 - profiles/r05_s22_enc_gen_slabs16.txt; a single frame has too few sets for that)
+    int enc_gen_small_div = 0;          // env QOIMI_ENC_GEN_GRID_DIV (0: 32)
     int enc_gen_grid_div = 1;           // (32 / 4 / 1: uiflat 21.3 / 21.2 / 20.4 ms, sprite_alpha 11.0 / 11.1 / 10.1 per 512, profiles/r05_s14_enc_grid.txt) env QOIMI_ENC_GEN_GRID_HOT: the pass over flagged images runs with 1/N of its units when the previous batch held flagged images
     int enc_uni = -1;                   // one encode pass, sets whose look-back window does not do take the state look-back one by one.  -1: for calls of a few
                                         // images (tree placement) behind a call that met flat stretches (host_word[14]); env QOIMI_ENC_UNI=1 always / 0 never
@@ -231,6 +233,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         flag("QOIMI_ENC_SPREAD", c->enc_spread); flag("QOIMI_ENC_TREE_TICKET", c->enc_tree_ticket); flag("QOIMI_ENC_ADAPT", c->enc_adapt);
         flag("QOIMI_ENC_G2", c->enc_g2); flag("QOIMI_ENC_ALL_G2", c->enc_all_g2); flag("QOIMI_ENC_PREZERO", c->enc_prezero); flag("QOIMI_ENC_UNI", c->enc_uni);
         flag("QOIMI_ENC_PIPE", c->enc_pipe);
+        if (const char* e = getenv("QOIMI_ENC_GEN_GRID_DIV")) { const int v = atoi(e); if (v >= 1) c->enc_gen_small_div = v; }
         if (const char* e = getenv("QOIMI_ENC_GEN_GRID_HOT")) { const int v = atoi(e); if (v >= 1) c->enc_gen_grid_div = v; }
         if (const char* e = getenv("QOIMI_ENC_GEN_SLABS")) { const int v = atoi(e); if (v >= 1 && v <= (int)kEncMaxSetSlabs) c->enc_gen_slabs = v; }
         if (const char* e = getenv("QOIMI_ENC_PERSIST")) { const int v = atoi(e); if (v >= 0) c->enc_persist = v; }
@@ -468,6 +471,7 @@ extern "C" int qoimi_encode_batch(qoimi_ctx* c, const void* d_pixels, size_t pix
     p.pool = lookback ? 1 : 0;
     p.gen_slabs = c->enc_gen_slabs > 0 ? (uint32_t)c->enc_gen_slabs : ((size_t)n_images * p.spi >= 3u * 65536u ? 2u * kEncGenSetSlabs : kEncGenSetSlabs);
     p.gen_grid_div = (c->enc_adapt && n_images >= 8 && c->host_word[13] != 0u) ? (uint32_t)c->enc_gen_grid_div : 0u;
+    p.gen_small_div = (uint32_t)c->enc_gen_small_div;
     // The previous batch held flagged images ONLY (flat content: host_word[13] counts them): this call's first pass will most likely find
     // an image's first flat stretch within microseconds and every other set of the image has nothing to do but to see the flag - one
     // workgroup per four sets is 345 000 workgroups that start and end for 512 4K frames, 0.5 ms of dispatch.  A sixteenth of them, each
@@ -842,6 +846,10 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     if (total > 0xFFFFFFF0ull) return fail(QOIMI_E_ARG, "batch too large (segment index overflows 32 bits)");
     DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
+    // The previous call of this context may have returned on its pinned result words while its dec_fill was still retiring (it zeroes the
+    // counter header last).  On the same stream this call's work is ordered behind it; a caller that changes streams gets the wait here.
+    if (c->dec_tail_open && c->dec_tail_stream != stream) HIP_TRY(hipStreamSynchronize((hipStream_t)c->dec_tail_stream));
+    c->dec_tail_open = false;
 
     DecParams p;
     memset(&p, 0, sizeof p);
@@ -986,6 +994,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
                 }
             }
             if (!seen || hw[23] != 0u) HIP_TRY(hipStreamSynchronize(st));
+            else { c->dec_tail_open = true; c->dec_tail_stream = stream; }
             c->host_word[0] = c->host_word[20]; c->host_word[1] = c->host_word[21]; c->host_word[2] = c->host_word[22];
             // (that dec_fill left the header zeroed; good for the next call if nothing else of this call touches it: no further round)
             c->dec_hdr_zero.at = (void*)p.pending; c->dec_hdr_zero.gen = c->dec_ws.gen; c->dec_hdr_zero.valid = c->host_word[0] == 0u && c->host_word[2] == 0u;

@@ -74,6 +74,7 @@ struct EncParams {
     uint32_t n_units;        // set by the launcher: (image, four consecutive sets) work units
     uint32_t spread;         // 1 (default): the wavefronts of a workgroup serve consecutive images (env QOIMI_ENC_SPREAD=0: all four take tickets of one image)
     uint32_t gen_grid_div;   // 0: the pass over flagged images runs with the small grid; N: with 1/N of its units (the previous batch of the context held flagged images)
+    uint32_t gen_small_div;  // 0 (= 32): the passes that usually find nothing run with 1/N of the full grid, 2048 workgroups at least (env QOIMI_ENC_GEN_GRID_DIV under QOIMI_TUNING)
     uint32_t gen_slabs;      // slabs per set of the pass over flagged images (kEncGenSetSlabs; env QOIMI_ENC_GEN_SLABS)
     uint32_t spin_bound;     // polls a placement wait makes before it gives up (err bit 0): 2^22 with tickets (start order), 2^15 for the tree by workgroup index
     uint32_t uni;            // 1 (env QOIMI_ENC_UNI=1, or a small call behind one that held flat stretches): one pass (enc_sets<ENTRY 3>) - sets whose look-back window does not do take the state look-back themselves; g2_rec holds a record per set of the FIRST pass

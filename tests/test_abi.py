@@ -54,6 +54,15 @@ def test_environment_knobs_are_gated(lib):
     if os.path.exists(test):
         assert b"QOIMI_TEST_SPIN_BOUND" in open(test, "rb").read()
     assert "QOIMI_LIB" not in open(os.path.join(ROOT, "qoi_amd", "api.py")).read()
+    # ... and no kernel file asks the environment anything; the host shim asks for three documented settings, QOIMI_TUNING, and - inside
+    # the gate or the test-hook block - the knobs
+    for f in ("qoi_encode.hip", "qoi_decode.hip", "qoi_synth.hip"):
+        assert "getenv" not in open(os.path.join(ROOT, "qoi_amd", "csrc", f)).read(), f
+    host = open(os.path.join(ROOT, "qoi_amd", "csrc", "qoi_host.hip")).read()
+    gate = host.index('getenv("QOIMI_TUNING")')
+    outside = [m for m in re.findall(r'getenv\("(QOIMI_[A-Z0-9_]+)"\)', host[:gate])]
+    assert sorted(outside) == ["QOIMI_ENCODE_TIGHT_BUFFER", "QOIMI_ENC_PROBE"], outside
+    assert re.findall(r'getenv\("(QOIMI_[A-Z0-9_]+)"\)', host[host.index("static qoimi_ctx* thread_ctx()"):]) == ["QOIMI_DEVICE"]
 
 
 def test_desc_layout():

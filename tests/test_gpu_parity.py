@@ -589,6 +589,35 @@ def test_small_calls_single_pass_lookback(api, oracle, seg, fused):
     c.close()
 
 
+def test_small_calls_on_alternating_streams(api, oracle):
+    """A call of a few images returns on the result words its last launch writes to pinned memory; that launch (it zeroes the counter
+    header for the context's next call) may still be retiring.  One context, calls in turn on two streams and on the default stream, no
+    waits in between on the caller's side, photographs and noise (the noise call falls back to the chains and leaves no zeroed header):
+    every image exact - the context waits for the previous call's stream by itself when the stream changes."""
+    import torch
+    from qoi_amd import synth
+    c = api.Context(0)
+    w, h = 1024, 768
+    items = []
+    for i, kind in enumerate(["photo", "photo_hard", "noise", "photo", "uiflat"]):
+        px = synth.frame_rgba(kind, w, h, 900 + i)
+        st = oracle.encode(px, w, h, 4)
+        items.append((torch.frombuffer(bytearray(st + b"\0" * 8), dtype=torch.uint8).cuda(), len(st), torch.from_numpy(px.reshape(-1).copy()).cuda()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), None]
+    outs = [torch.empty(w * h * 4, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    for it in range(90):
+        k = it % 3
+        d_s, n, want = items[(it * 7) % len(items)]
+        handle = streams[k].cuda_stream if streams[k] is not None else 0
+        outs[k].fill_(0x5A) if it % 11 == 0 else None
+        torch.cuda.synchronize() if it % 11 == 0 else None
+        c.decode_batch(d_s.data_ptr(), d_s.numel(), [n], [api.QoiDesc(w, h, 4, 0)], 4, outs[k].data_ptr(), w * h * 4, handle)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[k], want), (it, k)
+    c.close()
+
+
 def test_differential_fuzz(api, oracle):
     """tests/fuzz_decode.py (qoifuzz.c's input convention, but results are compared with the oracle):
     mutated / truncated / spliced streams, every `channels` argument incl. invalid ones."""
