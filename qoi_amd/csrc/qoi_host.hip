@@ -791,6 +791,9 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
         }
         double best = 1e30;
         for (uint32_t cand = 128; cand <= 4096u; cand <<= 1) {
+            // (calls of a few images: only the sizes their single-pass path takes - one or 8..64 pieces of 128 bytes; an 8192^2 image took 512
+            // bytes and with them the three-level chains: 686 us against 522 at 1 KiB, profiles/r06_s20_single_by_seg.txt)
+            if (n_images <= 4 && c->dec_fused && c->dec_fine && (cand == 256u || cand == 512u)) continue;
             const double lanes = (double)bytes / cand;
             const double rounds = lanes <= 98304.0 ? 1.0 : lanes / 98304.0;
             const double t = (cand / 1.2) * 0.6 * rounds + ((double)largest / cand / 64.0 / 8.0 + 16.0) * 0.5;
