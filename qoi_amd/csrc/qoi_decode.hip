@@ -903,30 +903,62 @@ __device__ __forceinline__ void sym_compose_range(const sym_t* __restrict__ rec,
     }
 }
 // concrete state pushed through rec[0..count); the state BEFORE record i is written to out + i*65 for i >= first_out
+// TRACK (refinement passes, DecParams::conv): `changed` is raised where a state written differs from the one it replaces in what
+// dec_summarize_rec<true> reads from it - the alpha byte of every word, the slot of the entry pixel.  The old words are fetched a batch ahead
+// of their stores, as the records are.
+template <bool TRACK = false>
 __device__ __forceinline__ void sym_sweep_range(const sym_t* __restrict__ rec, uint32_t count, uint32_t lane, uint32_t& tabv, uint32_t& pxv,
-                                                uint32_t* __restrict__ out, uint32_t first_out) {
+                                                uint32_t* out, uint32_t first_out, bool* changed = nullptr) {
     if (count == 0u) return;
     pxv = (uint32_t)__builtin_amdgcn_readfirstlane((int)pxv);               // (the same in every lane: say so, the pixel half of a step is scalar work)
     SymBatch cur, nxt;
+    uint32_t old_c[kChainBatch], old_n[kChainBatch], oldpx_c = 0u, oldpx_n = 0u;
+    auto old_load = [&](uint32_t (&o)[kChainBatch], uint32_t& opx, uint32_t first) {
+        opx = out[(size_t)min(first + lane, count - 1u) * 65u + 64u];
+#pragma unroll
+        for (int i = 0; i < kChainBatch; ++i) o[i] = out[(size_t)min(first + (uint32_t)i, count - 1u) * 65u + lane];
+    };
     sym_batch_load(cur, rec, 0u, count, lane);
+    if (TRACK) old_load(old_c, oldpx_c, 0u);
+    uint32_t diff = 0u;
     for (uint32_t g = 0; g < count; g += kChainBatch) {
         const uint32_t n = min(count - g, (uint32_t)kChainBatch);
         sym_batch_load(nxt, rec, g + kChainBatch, count, lane);
+        if (TRACK) old_load(old_n, oldpx_n, g + kChainBatch);
 #pragma unroll
         for (int i = 0; i < kChainBatch; ++i) {
             if ((uint32_t)i < n) {
                 if (g + (uint32_t)i >= first_out) {
                     out[(size_t)(g + i) * 65u + lane] = tabv;
                     if (lane == 0) out[(size_t)(g + i) * 65u + 64u] = pxv;
+                    if (TRACK) {
+                        const uint32_t opx = read_lane(oldpx_c, i);
+                        diff |= (old_c[i] ^ tabv) >> 24;
+                        diff |= ((opx ^ pxv) >> 24) | (hash_px(opx) ^ hash_px(pxv));
+                    }
                 }
                 sym_sweep_step(cur.tab[i], batch_px(cur, i), tabv, pxv);
             }
         }
         cur = nxt;
+        if (TRACK) {
+#pragma unroll
+            for (int i = 0; i < kChainBatch; ++i) old_c[i] = old_n[i];
+            oldpx_c = oldpx_n;
+        }
     }
+    if (TRACK) *changed = lanes_where(diff != 0u) != 0ull;
+}
+// refinement passes: what the kernels of a pass ask first (see DecParams::conv)
+__device__ __forceinline__ bool refine_pass_idle(const DecParams& p) {
+    return p.conv_pass > 1u && p.conv[p.conv_pass - 2u] == 0u;
+}
+__device__ __forceinline__ void refine_pass_note(const DecParams& p, bool changed, uint32_t lane) {
+    if (changed && lane == 0u) atomicAdd(&p.conv[p.conv_pass - 1u], 1u);
 }
 
 __global__ __launch_bounds__(64) void dec_chain_state_l1(DecParams p) {
+    if (refine_pass_idle(p)) return;
     const uint32_t G = blockIdx.x, lane = lane_id();
     const uint32_t img = find_image_by_group(p.images, p.n_images, G);
     const DecImage im = p.images[img];
@@ -940,6 +972,7 @@ __global__ __launch_bounds__(64) void dec_chain_state_l1(DecParams p) {
 }
 
 __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2(DecParams p) {
+    if (refine_pass_idle(p)) return;
     __shared__ sym_t s_sum[kL2Waves][65];        // symbolic summary of every share
     __shared__ uint32_t s_ent[kL2Waves][65];     // concrete state at every share's entry
     const uint32_t img = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -979,6 +1012,7 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2(DecParams p)
 // the 4K frame).  A workgroup's place in its image is the order in which the workgroups STARTED (a ticket), so the ones it waits
 // for are running whatever order the dispatcher chose.
 __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2m(DecParams p, uint32_t tag) {
+    if (refine_pass_idle(p)) return;                       // (before the ticket: a launch takes all of its tickets or none)
     __shared__ sym_t s_sum[kL2Waves + 1][65];    // symbolic summary of every share; [kL2Waves]: scratch of the hand-over
     __shared__ uint32_t s_ent[kL2Waves][65];     // concrete state at every share's entry
     __shared__ uint32_t s_k;
@@ -1034,6 +1068,7 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2m(DecParams p
 }
 
 __global__ __launch_bounds__(64) void dec_chain_state_l3(DecParams p) {
+    if (refine_pass_idle(p)) return;
     const uint32_t G = blockIdx.x, lane = lane_id();
     const uint32_t img = find_image_by_group(p.images, p.n_images, G);
     const DecImage im = p.images[img];
@@ -1042,6 +1077,13 @@ __global__ __launch_bounds__(64) void dec_chain_state_l3(DecParams p) {
     const uint32_t lo = max(j0, im.start_seg), hi = min(j0 + kGrp, im.n_active);
     uint32_t tabv = p.grp_entry[(size_t)G * 65u + lane], pxv = p.grp_entry[(size_t)G * 65u + 64u];
     // start_seg's entry state is given, never rewritten
+    if (p.conv_pass) {
+        bool changed = false;
+        sym_sweep_range<true>(p.summary + (size_t)(im.seg_base + lo) * 65u, hi - lo, lane, tabv, pxv,
+                              p.entry + (size_t)(im.seg_base + lo) * 65u, lo == im.start_seg ? 1u : 0u, &changed);
+        refine_pass_note(p, changed, lane);
+        return;
+    }
     sym_sweep_range(p.summary + (size_t)(im.seg_base + lo) * 65u, hi - lo, lane, tabv, pxv,
                     p.entry + (size_t)(im.seg_base + lo) * 65u, lo == im.start_seg ? 1u : 0u);
 }
@@ -1095,6 +1137,7 @@ __device__ __forceinline__ void sym_compose_range_prefix_coherent(const sym_t* r
 }
 __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2p(DecParams p) {
     __shared__ sym_t s_sum[kL2Waves][65];
+    if (refine_pass_idle(p)) return;
     if (p.tr_scan && *p.sync_fails != 0u) return;
     const uint32_t img = blockIdx.x / kL2pWgs, k = blockIdx.x % kL2pWgs, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const DecImage im = p.images[img];
@@ -1117,6 +1160,7 @@ __global__ __launch_bounds__(64 * kL2Waves) void dec_chain_state_l2p(DecParams p
 }
 __global__ __launch_bounds__(256) void dec_chain_state_l1q(DecParams p) {
     __shared__ sym_t s_q[4][65];
+    if (refine_pass_idle(p)) return;
     if (p.tr_scan && *p.sync_fails != 0u) return;
     const uint32_t G = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t img = find_image_by_group(p.images, p.n_images, G);
@@ -1171,6 +1215,7 @@ __global__ __launch_bounds__(256) void dec_chain_state_l1q(DecParams p) {
     if (lane == 0) granule_store(&p.l2_sum[(size_t)(img * kL2pWgs + k) * 65u + 64u], P_px);
 }
 __global__ __launch_bounds__(256) void dec_chain_state_l3q(DecParams p) {
+    if (refine_pass_idle(p)) return;
     if (p.tr_scan && *p.sync_fails != 0u) return;
     const uint32_t G = blockIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t img = find_image_by_group(p.images, p.n_images, G);
@@ -1214,6 +1259,13 @@ __global__ __launch_bounds__(256) void dec_chain_state_l3q(DecParams p) {
 #pragma unroll
     for (uint32_t k = 0; k < 3u; ++k) if (k < wave) sym_sweep_step(qt[k], uniform_sym(qp[k]), tabv, pxv);
     // start_seg's entry state is given, never rewritten
+    if (p.conv_pass) {
+        bool changed = false;
+        sym_sweep_range<true>(p.summary + (size_t)(im.seg_base + wlo) * 65u, whi - wlo, lane, tabv, pxv,
+                              p.entry + (size_t)(im.seg_base + wlo) * 65u, wlo == im.start_seg ? 1u : 0u, &changed);
+        refine_pass_note(p, changed, lane);
+        return;
+    }
     sym_sweep_range(p.summary + (size_t)(im.seg_base + wlo) * 65u, whi - wlo, lane, tabv, pxv,
                     p.entry + (size_t)(im.seg_base + wlo) * 65u, wlo == im.start_seg ? 1u : 0u);
 }
@@ -2067,6 +2119,7 @@ __global__ __launch_bounds__(64) void dec_summarize_rec(DecParams p) {
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     const uint32_t lane = lane_id();
     if (p.tr_scan && *p.sync_fails != 0u) return;          // (a call whose first pass could not synchronise every segment is void up to here: the host takes the chains)
+    if (REFINE && refine_pass_idle(p)) return;             // (the pass before this one changed nothing: a fixed point)
     if (p.s3_ctr && blockIdx.x == 0u)                      // the arrival counters of the state chain that follows this launch (dec_chain_state_l1q)
         for (uint32_t i = lane; i < p.n_images * kL2pWgs * (kL2Waves + 1u); i += 64u) p.s3_ctr[i] = 0u;
     const uint32_t q = blockIdx.x * 64u + lane;
@@ -2893,12 +2946,16 @@ void launch_decode_parse_rest(const DecParams& p, hipStream_t st, KernelTimer* t
     tm->mark(kT_dec_chain_parse, st);
 }
 
-void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipStream_t st, KernelTimer* tm) {
+void launch_decode_round(const DecParams& p_in, int out_channels, bool refine, hipStream_t st, KernelTimer* tm) {
+    const DecParams& p = p_in;
     if (!p.total_segs) return;
     const uint32_t b64 = (p.total_segs + 63u) / 64u;
     tm->mark(kT_begin, st);
-    uint32_t l2_seq = 0;
-    auto chain_state = [&]() {
+    uint32_t l2_seq = 0, last_pass = 0;
+    // (pass: 1 + the number of the refinement pass whose summaries this chain follows, 0 for the chain behind P3 proper - DecParams::conv)
+    auto chain_state = [&](uint32_t pass = 0u) {
+        DecParams p = p_in;
+        p.conv_pass = (p.conv && pass <= 16u) ? pass : 0u;
         if (p.qtr_summary) hipLaunchKernelGGL(dec_chain_state_l1q, dim3(p.total_grps), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(dec_chain_state_l1, dim3(p.total_grps), dim3(64), 0, st, p);
         if (p.grp_prefix && p.s3_ctr) { }                        // (the per-image level rode on dec_chain_state_l1q's launch)
@@ -2916,10 +2973,13 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
         // stretches: 13 rounds, each with a P4 over every open segment).  P3 + S3 are a fraction of P4 on such streams.
         const uint32_t inner = p.refine_inner ? p.refine_inner : 1u;
         for (uint32_t it = 0; it < inner; ++it) {
-            hipLaunchKernelGGL(dec_summarize_rec<true>, dim3(b64), dim3(64), 0, st, p);
+            DecParams pr = p;
+            pr.conv_pass = (p.conv && it < 16u) ? it + 1u : 0u;
+            hipLaunchKernelGGL(dec_summarize_rec<true>, dim3(b64), dim3(64), 0, st, pr);
             tm->mark(kT_dec_summarize, st);
-            if (it + 1u < inner) chain_state();
+            if (it + 1u < inner) chain_state(it + 1u);
         }
+        last_pass = inner;
     } else {
         if (!p.fused) {                       // (fused: dec_scan_entry has left slot_in / alpha_in)
             hipLaunchKernelGGL(dec_transcode<1>, dim3((p.total_segs + kTrThreads - 1u) / kTrThreads), dim3(kTrThreads), 0, st, p);
@@ -2933,7 +2993,7 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
         hipLaunchKernelGGL(dec_summarize_rec<false>, dim3(b64), dim3(64), 0, st, p);
         tm->mark(kT_dec_summarize, st);
     }
-    chain_state();
+    chain_state(last_pass);
     if (!refine && p.first_inner) {
         // Flat images (dec_image_is_flat): their first round nearly always fails at the second or third segment - P2's guess
         // "an INDEX chunk leaves the alpha as it is" is wrong where alpha levels go through the colour table - and a round's P4
@@ -2942,9 +3002,10 @@ void launch_decode_round(const DecParams& p, int out_channels, bool refine, hipS
         DecParams pf = p;
         pf.only_flat = 1u;
         for (uint32_t it = 0; it < p.first_inner; ++it) {
+            pf.conv_pass = (p.conv && it < 16u) ? it + 1u : 0u;
             hipLaunchKernelGGL(dec_summarize_rec<true>, dim3(b64), dim3(64), 0, st, pf);
             tm->mark(kT_dec_summarize, st);
-            chain_state();
+            chain_state(it + 1u);
         }
     }
     if (out_channels == 4) hipLaunchKernelGGL((dec_segments_rec<4, false>), dim3(b64), dim3(64), 0, st, p);

@@ -122,6 +122,7 @@ struct qoimi_ctx {
                                         // and always inside the drop-in qoi_encode, which encodes again by itself): by workgroup index, 4 us less per 4K frame
     int dec_tr_scan = 0;                // env QOIMI_DEC_TR_SCAN=1 (experiment, measured SLOWER: 46.6 us against 24.5 + 20.3 on a lone 4K frame, profiles/r06_s15): dec_scan_entry's
                                         // work as the epilogue of the two-lane transcoder instead of a launch of its own
+    int dec_conv = 1;                   // env QOIMI_DEC_CONV=0: refinement passes run to their count (1: they stop at a fixed point, DecParams::conv)
     int dec_s3_ride = 0;                // env QOIMI_DEC_S3_RIDE=1 (experiment, measured: 21.6 -> 20.7 us for the two levels on a lone 4K frame, profiles/r06_s14): the per-image
                                         // level of the state chain rides on the group level's launch (last arrivers) instead of dec_chain_state_l2p's own launch
     int dec_split = 1;                  // env QOIMI_DEC_SPLIT=0: one transcoder lane per segment in those calls too
@@ -241,7 +242,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         if (const char* e = getenv("QOIMI_DEC_INNER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner = v; }
         if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
         knob("QOIMI_DEC_L2M", c->dec_l2_wgs); knob("QOIMI_DEC_RUN_DESC", c->dec_run_desc); knob("QOIMI_DEC_FLAT_SEG", c->dec_flat_seg);
-        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split); knob("QOIMI_DEC_S3_RIDE", c->dec_s3_ride); knob("QOIMI_DEC_TR_SCAN", c->dec_tr_scan);
+        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split); knob("QOIMI_DEC_S3_RIDE", c->dec_s3_ride); knob("QOIMI_DEC_TR_SCAN", c->dec_tr_scan); knob("QOIMI_DEC_CONV", c->dec_conv);
         if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
         if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
         if (const char* e = getenv("QOIMI_SEG_BYTES")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v; }
@@ -820,7 +821,11 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     // Calls of a few images take the single-pass look-back kernel for pixel offsets and speculated slots (dec_scan_entry: one launch
     // where the three-level chains take ten); every image then begins on a multiple of kScanSegs segments.  Needs dec_transcode<0> (the
     // 128-byte piece parse's segment sizes) and falls back to the chains by itself where that pass cannot synchronise every segment.
-    const bool fused_layout = c->dec_fused && n_images <= 4 && B % 128u == 0u && ((B / 128u == 1u) || (B / 128u >= 8u && B / 128u <= 64u)) && ((B / 128u) & (B / 128u - 1u)) == 0u && c->dec_fine;
+    // (segments below 128 bytes, any multiple of 16 from 64 on: two transcoder lanes per segment; no piece parse for those - a call whose
+    // transcoder cannot synchronise every segment takes the full five-phase parse)
+    const bool small_seg = B >= 64u && B < 128u && B % 16u == 0u && c->dec_split;
+    const bool fused_layout = c->dec_fused && n_images <= 4 && c->dec_fine &&
+                              (small_seg || (B % 128u == 0u && ((B / 128u == 1u) || (B / 128u >= 8u && B / 128u <= 64u)) && ((B / 128u) & (B / 128u - 1u)) == 0u));
     for (int i = 0; i < n_images; ++i) {
         if (sizes[i] < kHeaderBytes + kTrailerBytes) return fail(QOIMI_E_ARG, "stream shorter than 22 bytes (qoi.h:500)");
         if (!desc_ok(&descs[i])) return fail(QOIMI_E_ARG, "descriptor rejected (qoi.h:513-521 rules)");
@@ -860,7 +865,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
     p.rec_rows = rec_rows_of(B);
-    if (fused && B == 128u && c->dec_split) {          // two transcoder lanes per segment (dec_transcode<0, .., SPLIT>): rows for two halves
+    if (fused && B <= 128u && c->dec_split) {          // two transcoder lanes per segment (dec_transcode<0, .., SPLIT>): rows for two halves
         p.tr_split = 1u; p.tr_rows_half = rec_rows_of(B / 2u); p.rec_rows = 2u * p.tr_rows_half;
         p.tr_scan = c->dec_tr_scan ? 1u : 0u;
     }
@@ -898,6 +903,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         p.pending = w.take<uint32_t>(4); p.redo_segs = p.pending ? p.pending + 1 : nullptr; p.sync_fails = p.pending ? p.pending + 2 : nullptr;
         p.run_queue_n = p.pending ? p.pending + 3 : nullptr;
         p.l2_ticket = p.pending ? p.pending + 8 : nullptr; p.l2_flag = p.pending ? p.pending + 16 : nullptr;       // words 8..11 and 16..47 of the zeroed 256-byte header
+        p.conv = (p.pending && c->dec_conv) ? p.pending + 48 : nullptr;                                      // words 48..63: refinement passes that changed something (DecParams::conv)
         p.images = w.take<DecImage>((size_t)n_images);
         p.first_bad = w.take<uint32_t>((size_t)n_images);
         p.parse = w.take<ParseRec>(Q); p.entry_phase = w.take<uint8_t>(Q); p.px_off = w.take<uint32_t>(Q);
@@ -973,6 +979,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     uint32_t redo_cum = 0, open_prev = 0xFFFFFFFFu; int stalled = 0;
     for (;;) {
         if (rounds > 0) HIP_TRY(hipMemsetAsync(p.pending, 0, sizeof(uint32_t), st));
+        if (rounds > 0 && p.conv) HIP_TRY(hipMemsetAsync(p.conv, 0, 16 * sizeof(uint32_t), st));
         p.l2_tag_base = (uint32_t)rounds * 65536u + 1u;            // (a round launches S3 1 + first_inner / refine_inner times: far fewer than 65536)
         // the first round of a call of a few images: dec_fill leaves the round's counters in pinned host words (no copy back)
         p.tail_fused = (p.fused && rounds == 0) ? 1u : 0u;
@@ -1012,7 +1019,9 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
             // that stand (the flagged segments are transcoded by dec_transcode<1>).
             p.fused = 0u; fused = false; p.tr_scan = 0u;         // (tr_scan off: the kernels of the chains must not return on sync_fails)
             rounds = 0;
-            launch_decode_parse_rest(p, st, &c->timer);
+            if (p.fine_per_seg) launch_decode_parse_rest(p, st, &c->timer);
+            else { HIP_TRY(hipMemsetAsync(p.sync_fails, 0, sizeof(uint32_t), st)); launch_decode_parse(p, st, &c->timer); }
+            if (p.conv) HIP_TRY(hipMemsetAsync(p.conv, 0, 16 * sizeof(uint32_t), st));       // (segment sizes without the piece parse: everything again)
             continue;
         }
         p.fused = 0u; p.tr_scan = 0u;                       // (rounds after a failed check are the three-level ones, from the image's first bad segment)

@@ -189,6 +189,11 @@ struct DecParams {
     uint32_t refine_inner;     // refinement rounds: repetitions of P3 + S3 before P4 (env QOIMI_DEC_INNER)
     uint32_t first_inner;      // first round: refinement passes (P3 from the speculated entry states + S3) appended for flat images (env QOIMI_DEC_INNER1)
     uint32_t only_flat;        // set by the launcher for those passes: dec_summarize_rec<true> serves flat images only
+    // Refinement passes stop by themselves (round 6): the state chain that follows pass s counts the segments whose entry state changed in
+    // what the next pass would read from it (the alpha bytes, the slot of the entry pixel) in conv[s]; the kernels of pass s + 1 return at
+    // once where that count is zero - the passes behind a fixed point are launches of nothing.  conv: 16 words of the zeroed counter header.
+    uint32_t* conv;
+    uint32_t  conv_pass;       // set by the launcher: 1 + the pass's number (1..16); 0 = not a refinement pass (nothing counted, nothing skipped)
     // calls of a few large images: the per-image level of the state chain (S3 l2) runs as l2_wgs workgroups per image
     uint32_t  l2_wgs;          // 1: dec_chain_state_l2; 8: dec_chain_state_l2m (ticket / flag words live in the counter header)
     uint32_t  l2_tag_base;     // first tag of this round's S3 launches (a launch's flags carry its tag: nothing to reset)

@@ -44,3 +44,9 @@ for _ in range(reps if mode != "enc" else 0):
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"single frame: encode {(t1 - t0) / reps * 1e6:.1f} us, decode {(t2 - t1) / reps * 1e6:.1f} us, equal {bool(torch.equal(out[:npx * 4], px[:npx * 4]))}")
+if os.environ.get("STATS"):
+    print("decode stats of the last call:", ctx.decode_stats())
+    ctx.set_profiling(True)
+    ctx.decode_batch(st.data_ptr(), ss, n, [desc], 4, out.data_ptr(), ps, stream)
+    prof = ctx.get_profile(stream)
+    print("per kernel (us, launches):", {k: (round(v[0] * 1e3, 1), v[1]) for k, v in prof.items() if v[1]})
