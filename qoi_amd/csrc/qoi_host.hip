@@ -122,6 +122,7 @@ struct qoimi_ctx {
                                         // and always inside the drop-in qoi_encode, which encodes again by itself): by workgroup index, 4 us less per 4K frame
     int dec_tr_scan = 0;                // env QOIMI_DEC_TR_SCAN=1 (experiment, measured SLOWER: 46.6 us against 24.5 + 20.3 on a lone 4K frame, profiles/r06_s15): dec_scan_entry's
                                         // work as the epilogue of the two-lane transcoder instead of a launch of its own
+    int dec_small_seg = 1;              // env QOIMI_DEC_SMALL_SEG=0: calls of a few images never below 128-byte segments
     int dec_conv = 1;                   // env QOIMI_DEC_CONV=0: refinement passes run to their count (1: they stop at a fixed point, DecParams::conv)
     int dec_s3_ride = 0;                // env QOIMI_DEC_S3_RIDE=1 (experiment, measured: 21.6 -> 20.7 us for the two levels on a lone 4K frame, profiles/r06_s14): the per-image
                                         // level of the state chain rides on the group level's launch (last arrivers) instead of dec_chain_state_l2p's own launch
@@ -242,7 +243,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         if (const char* e = getenv("QOIMI_DEC_INNER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner = v; }
         if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
         knob("QOIMI_DEC_L2M", c->dec_l2_wgs); knob("QOIMI_DEC_RUN_DESC", c->dec_run_desc); knob("QOIMI_DEC_FLAT_SEG", c->dec_flat_seg);
-        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split); knob("QOIMI_DEC_S3_RIDE", c->dec_s3_ride); knob("QOIMI_DEC_TR_SCAN", c->dec_tr_scan); knob("QOIMI_DEC_CONV", c->dec_conv);
+        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split); knob("QOIMI_DEC_S3_RIDE", c->dec_s3_ride); knob("QOIMI_DEC_TR_SCAN", c->dec_tr_scan); knob("QOIMI_DEC_CONV", c->dec_conv); knob("QOIMI_DEC_SMALL_SEG", c->dec_small_seg);
         if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
         if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
         if (const char* e = getenv("QOIMI_SEG_BYTES")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v; }
@@ -800,6 +801,15 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
             const double t = (cand / 1.2) * 0.6 * rounds + ((double)largest / cand / 64.0 / 8.0 + 16.0) * 0.5;
             if (t < best) { best = t; B = cand; }
         }
+        // Calls of a few images whose streams are small: the chip is not full at 128 bytes (a 1080p photograph: 20 K segments, 320
+        // wavefronts for 1024 SIMDs), a pass is as long as one lane's walk - shorter segments, two transcoder lanes each, as long as
+        // the call stays below ~48 K segments (1280 x 720: 111 -> 100 us at 64 bytes, 1080p 120 -> 114, 1440p 132 -> 128 at 96; a 4K
+        // photograph keeps 128: 168 us at 112, profiles/r06_s22_single_small_seg.txt).  No piece parse below 128 bytes: a call whose
+        // transcoder cannot synchronise every segment takes the full five-phase parse.
+        if (B == 128u && n_images <= 4 && c->dec_fused && c->dec_fine && c->dec_split && c->dec_small_seg) {
+            const uint64_t want = (bytes / 49152u + 15u) / 16u * 16u;
+            B = want < 64u ? 64u : want < 128u ? (uint32_t)want : 128u;
+        }
         // A call that MIXES flat images with others (a directory of screenshots and photographs, bench.py "mixed_directory"): the flat
         // ones' streams are a few hundred KB - a few dozen lanes at the 4 KiB the photographs' bytes ask for - and the symbolic pass walks
         // them several times (refinement passes): 4.8 of that leg's 9.3 ms.  Not above 1 KiB then (photographs lose a few per cent, 4 x
@@ -1020,8 +1030,8 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
             p.fused = 0u; fused = false; p.tr_scan = 0u;         // (tr_scan off: the kernels of the chains must not return on sync_fails)
             rounds = 0;
             if (p.fine_per_seg) launch_decode_parse_rest(p, st, &c->timer);
-            else { HIP_TRY(hipMemsetAsync(p.sync_fails, 0, sizeof(uint32_t), st)); launch_decode_parse(p, st, &c->timer); }
-            if (p.conv) HIP_TRY(hipMemsetAsync(p.conv, 0, 16 * sizeof(uint32_t), st));       // (segment sizes without the piece parse: everything again)
+            else launch_decode_parse(p, st, &c->timer);           // (segment sizes without the piece parse: every segment again; sync_fails stands - the call's statistics)
+            if (p.conv) HIP_TRY(hipMemsetAsync(p.conv, 0, 16 * sizeof(uint32_t), st));
             continue;
         }
         p.fused = 0u; p.tr_scan = 0u;                       // (rounds after a failed check are the three-level ones, from the image's first bad segment)

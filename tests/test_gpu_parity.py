@@ -533,7 +533,7 @@ def test_selectable_paths(api, oracle, env):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("seg", ["", "128", "1024"])
+@pytest.mark.parametrize("seg", ["", "64", "80", "112", "128", "1024"])
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_small_calls_single_pass_lookback(api, oracle, seg, fused):
     """Calls of one to four images take dec_scan_entry (pixel offsets + speculated slots by a single-pass look-back over tagged words,
@@ -557,7 +557,7 @@ def test_small_calls_single_pass_lookback(api, oracle, seg, fused):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    shapes = [("photo", 1280, 720), ("uiflat", 640, 400), ("sprite_alpha", 333, 251), ("constant", 64, 64), ("photo_hard", 1, 1), ("photo", 97, 3), ("photo_hard", 800, 600)]
+    shapes = [("photo", 1280, 720), ("uiflat", 640, 400), ("sprite_alpha", 333, 251), ("constant", 64, 64), ("photo_hard", 1, 1), ("photo", 97, 3), ("photo_hard", 800, 600), ("noise", 200, 150)]          # (noise: the transcoder cannot synchronise it - the five-phase parse, at every segment size)
     streams, descs = [], []
     for i, (kind, w, h) in enumerate(shapes):
         px = synth.frame_rgba(kind, w, h, 70 + i)
