@@ -522,6 +522,23 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     for (int k = 0; k < 5; ++k) s_rec[wave][lane][1 + k] = r.pixels[k];
     __builtin_amdgcn_wave_barrier();
     const uint32_t g0 = lane - sub;                      // first lane of this segment's group
+    if (G < 8u) {                                        // two or four pieces (256- and 512-byte segments): fewer lanes than entry phases - the segment's first lane walks all five
+        if (have && sub == 0u) {
+            ParseRec o; o.exit_phase = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < 5u; ++e) {
+                uint32_t ph = e, tot = 0;
+                for (uint32_t k = 0; k < G; ++k) {
+                    tot += s_rec[wave][g0 + k][1u + ph];
+                    ph = (s_rec[wave][g0 + k][0] >> (3u * ph)) & 7u;
+                }
+                o.exit_phase |= ph << (3u * e);
+                o.pixels[e] = tot;
+            }
+            p.parse[q] = o;
+        }
+        return;
+    }
     if (sub < 5u) {
         uint32_t ph = sub, tot = 0;
         for (uint32_t k = 0; k < G; ++k) {
@@ -2527,7 +2544,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     {   // descriptor base: the image of the wavefront's first segment (its lanes' images follow it in memory)
         const uint32_t q0 = blockIdx.x * 64u;
         const uint32_t img0 = find_image(p.images, p.n_images, q0 < p.total_segs ? q0 : 0u);
-        W.init(lds_addr_of(&s_out[lane]), p.pixels + (size_t)img0 * p.pixel_stride, p.pixels + (size_t)img * p.pixel_stride,
+        W.init(lds_addr_of(&s_out[lane]), p.pixels + (size_t)p.images[img0].out_index * p.pixel_stride, p.pixels + (size_t)im.out_index * p.pixel_stride,
                im.npx * (uint32_t)OCH, px_first);
     }
     LdsTab32 tab{&s_tab[lane]};
@@ -2747,7 +2764,7 @@ __global__ __launch_bounds__(256) void dec_expand_runs(DecParams p) {
         const uint32_t n = p.run_cnt[q];
         const uint4* __restrict__ dsc = desc_base != kNoRunDesc ? p.run_desc + (size_t)(desc_base + (q - seg_base)) * p.desc_cap
                                                                  : reinterpret_cast<const uint4*>(p.summary + (size_t)q * 65u);
-        uint8_t* __restrict__ out = p.pixels + (size_t)img * p.pixel_stride;
+        uint8_t* __restrict__ out = p.pixels + (size_t)p.images[img].out_index * p.pixel_stride;
         auto get_desc = [&](uint32_t at) {                   // (two 8-byte halves: see dec_segments_rec)
             const uint2* d = reinterpret_cast<const uint2*>(dsc + at);
             const uint2 a = d[0], b = d[1];
@@ -2808,7 +2825,7 @@ __global__ __launch_bounds__(64) void dec_sequential(DecParams p) {
     uint32_t px = p.entry[q0 * 65u + 64u];
     __builtin_amdgcn_wave_barrier();
     if (lane != 0u) return;
-    uint8_t* out = p.pixels + (size_t)img * p.pixel_stride;
+    uint8_t* out = p.pixels + (size_t)im.out_index * p.pixel_stride;
     uint32_t pos = p.px_off[q0], stash = 0u;
     const uint32_t limit = im.npx;
     for (uint32_t j = im.start_seg; j < im.n_active && pos < limit; ++j) {
@@ -2893,7 +2910,7 @@ __global__ __launch_bounds__(256) void dec_fill(DecParams p) {
     if (blockIdx.x == 0u && threadIdx.x == 64u && !p.tail_fused) *p.run_queue_n = 0u;        // the round's run descriptors are written out (dec_expand_runs ran before this launch)
     if (im.total_px >= im.npx) return;
     const uint32_t px = im.n_active ? im.final_px : kInitPx;
-    uint8_t* out = p.pixels + (size_t)img * p.pixel_stride;
+    uint8_t* out = p.pixels + (size_t)im.out_index * p.pixel_stride;
     for (uint32_t i = im.total_px + slice * 256u + threadIdx.x; i < im.npx; i += kFillSlices * 256u) {
         if (OCH == 4) reinterpret_cast<uint32_t*>(out)[i] = px;
         else { uint8_t* d = out + (size_t)i * 3u; d[0] = (uint8_t)px; d[1] = (uint8_t)(px >> 8); d[2] = (uint8_t)(px >> 16); }

@@ -122,6 +122,8 @@ struct qoimi_ctx {
                                         // and always inside the drop-in qoi_encode, which encodes again by itself): by workgroup index, 4 us less per 4K frame
     int dec_tr_scan = 0;                // env QOIMI_DEC_TR_SCAN=1 (experiment, measured SLOWER: 46.6 us against 24.5 + 20.3 on a lone 4K frame, profiles/r06_s15): dec_scan_entry's
                                         // work as the epilogue of the two-lane transcoder instead of a launch of its own
+    bool dec_nonflat_repair = false;    // the context's last call of more than four images (flat ones aside) needed a repair round: see choose_seg_bytes
+    int dec_class_split = 1;            // env QOIMI_DEC_CLASS_SPLIT=0: a call that mixes flat images with others is one pass over all of them (round 5)
     int dec_small_seg = 1;              // env QOIMI_DEC_SMALL_SEG=0: calls of a few images never below 128-byte segments
     int dec_conv = 1;                   // env QOIMI_DEC_CONV=0: refinement passes run to their count (1: they stop at a fixed point, DecParams::conv)
     int dec_s3_ride = 0;                // env QOIMI_DEC_S3_RIDE=1 (experiment, measured: 21.6 -> 20.7 us for the two levels on a lone 4K frame, profiles/r06_s14): the per-image
@@ -243,7 +245,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         if (const char* e = getenv("QOIMI_DEC_INNER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner = v; }
         if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
         knob("QOIMI_DEC_L2M", c->dec_l2_wgs); knob("QOIMI_DEC_RUN_DESC", c->dec_run_desc); knob("QOIMI_DEC_FLAT_SEG", c->dec_flat_seg);
-        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split); knob("QOIMI_DEC_S3_RIDE", c->dec_s3_ride); knob("QOIMI_DEC_TR_SCAN", c->dec_tr_scan); knob("QOIMI_DEC_CONV", c->dec_conv); knob("QOIMI_DEC_SMALL_SEG", c->dec_small_seg);
+        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split); knob("QOIMI_DEC_S3_RIDE", c->dec_s3_ride); knob("QOIMI_DEC_TR_SCAN", c->dec_tr_scan); knob("QOIMI_DEC_CONV", c->dec_conv); knob("QOIMI_DEC_SMALL_SEG", c->dec_small_seg); knob("QOIMI_DEC_CLASS_SPLIT", c->dec_class_split);
         if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
         if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
         if (const char* e = getenv("QOIMI_SEG_BYTES")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v; }
@@ -793,12 +795,19 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
         }
         double best = 1e30;
         for (uint32_t cand = 128; cand <= 4096u; cand <<= 1) {
-            // (calls of a few images: only the sizes their single-pass path takes - one or 8..64 pieces of 128 bytes; an 8192^2 image took 512
-            // bytes and with them the three-level chains: 686 us against 522 at 1 KiB, profiles/r06_s20_single_by_seg.txt)
-            if (n_images <= 4 && c->dec_fused && c->dec_fine && (cand == 256u || cand == 512u)) continue;
             const double lanes = (double)bytes / cand;
             const double rounds = lanes <= 98304.0 ? 1.0 : lanes / 98304.0;
-            const double t = (cand / 1.2) * 0.6 * rounds + ((double)largest / cand / 64.0 / 8.0 + 16.0) * 0.5;
+            double t = (cand / 1.2) * 0.6 * rounds + ((double)largest / cand / 64.0 / 8.0 + 16.0) * 0.5;
+            if (n_images > 4) {
+                // Batches (round 6, fitted to 8 .. 256 4K frames of photographs and sprites at every size, profiles/r06_s31_batch_by_seg.txt):
+                // the passes run at the chip's throughput, ~5 us per MB of streams, plus the per-segment state - (1 + 140 / B) - and end
+                // with the longest lane's walk, which grows with the segment: ~0.3 us per byte (photographs 0.1, sprites with long runs
+                // 0.65); a call behind one that needed repair rounds counts 1.3 (a round's passes serve few segments: each is as long as
+                // one walk).  sqrt(bytes): 512 bytes for 8 photographs, 1 KiB for 32, 2 KiB for 128 .. 256, 4 KiB from ~3.6 GB of streams.
+                // (The model above it ties all sizes once the chip is full and took the largest: 32 sprite frames 5.5 ms at 4 KiB, 3.9 at 1 KiB.)
+                const double kappa = c->dec_nonflat_repair ? 1.3 : 0.3;
+                t = (double)bytes * 5e-6 * (1.0 + 140.0 / cand) + kappa * cand + ((double)largest / cand / 64.0 / 8.0 + 16.0) * 0.5;
+            }
             if (t < best) { best = t; B = cand; }
         }
         // Calls of a few images whose streams are small: the chip is not full at 128 bytes (a 1080p photograph: 20 K segments, 320
@@ -824,7 +833,9 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
 // one sub-batch: everything of qoimi_decode_batch for images whose record arena fits dec_rec_cap
 static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride,
                        const int* sizes, const qoi_desc* descs, int n_images, int channels,
-                       void* d_pixels, size_t pixel_stride, void* stream, uint32_t B, bool lone_image, long long stats[4]) {
+                       void* d_pixels, size_t pixel_stride, void* stream, uint32_t B, bool lone_image, long long stats[4], const int* place = nullptr) {
+    // place (a call decoded class by class): image i of this sub-call is the caller's image place[i] - its stream at place[i] * stream_stride,
+    // its pixels at place[i] * pixel_stride; sizes / descs are the sub-call's own arrays
     int och = 0;
     std::vector<DecImage> imgs((size_t)n_images);
     uint64_t total = 0, total_g = 0, flat_total = 0;
@@ -835,7 +846,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     // transcoder cannot synchronise every segment takes the full five-phase parse)
     const bool small_seg = B >= 64u && B < 128u && B % 16u == 0u && c->dec_split;
     const bool fused_layout = c->dec_fused && n_images <= 4 && c->dec_fine &&
-                              (small_seg || (B % 128u == 0u && ((B / 128u == 1u) || (B / 128u >= 8u && B / 128u <= 64u)) && ((B / 128u) & (B / 128u - 1u)) == 0u));
+                              (small_seg || (B % 128u == 0u && B / 128u >= 1u && B / 128u <= 64u && ((B / 128u) & (B / 128u - 1u)) == 0u));
     for (int i = 0; i < n_images; ++i) {
         if (sizes[i] < kHeaderBytes + kTrailerBytes) return fail(QOIMI_E_ARG, "stream shorter than 22 bytes (qoi.h:500)");
         if (!desc_ok(&descs[i])) return fail(QOIMI_E_ARG, "descriptor rejected (qoi.h:513-521 rules)");
@@ -847,7 +858,8 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
         if ((size_t)sizes[i] > stream_stride && !lone_image) return fail(QOIMI_E_ARG, "stream longer than stream_stride");
         DecImage& im = imgs[(size_t)i];
         memset(&im, 0, sizeof im);
-        im.stream_off = (size_t)i * stream_stride;
+        im.stream_off = (size_t)(place ? place[i] : i) * stream_stride;
+        im.out_index = (uint32_t)(place ? place[i] : i);
         im.chunks_end = (uint32_t)(sizes[i] - kTrailerBytes);
         im.npx = (uint32_t)npx;
         if (fused_layout) { total = (total + kScanSegs - 1u) / kScanSegs * kScanSegs; total_g = total / 64u; }
@@ -894,9 +906,9 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     }
     p.pixels = (uint8_t*)d_pixels; p.pixel_stride = pixel_stride;
     const size_t Q = total + 1;   // +1: check of segment q reads entry[q+1]
-    {   // P1/P2 on 128-byte pieces when a segment is 1, 8, 16, 32 or 64 of them
+    {   // P1/P2 on 128-byte pieces when a segment is 1, 2, 4 ... 64 of them
         const uint32_t g = B / 128u;
-        const bool ok = B % 128u == 0u && (g == 1u || (g >= 8u && g <= 64u)) && (g & (g - 1u)) == 0u && c->dec_fine;
+        const bool ok = B % 128u == 0u && g >= 1u && g <= 64u && (g & (g - 1u)) == 0u && c->dec_fine;
         p.fine_per_seg = ok ? g : 0u;
         p.fine_shift = 0;
         while (ok && (1u << p.fine_shift) < g) ++p.fine_shift;
@@ -1081,25 +1093,62 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
     if (channels != 0 && channels != 3 && channels != 4) return fail(QOIMI_E_ARG, "channels must be 0, 3 or 4 (qoi.h:499)");
     for (int i = 1; i < n_images && channels == 0; ++i)
         if (descs[i].channels != descs[0].channels) return fail(QOIMI_E_ARG, "all images of a batch must share the output channel count");
-    const uint32_t B = choose_seg_bytes(c, sizes, descs, n_images);
     // The chunk records take four bytes per stream byte (worst case) while a call is in flight.  Calls whose streams would
     // need more than dec_rec_cap are decoded as consecutive sub-batches of whole images through the same workspace.
     const uint64_t cap_stream = (uint64_t)(c->dec_rec_cap / 4u) - (uint64_t)(c->dec_rec_cap / 4u) / 64u;
     long long acc[4] = {0, 0, 0, 0};
-    for (int first = 0; first < n_images;) {
-        uint64_t bytes = 0;
-        int n = 0;
-        while (first + n < n_images) {
-            const uint64_t sz = (uint64_t)(sizes[first + n] > 0 ? sizes[first + n] : 0) + B;
-            if (n > 0 && bytes + sz > cap_stream) break;
-            bytes += sz; ++n;
+    auto sub_batches = [&](const int* sz_v, const qoi_desc* ds_v, const int* place, int n_all, uint32_t B) -> int {
+        for (int first = 0; first < n_all;) {
+            uint64_t bytes = 0;
+            int n = 0;
+            while (first + n < n_all) {
+                const uint64_t sz = (uint64_t)(sz_v[first + n] > 0 ? sz_v[first + n] : 0) + B;
+                if (n > 0 && bytes + sz > cap_stream) break;
+                bytes += sz; ++n;
+            }
+            long long st3[4] = {0, 0, 0, 0};
+            int rc;
+            if (place) rc = decode_some(c, d_streams, stream_stride, sz_v + first, ds_v + first, n, channels, d_pixels, pixel_stride, stream, B, false, st3, place + first);
+            else rc = decode_some(c, (const uint8_t*)d_streams + (size_t)first * stream_stride, stream_stride, sz_v + first, ds_v + first, n, channels,
+                                  (uint8_t*)d_pixels + (size_t)first * pixel_stride, pixel_stride, stream, B, n_images == 1, st3);
+            if (rc != QOIMI_OK) return rc;
+            acc[0] = st3[0] > acc[0] ? st3[0] : acc[0]; acc[1] += st3[1]; acc[2] += st3[2]; acc[3] += st3[3];
+            first += n;
         }
-        long long st3[4] = {0, 0, 0, 0};
-        const int rc = decode_some(c, (const uint8_t*)d_streams + (size_t)first * stream_stride, stream_stride, sizes + first, descs + first, n, channels,
-                                   (uint8_t*)d_pixels + (size_t)first * pixel_stride, pixel_stride, stream, B, n_images == 1, st3);
+        return QOIMI_OK;
+    };
+    // A call that MIXES flat images (UI frames, constant frames: streams of a few hundred KB) with others - a directory of screenshots and
+    // photographs - is decoded CLASS BY CLASS: the flat images' passes (a few refinement passes in front of their P4, the P4 that leaves run
+    // descriptors) are as long as one lane's walk over one segment, and the segment size the other images' bytes ask for made each of them
+    // ~270 us for a few hundred lanes (3 of the mixed directory's 5.4 ms, profiles/r06_s28_mixed_timeline.txt).  Each class takes the
+    // segment size of its own bytes; an image's place in the caller's buffers travels in the table (DecImage::out_index).
+    int n_flat = 0;
+    if (n_images > 4)
+        for (int i = 0; i < n_images; ++i)
+            n_flat += (sizes[i] > 22 && descs[i].width != 0 && dec_image_is_flat((uint32_t)sizes[i] - 8u, (uint32_t)((uint64_t)descs[i].width * descs[i].height))) ? 1 : 0;
+    if (n_flat != 0 && n_flat != n_images && c->dec_run_desc && c->dec_class_split) {
+        for (int cls = 0; cls < 2; ++cls) {
+            std::vector<int> place, sz_v; std::vector<qoi_desc> ds_v;
+            for (int i = 0; i < n_images; ++i) {
+                const bool flat = sizes[i] > 22 && descs[i].width != 0 && dec_image_is_flat((uint32_t)sizes[i] - 8u, (uint32_t)((uint64_t)descs[i].width * descs[i].height));
+                if ((flat ? 1 : 0) == cls) { place.push_back(i); sz_v.push_back(sizes[i]); ds_v.push_back(descs[i]); }
+            }
+            const uint32_t forced = c->seg_bytes;
+            if (cls == 1) c->seg_bytes = 0;                          // (QOIMI_SEG_BYTES: the other images' size; the flat class keeps its rule)
+            const uint32_t B = choose_seg_bytes(c, sz_v.data(), ds_v.data(), (int)place.size());
+            c->seg_bytes = forced;
+            const long long before = acc[0];
+            acc[0] = 0;
+            const int rc = sub_batches(sz_v.data(), ds_v.data(), place.data(), (int)place.size(), B);
+            if (rc != QOIMI_OK) return rc;
+            if (cls == 0 && place.size() > 4u) c->dec_nonflat_repair = acc[0] > 1;
+            acc[0] = acc[0] > before ? acc[0] : before;
+        }
+    } else {
+        const uint32_t B = choose_seg_bytes(c, sizes, descs, n_images);
+        const int rc = sub_batches(sizes, descs, nullptr, n_images, B);
         if (rc != QOIMI_OK) return rc;
-        acc[0] = st3[0] > acc[0] ? st3[0] : acc[0]; acc[1] += st3[1]; acc[2] += st3[2]; acc[3] += st3[3];
-        first += n;
+        if (n_images > 4 && n_flat == 0) c->dec_nonflat_repair = acc[0] > 1;
     }
     c->dec_stats[0] = acc[0]; c->dec_stats[1] = acc[1]; c->dec_stats[2] = acc[2]; c->dec_stats[3] = acc[3];
     return QOIMI_OK;

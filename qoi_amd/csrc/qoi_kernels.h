@@ -139,6 +139,7 @@ struct DecImage {
     uint32_t start_seg;    // first segment still to be (re)decoded; n_active: done
     uint32_t final_px;     // exit pixel of the last active segment                 (P4)
     uint32_t desc_base;    // flat images (run descriptors): index of the image's first segment among the flat images' segments; kNoRunDesc: none
+    uint32_t out_index;    // the image's place in the caller's pixel buffer: pixels + out_index * pixel_stride (a call decoded class by class: not the table index)
 };
 constexpr uint32_t kNoRunDesc = 0xFFFFFFFFu;
 
@@ -150,7 +151,7 @@ struct DecParams {
     const uint8_t* streams;
     DecImage* images;      // device array [n_images]
     uint32_t n_images, total_segs, total_grps, seg_bytes;
-    uint32_t fine_per_seg, fine_shift;   // 128-byte pieces per segment for P1/P2 (8..64, power of two), 0: lane per segment
+    uint32_t fine_per_seg, fine_shift;   // 128-byte pieces per segment for P1/P2 (1..64, power of two), 0: lane per segment
     uint32_t rec_rows;                   // granules (4 records) reserved per segment: rec_region_dwords(seg_bytes) / 4
     uint32_t* recs;                      // chunk records (qoi_decode_core.h), [block of 64 segments][granule row][lane = segment & 63] x 16 bytes:
                                          // a wavefront's granule row is one contiguous KiB - every record load / store is fully coalesced

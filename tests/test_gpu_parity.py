@@ -589,6 +589,53 @@ def test_small_calls_single_pass_lookback(api, oracle, seg, fused):
     c.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"QOIMI_DEC_CLASS_SPLIT": "0"}, {"QOIMI_DEC_REC_CAP_MB": "1"}, {"QOIMI_SEG_BYTES": "256"}])
+def test_mixed_call_class_by_class(api, oracle, env):
+    """A call of more than four images that mixes flat images (UI frames, constant frames) with others is decoded class by class, each
+    class at the segment size of its own bytes; an image's place in the caller's buffers travels in the image table.  Eleven images of
+    different shapes, the classes interleaved, a flat stream cut short (its last pixel repeated, qoi.h:544) and a photograph's stream cut
+    short; 3- and 4-channel output; twice on one context; against the reference decoder.  Also as one pass over everything (round 5), with
+    the record arena capped (sub-batches inside a class) and at a forced segment size."""
+    import torch
+    from qoi_amd import synth
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = api.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    shapes = [("photo", 640, 360), ("uiflat", 800, 600), ("noise", 120, 90), ("constant", 512, 512), ("sprite_alpha", 333, 251), ("uiflat", 1280, 720),
+              ("photo_hard", 400, 300), ("constant", 31, 17), ("photo", 97, 3)]
+    streams, descs = [], []
+    for i, (kind, w, h) in enumerate(shapes):
+        streams.append(oracle.encode(synth.frame_rgba(kind, w, h, 90 + i), w, h, 4)); descs.append((w, h))
+    streams.append(streams[1][:len(streams[1]) // 2] + streams[1][-8:]); descs.append(descs[1])          # a flat stream cut short
+    streams.append(streams[0][:len(streams[0]) // 3] + streams[0][-8:]); descs.append(descs[0])
+    n = len(streams)
+    stride_s = (max(len(s) for s in streams) + 255) // 256 * 256
+    stride_p = (max(w * h for w, h in descs) * 4 + 255) // 256 * 256
+    stream = torch.cuda.current_stream().cuda_stream
+    d_s = torch.zeros(n * stride_s, dtype=torch.uint8, device="cuda")
+    for k in range(n):
+        d_s[k * stride_s:k * stride_s + len(streams[k])] = torch.frombuffer(bytearray(streams[k]), dtype=torch.uint8).cuda()
+    for rep in range(2):
+        for och in (4, 3):
+            d_p = torch.full((n * stride_p + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+            c.decode_batch(d_s.data_ptr(), stride_s, [len(s) for s in streams], [api.QoiDesc(w, h, 4, 0) for w, h in descs], och, d_p.data_ptr(), stride_p, stream)
+            host = d_p.cpu().numpy()
+            for k in range(n):
+                want, _ = oracle.decode(streams[k], och)
+                got = host[k * stride_p:k * stride_p + descs[k][0] * descs[k][1] * och]
+                assert np.array_equal(got, want), (env, rep, och, k)
+                tail = host[k * stride_p + descs[k][0] * descs[k][1] * och:(k + 1) * stride_p]
+                assert (tail == 0xA5).all(), ("wrote behind the image", env, och, k)
+    c.close()
+
+
 def test_small_calls_on_alternating_streams(api, oracle):
     """A call of a few images returns on the result words its last launch writes to pinned memory; that launch (it zeroes the counter
     header for the context's next call) may still be retiring.  One context, calls in turn on two streams and on the default stream, no

@@ -2,7 +2,7 @@
 # round 6, session 24: the mixed directory's decode, launch by launch
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/r06_s24
+OUT=gpurun_out/${SESSION:-r06_s24}
 mkdir -p "$OUT"
 export TMPDIR=/tmp PYTHONUNBUFFERED=1 HSA_ENABLE_COREDUMP=0 QOIMI_TUNING=1
 ulimit -c 0
