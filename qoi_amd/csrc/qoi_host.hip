@@ -122,6 +122,8 @@ struct qoimi_ctx {
                                         // and always inside the drop-in qoi_encode, which encodes again by itself): by workgroup index, 4 us less per 4K frame
     int dec_tr_scan = 0;                // env QOIMI_DEC_TR_SCAN=1 (experiment, measured SLOWER: 46.6 us against 24.5 + 20.3 on a lone 4K frame, profiles/r06_s15): dec_scan_entry's
                                         // work as the epilogue of the two-lane transcoder instead of a launch of its own
+    bool dec_few_syncfail = false;      // the context's last call of up to four images held segments its transcoder could not synchronise: see decode_some
+    int dec_fused_adapt = 1;            // env QOIMI_DEC_FUSED_ADAPT=0: such calls try the single-pass path every time
     bool dec_nonflat_repair = false;    // the context's last call of more than four images (flat ones aside) needed a repair round: see choose_seg_bytes
     int dec_class_split = 1;            // env QOIMI_DEC_CLASS_SPLIT=0: a call that mixes flat images with others is one pass over all of them (round 5)
     int dec_small_seg = 1;              // env QOIMI_DEC_SMALL_SEG=0: calls of a few images never below 128-byte segments
@@ -245,7 +247,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         if (const char* e = getenv("QOIMI_DEC_INNER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner = v; }
         if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
         knob("QOIMI_DEC_L2M", c->dec_l2_wgs); knob("QOIMI_DEC_RUN_DESC", c->dec_run_desc); knob("QOIMI_DEC_FLAT_SEG", c->dec_flat_seg);
-        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split); knob("QOIMI_DEC_S3_RIDE", c->dec_s3_ride); knob("QOIMI_DEC_TR_SCAN", c->dec_tr_scan); knob("QOIMI_DEC_CONV", c->dec_conv); knob("QOIMI_DEC_SMALL_SEG", c->dec_small_seg); knob("QOIMI_DEC_CLASS_SPLIT", c->dec_class_split);
+        knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split); knob("QOIMI_DEC_S3_RIDE", c->dec_s3_ride); knob("QOIMI_DEC_TR_SCAN", c->dec_tr_scan); knob("QOIMI_DEC_CONV", c->dec_conv); knob("QOIMI_DEC_SMALL_SEG", c->dec_small_seg); knob("QOIMI_DEC_CLASS_SPLIT", c->dec_class_split); knob("QOIMI_DEC_FUSED_ADAPT", c->dec_fused_adapt);
         if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
         if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
         if (const char* e = getenv("QOIMI_SEG_BYTES")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v; }
@@ -815,7 +817,7 @@ static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi
         // the call stays below ~48 K segments (1280 x 720: 111 -> 100 us at 64 bytes, 1080p 120 -> 114, 1440p 132 -> 128 at 96; a 4K
         // photograph keeps 128: 168 us at 112, profiles/r06_s22_single_small_seg.txt).  No piece parse below 128 bytes: a call whose
         // transcoder cannot synchronise every segment takes the full five-phase parse.
-        if (B == 128u && n_images <= 4 && c->dec_fused && c->dec_fine && c->dec_split && c->dec_small_seg) {
+        if (B == 128u && n_images <= 4 && c->dec_fused && c->dec_fine && c->dec_split && c->dec_small_seg && !c->dec_few_syncfail) {
             const uint64_t want = (bytes / 49152u + 15u) / 16u * 16u;
             B = want < 64u ? 64u : want < 128u ? (uint32_t)want : 128u;
         }
@@ -845,7 +847,12 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     // (segments below 128 bytes, any multiple of 16 from 64 on: two transcoder lanes per segment; no piece parse for those - a call whose
     // transcoder cannot synchronise every segment takes the full five-phase parse)
     const bool small_seg = B >= 64u && B < 128u && B % 16u == 0u && c->dec_split;
-    const bool fused_layout = c->dec_fused && n_images <= 4 && c->dec_fine &&
+    // (the context's previous call of a few images could not synchronise every segment - sprites with many alpha levels, noise - and paid for the
+    // attempt: a wait, the parse, everything again through the chains.  The next such call takes the chains at once - and run descriptors for
+    // long runs, a launch more on a path that no longer counts them; a call that synchronises everything switches back.  A lone 4K sprite
+    // frame: 587 -> 285 us, profiles/r06_s34_single_kinds.txt)
+    const bool skip_fused = n_images <= 4 && c->dec_few_syncfail && c->dec_fused_adapt;
+    const bool fused_layout = c->dec_fused && !skip_fused && n_images <= 4 && c->dec_fine &&
                               (small_seg || (B % 128u == 0u && B / 128u >= 1u && B / 128u <= 64u && ((B / 128u) & (B / 128u - 1u)) == 0u));
     for (int i = 0; i < n_images; ++i) {
         if (sizes[i] < kHeaderBytes + kTrailerBytes) return fail(QOIMI_E_ARG, "stream shorter than 22 bytes (qoi.h:500)");
@@ -895,7 +902,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.desc_cap = (p.tr_split ? 2u * rec_max_records(B / 2u) : rec_max_records(B)) / 2u + 2u;              // a run ends with the record behind it: every second record at most
     // descriptors for the long runs of the other images as well - not for calls of a few images without a flat one (one more launch
     // on a path that counts them)
-    p.desc_all = (c->dec_run_desc >= 2 && (n_images > 4 || flat_total != 0)) ? 1u : 0u;
+    p.desc_all = (c->dec_run_desc >= 2 && (n_images > 4 || flat_total != 0 || skip_fused)) ? 1u : 0u;
     p.sync_all = 0;
     p.p3_plain = (uint32_t)c->dec_p3_plain;
     p.refine_inner = (uint32_t)c->dec_inner;
@@ -1083,6 +1090,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     stats[2] = (long long)total;
     stats[3] = p.total_segs ? c->host_word[2] : 0;
     c->dec_seq_images += stats_seq;
+    if (n_images <= 4 && p.total_segs) c->dec_few_syncfail = c->host_word[2] != 0u;
     return QOIMI_OK;
 }
 

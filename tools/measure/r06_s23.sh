@@ -2,7 +2,7 @@
 # round 6, session 23: lone frames of the kinds that are not photographs: rounds, re-opened segments and per-kernel times
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/r06_s23
+OUT=gpurun_out/${SESSION:-r06_s23}
 mkdir -p "$OUT"
 export TMPDIR=/tmp PYTHONUNBUFFERED=1 HSA_ENABLE_COREDUMP=0 QOIMI_TUNING=1
 ulimit -c 0

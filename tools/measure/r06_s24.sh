@@ -18,7 +18,7 @@ rows.sort()
 # the last decode call that is not under profiling: find calls = sequences starting at dec_transcode<0 ...> up to dec_fill; print the one before the last two
 starts = [i for i, r in enumerate(rows) if "dec_transcode<0" in r[2]]
 print(len(rows), "launches,", len(starts), "decode calls")
-i0 = starts[-3]; i1 = starts[-2]
+i0 = starts[-5]; i1 = starts[-3]
 t0 = rows[i0][0]; prev = t0
 for s, e, n in rows[i0:i1]:
     if "enc_" in n or "synth" in n or "hash" in n: break
