@@ -457,12 +457,15 @@ __global__ __launch_bounds__(256) void dec_parse_fine(DecParams p) {
     __shared__ LdsLut s_lut;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (*p.sync_fails == 0u) return;                       // nothing to parse (dec_transcode synchronised every segment)
-    build_lut(s_lut, threadIdx.x, 256u);
     const uint32_t G = p.fine_per_seg, gs = p.fine_shift;
     const uint32_t F = blockIdx.x * 256u + threadIdx.x;
     const uint32_t q = F >> gs, sub = F & (G - 1u);
     bool have = q < p.total_segs;
     have = have && p.sync_fail[have ? q : 0u] != 0u;      // only the segments dec_transcode could not synchronise
+    // (a workgroup without one returns before it builds its table: a call with a handful of flagged segments was 11 000 workgroups that
+    // each built one - 65 of the mixed directory's 3700 us, profiles/r06_s33_mixed_timeline.txt)
+    if (!__syncthreads_or(have ? 1 : 0)) return;
+    build_lut(s_lut, threadIdx.x, 256u);
     if (!lanes_where(have)) return;
     const uint32_t img = find_image(p.images, p.n_images, have ? q : 0u);
     const DecImage im = p.images[img];
@@ -1593,6 +1596,10 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
     static_assert(!SCAN || (SPLIT && MODE == 0), "the scan rides on the two-lane form of the first transcoder pass");
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     if (MODE == 1 && !p.sync_all && *p.sync_fails == 0u) return;
+    if (MODE == 1 && !p.sync_all) {                        // (a workgroup without a flagged segment returns before it builds its table: see dec_parse_fine)
+        const uint32_t t = blockIdx.x * kTrThreads + threadIdx.x;
+        if (!__syncthreads_or((t < p.total_segs && p.sync_fail[t] != 0u) ? 1 : 0)) return;
+    }
     if (SCAN) {
         // the workgroup's place in the call by ticket (start order: what its look-back waits for has started); the answer travels while the table is built
         if (threadIdx.x == 0) s_gb = atomicAdd(p.scan_ticket, 1u);
