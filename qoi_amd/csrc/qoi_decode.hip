@@ -401,6 +401,10 @@ __device__ __forceinline__ SlotRec slot_unpack(uint32_t w) {
     return t;
 }
 
+#ifndef QOIMI_SYNC_RETRY
+#define QOIMI_SYNC_RETRY 192
+#endif
+constexpr uint32_t kSyncRetryBytes = QOIMI_SYNC_RETRY;      // dec_transcode<0>: the second run-up of lanes whose chains did not meet in the first (0: none)
 constexpr uint32_t kFineBytes = 128;
 constexpr uint32_t kFinePieces = 10;                    // 16-byte loads per lane: 15 (alignment) + 128 + 8 <= 160
 constexpr uint32_t kFineDwords = kFinePieces * 4;
@@ -1707,7 +1711,30 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
             R.template turn<1>(m); sync_steps();
             R.template turn<2>(m); sync_steps();
         }
-        failed = have && (!merged || !reach);
+        bool reach2 = true;
+        if (kSyncRetryBytes != 0u && lanes_where(have && reach && !merged) != 0ull) {
+            // Chains that have not met within the run-up (a Kodak-like 4K photograph: 7 of 67 000 segments at 32 bytes) get ONE more, longer one
+            // before the segment is handed to the five-phase parse - which costs a call of a few images its single-pass path (a wait, the parse,
+            // everything again through the chains) and any call a second walk over the segment under plain loads.  Only wavefronts that hold such
+            // a lane pay: the reader starts anew, kSyncRetryBytes back for those lanes, where it stands for the others.
+            const bool again = have && reach && !merged;
+            const bool from_start2 = base <= (uint32_t)kHeaderBytes + kSyncRetryBytes;
+            const uint32_t t1 = again ? (from_start2 ? (uint32_t)kHeaderBytes : base - kSyncRetryBytes) : m;
+            reach2 = R.init_desc(lds_addr_of(&s_ring[wave][lane]), reinterpret_cast<const uint8_t*>(wave_base), (unsigned long long)(last_end - wave_base),
+                                 my_stream, t1, have, reinterpret_cast<const uint8_t*>(my_end));
+            if (again) {
+                parse_init(s, t1);
+                if (from_start2) { s.p1 = s.p2 = s.p3 = s.p4 = t1; }
+                m = t1; merged = from_start2;
+            }
+            going = again && reach2 && m < base;
+            while (lanes_where(going)) {
+                R.template turn<0>(m); sync_steps();
+                R.template turn<1>(m); sync_steps();
+                R.template turn<2>(m); sync_steps();
+            }
+        }
+        failed = have && (!merged || !reach || !reach2);
         if (SPLIT) {                                          // either half: the whole segment takes the five-phase parse
             const int other = __shfl_xor((int)failed, 1);     // (every lane asks: a lane that skipped the exchange would hand its neighbour nothing)
             failed = failed || other != 0;
@@ -2538,6 +2565,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     uint4* const my_desc = FLAT ? p.run_desc + (size_t)(im.desc_base + j) * p.desc_cap : reinterpret_cast<uint4*>(p.summary + (size_t)(have ? q : 0u) * 65u);
     uint32_t n_desc = 0u, span_start = px_first, span_len = 0u;     // FLAT: the pixels since the value last changed: [span_start, span_start + span_len), all of them px
     uint32_t span_px = 0u;                                          // the other images: the span of long runs in the making holds this pixel
+    uint32_t n_long = 0u;                                           // QOI_OP_RUNs of kLongRun pixels or more this lane met (calls of a few images: what the next call's desc_all goes by)
     RecSource S; S.init(p, blockIdx.x, lane, have && px_first < limit ? p.rec_gran[q] : 0u);
     const uint32_t nblk = wave_max_u32((S.n_gran + 1u) >> 1);
 #ifndef QOIMI_P4_DEPTH
@@ -2680,6 +2708,7 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
                     rem -= n2;
                     if (rem) {
                         if (rem >= kLongRun) {
+                            ++n_long;
                             if (p.desc_all) {
                                 // sprites, screenshots with photographs in them: the whole run (the two pixels above taken back) becomes a span for
                                 // dec_expand_runs, and the QOI_OP_RUNs that follow it directly lengthen the span - three additions per chunk of 62
@@ -2716,6 +2745,10 @@ __global__ __launch_bounds__(64) void dec_segments_rec(DecParams p) {
     if (lanes_where(clip_lane)) run(std::true_type{}); else run(std::false_type{});
     if (FLAT) { if (span_len != 0u) close_span(px); W.fpos = W.ppos; }
     else if (span_len != 0u) { put_desc(n_desc, span_start, span_len, span_px); ++n_desc; }       // (a place was kept for it)
+    if (!FLAT && p.tail_fused && lanes_where(n_long != 0u) != 0ull) {           // (header word 6: dec_fill hands it to the host)
+        const uint32_t tot = wave_sum(n_long);
+        if (lane == 0) atomicAdd(p.pending + 6, tot);
+    }
     if (FLAT || p.desc_all) {
         // segments with descriptors queue up for dec_expand_runs: one returning atomic per wavefront that has any
         const bool some = have && n_desc != 0u;
@@ -2906,12 +2939,13 @@ __global__ __launch_bounds__(256) void dec_fill(DecParams p) {
                 __hip_atomic_store(&p.host_result[2], sf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&p.host_result[0], pend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&p.host_result[3], need_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&p.host_result[5], __hip_atomic_load(p.pending + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // long runs met (dec_segments_rec)
                 __hip_atomic_store(&p.host_result[4], p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // "the words above are this call's"
             }
             // The call is complete (no image to restart, every segment synchronised): the counter header as the context's NEXT call wants to
             // find it - that call then needs no copy in front of its first kernel.  Nothing of this launch looks at these words any more.
             if (pend == 0u && sf == 0u) p.pending[threadIdx.x] = 0u;
-            else if (threadIdx.x == 3u) p.pending[3] = 0u;                     // run_queue_n (dec_expand_runs ran before this launch)
+            else if (threadIdx.x == 3u || threadIdx.x == 6u) p.pending[threadIdx.x] = 0u;     // run_queue_n (dec_expand_runs ran before this launch), the count of long runs
         }
     } else if (slice == 0u && threadIdx.x < 64u && p.total_segs != 0u) prepare_restart(p, img, threadIdx.x);
     if (blockIdx.x == 0u && threadIdx.x == 64u && !p.tail_fused) *p.run_queue_n = 0u;        // the round's run descriptors are written out (dec_expand_runs ran before this launch)

@@ -122,6 +122,7 @@ struct qoimi_ctx {
                                         // and always inside the drop-in qoi_encode, which encodes again by itself): by workgroup index, 4 us less per 4K frame
     int dec_tr_scan = 0;                // env QOIMI_DEC_TR_SCAN=1 (experiment, measured SLOWER: 46.6 us against 24.5 + 20.3 on a lone 4K frame, profiles/r06_s15): dec_scan_entry's
                                         // work as the epilogue of the two-lane transcoder instead of a launch of its own
+    bool dec_few_longruns = false;      // the context's last call of up to four images on the single-pass path met 1024 long QOI_OP_RUNs or more: the next one takes run descriptors
     bool dec_few_syncfail = false;      // the context's last call of up to four images held segments its transcoder could not synchronise: see decode_some
     int dec_fused_adapt = 1;            // env QOIMI_DEC_FUSED_ADAPT=0: such calls try the single-pass path every time
     bool dec_nonflat_repair = false;    // the context's last call of more than four images (flat ones aside) needed a repair round: see choose_seg_bytes
@@ -902,7 +903,9 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.desc_cap = (p.tr_split ? 2u * rec_max_records(B / 2u) : rec_max_records(B)) / 2u + 2u;              // a run ends with the record behind it: every second record at most
     // descriptors for the long runs of the other images as well - not for calls of a few images without a flat one (one more launch
     // on a path that counts them)
-    p.desc_all = (c->dec_run_desc >= 2 && (n_images > 4 || flat_total != 0 || skip_fused)) ? 1u : 0u;
+    // (... nor for a call of a few images unless the context's previous one met long runs by the thousand - a sprite's transparent bands: its P4 is
+    // then as long as the lane that writes a band 16 bytes at a time, 257 us for a 4K frame against 112 with descriptors)
+    p.desc_all = (c->dec_run_desc >= 2 && (n_images > 4 || flat_total != 0 || skip_fused || c->dec_few_longruns)) ? 1u : 0u;
     p.sync_all = 0;
     p.p3_plain = (uint32_t)c->dec_p3_plain;
     p.refine_inner = (uint32_t)c->dec_inner;
@@ -1035,6 +1038,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
             if (!seen || hw[23] != 0u) HIP_TRY(hipStreamSynchronize(st));
             else { c->dec_tail_open = true; c->dec_tail_stream = stream; }
             c->host_word[0] = c->host_word[20]; c->host_word[1] = c->host_word[21]; c->host_word[2] = c->host_word[22];
+            c->dec_few_longruns = c->host_word[25] >= 1024u;
             // (that dec_fill left the header zeroed; good for the next call if nothing else of this call touches it: no further round)
             c->dec_hdr_zero.at = (void*)p.pending; c->dec_hdr_zero.gen = c->dec_ws.gen; c->dec_hdr_zero.valid = c->host_word[0] == 0u && c->host_word[2] == 0u;
         } else {

@@ -636,6 +636,40 @@ def test_mixed_call_class_by_class(api, oracle, env):
     c.close()
 
 
+def test_small_calls_adapt_to_the_previous_call(api, oracle):
+    """What a call of a few images learns from the one before it on the same context: a frame with long runs by the thousand (a sprite's
+    transparent bands) makes the next call leave run descriptors for dec_expand_runs, a call whose transcoder could not synchronise every
+    segment (a stream of equally long multi-byte chunks built against it) makes the next one take the chains at once; both switch back.
+    Sprite, photograph, the hostile stream, sprite, sprite, photograph ... on one context, 3- and 4-channel output, against the reference
+    decoder every time."""
+    import torch
+    from qoi_amd import synth
+    c = api.Context(0)
+    items = []
+    for kind, w, h, seed in [("sprite_alpha", 1600, 900, 11), ("photo", 640, 360, 12), ("noise", 256, 200, 13)]:
+        items.append((oracle.encode(synth.frame_rgba(kind, w, h, seed), w, h, 4), w, h))
+    # QOI_OP_RGBA chunks whose alpha byte reads as another QOI_OP_RGBA tag: five chains that never meet, whatever the run-up
+    w, h = 300, 200
+    hostile = bytearray(b"qoif" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([4, 0]))
+    for i in range(w * h):
+        hostile += bytes([0xFF, (i * 7) & 0xFF, 0xFF, (i * 13) & 0xFF, 0xFF])
+    hostile += bytes([0, 0, 0, 0, 0, 0, 0, 1])
+    items.append((bytes(hostile), w, h))
+    order = [0, 1, 3, 0, 0, 1, 2, 3, 1, 0]
+    stream = torch.cuda.current_stream().cuda_stream
+    for rep, k in enumerate(order):
+        st, w, h = items[k]
+        for och in (4, 3):
+            d_s = torch.frombuffer(bytearray(st) + bytearray(64), dtype=torch.uint8).cuda()
+            d_p = torch.full((w * h * och + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+            c.decode_batch(d_s.data_ptr(), d_s.numel(), [len(st)], [api.QoiDesc(w, h, 4, 0)], och, d_p.data_ptr(), w * h * och + 64, stream)
+            want, _ = oracle.decode(st, och)
+            got = d_p.cpu().numpy()
+            assert np.array_equal(got[:w * h * och], want), (rep, k, och)
+            assert (got[w * h * och:] == 0xA5).all(), ("wrote behind the image", rep, k, och)
+    c.close()
+
+
 def test_small_calls_on_alternating_streams(api, oracle):
     """A call of a few images returns on the result words its last launch writes to pinned memory; that launch (it zeroes the counter
     header for the context's next call) may still be retiring.  One context, calls in turn on two streams and on the default stream, no
