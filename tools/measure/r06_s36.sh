@@ -2,7 +2,7 @@
 # round 6, session 36: campaigns on the final decode paths (class-by-class calls, passes that stop at a fixed point, small segments, the adaptive small-call path)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/r06_s36
+OUT=gpurun_out/${SESSION:-r06_s36}
 mkdir -p "$OUT"
 export TMPDIR=/tmp PYTHONUNBUFFERED=1 HSA_ENABLE_COREDUMP=0
 ulimit -c 0
