@@ -1663,10 +1663,13 @@ __global__ __launch_bounds__(kTrThreads) void dec_transcode(DecParams p) {
         R.init(lds_addr_of(&s_ring[wave][lane]), p.streams + im.stream_off, pos, im.chunks_end + kTrailerBytes, dummy16);
     } else {
         // ---- look-back synchronisation ------------------------------------------------------------------------------
-        // (segments of up to 256 bytes - calls of a few images - start their chains 32 bytes back: the chains of natural content meet within a
+        // (segments of up to 256 bytes - calls of a few images - start their chains 16 bytes back (32 until the second run-up existed): the chains of natural content meet within a
         // dozen bytes, those of noise never do, and at 128-byte segments the 64-byte run-up was a third of the lane's walk; a lane whose
         // chains have not met takes the five-phase parse as ever)
-        const uint32_t back = p.seg_bytes <= 256u ? kSyncBytes / 2u : kSyncBytes;
+#ifndef QOIMI_SYNC_SHORT
+#define QOIMI_SYNC_SHORT 16u             // (round 6, with the second run-up behind it: 16 / 24 / 32 bytes = 26.3 / 26.9 / 28.0 us for a 4K photograph's transcoder, profiles/r06_s43_short_len.txt)
+#endif
+        const uint32_t back = p.seg_bytes <= 256u ? QOIMI_SYNC_SHORT : kSyncBytes;
         const bool from_start = base <= (uint32_t)kHeaderBytes + back;            // the stream's first chunk is in reach: one chain from byte 14
         const uint32_t t0 = from_start ? (uint32_t)kHeaderBytes : base - back;
         // the wavefront's descriptor: from the stream of its first segment to the last granule of the stream of its last one

@@ -758,8 +758,8 @@ extern "C" int qoimi_encode_status(qoimi_ctx* c, void* stream) {
 // decode
 // ------------------------------------------------------------------------------------
 // segment size of a decode call (see the cost model below)
-static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi_desc* descs, int n_images) {
-    uint32_t B = c->seg_bytes;
+static uint32_t choose_seg_bytes(const qoimi_ctx* c, const int* sizes, const qoi_desc* descs, int n_images, bool honour_forced = true) {
+    uint32_t B = honour_forced ? c->seg_bytes : 0u;         // (QOIMI_SEG_BYTES)
     if (B == 0 && c->dec_run_desc && c->dec_flat_seg) {
         // A call of FLAT images only (run descriptors): a lane's walk over its segment no longer writes the segment's pixels, it costs
         // its chunks alone - larger segments mean fewer entry states (780 bytes per segment whatever its size), fewer chances to miss
@@ -1145,10 +1145,7 @@ extern "C" int qoimi_decode_batch(qoimi_ctx* c, const void* d_streams, size_t st
                 const bool flat = sizes[i] > 22 && descs[i].width != 0 && dec_image_is_flat((uint32_t)sizes[i] - 8u, (uint32_t)((uint64_t)descs[i].width * descs[i].height));
                 if ((flat ? 1 : 0) == cls) { place.push_back(i); sz_v.push_back(sizes[i]); ds_v.push_back(descs[i]); }
             }
-            const uint32_t forced = c->seg_bytes;
-            if (cls == 1) c->seg_bytes = 0;                          // (QOIMI_SEG_BYTES: the other images' size; the flat class keeps its rule)
-            const uint32_t B = choose_seg_bytes(c, sz_v.data(), ds_v.data(), (int)place.size());
-            c->seg_bytes = forced;
+            const uint32_t B = choose_seg_bytes(c, sz_v.data(), ds_v.data(), (int)place.size(), cls == 0);      // (QOIMI_SEG_BYTES: the other images' size; the flat class keeps its rule)
             const long long before = acc[0];
             acc[0] = 0;
             const int rc = sub_batches(sz_v.data(), ds_v.data(), place.data(), (int)place.size(), B);
