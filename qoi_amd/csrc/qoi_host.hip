@@ -131,6 +131,7 @@ struct qoimi_ctx {
     int dec_conv = 1;                   // env QOIMI_DEC_CONV=0: refinement passes run to their count (1: they stop at a fixed point, DecParams::conv)
     int dec_s3_ride = 0;                // env QOIMI_DEC_S3_RIDE=1 (experiment, measured: 21.6 -> 20.7 us for the two levels on a lone 4K frame, profiles/r06_s14): the per-image
                                         // level of the state chain rides on the group level's launch (last arrivers) instead of dec_chain_state_l2p's own launch
+    int dec_split_max = 512;            // env QOIMI_DEC_SPLIT_MAX: the largest segment of a call of a few images that takes two transcoder lanes (128 / 256 / 512 / 1024: a 5120 x 2880 photograph 211 / 200 / 199 / 198 us, a 4K noise frame 208 / 208 / 197 / 199, 8192^2 510 / 519 / 544 / 546 - it takes 1 KiB - profiles/r06_s44_split_max.txt)
     int dec_split = 1;                  // env QOIMI_DEC_SPLIT=0: one transcoder lane per segment in those calls too
     int dec_fused = 1;                  // env QOIMI_DEC_FUSED=0: calls of a few images take the three-level chains of the batch path instead of the single-pass look-back kernels
     uint32_t test_spin_bound = 0;       // env QOIMI_TEST_SPIN_BOUND (tests): polls before a placement wait gives up
@@ -249,6 +250,7 @@ extern "C" int qoimi_ctx_create(int device, qoimi_ctx** out) {
         if (const char* e = getenv("QOIMI_DEC_INNER1")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->dec_inner1 = v; }
         knob("QOIMI_DEC_L2M", c->dec_l2_wgs); knob("QOIMI_DEC_RUN_DESC", c->dec_run_desc); knob("QOIMI_DEC_FLAT_SEG", c->dec_flat_seg);
         knob("QOIMI_DEC_FUSED", c->dec_fused); knob("QOIMI_DEC_SPLIT", c->dec_split); knob("QOIMI_DEC_S3_RIDE", c->dec_s3_ride); knob("QOIMI_DEC_TR_SCAN", c->dec_tr_scan); knob("QOIMI_DEC_CONV", c->dec_conv); knob("QOIMI_DEC_SMALL_SEG", c->dec_small_seg); knob("QOIMI_DEC_CLASS_SPLIT", c->dec_class_split); knob("QOIMI_DEC_FUSED_ADAPT", c->dec_fused_adapt);
+        if (const char* e = getenv("QOIMI_DEC_SPLIT_MAX")) { const int v = atoi(e); if (v >= 64 && v <= 4096) c->dec_split_max = v; }
         if (const char* e = getenv("QOIMI_DEC_MAX_ROUNDS")) { int v = atoi(e); if (v >= 1) c->dec_max_rounds = v; }
         if (const char* e = getenv("QOIMI_DEC_REC_CAP_MB")) { long v = atol(e); if (v >= 1) c->dec_rec_cap = (size_t)v << 20; }
         if (const char* e = getenv("QOIMI_SEG_BYTES")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->seg_bytes = (uint32_t)v; }
@@ -895,7 +897,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     p.streams = (const uint8_t*)d_streams; p.n_images = (uint32_t)n_images;
     p.total_segs = (uint32_t)total; p.total_grps = (uint32_t)total_g; p.seg_bytes = B;
     p.rec_rows = rec_rows_of(B);
-    if (fused && B <= 128u && c->dec_split) {          // two transcoder lanes per segment (dec_transcode<0, .., SPLIT>): rows for two halves
+    if (fused && B <= (uint32_t)c->dec_split_max && c->dec_split) {          // two transcoder lanes per segment (dec_transcode<0, .., SPLIT>): rows for two halves
         p.tr_split = 1u; p.tr_rows_half = rec_rows_of(B / 2u); p.rec_rows = 2u * p.tr_rows_half;
         p.tr_scan = c->dec_tr_scan ? 1u : 0u;
     }

@@ -533,7 +533,7 @@ def test_selectable_paths(api, oracle, env):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("seg", ["", "64", "80", "112", "128", "1024"])
+@pytest.mark.parametrize("seg", ["", "64", "80", "112", "128", "256", "512", "1024"])
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_small_calls_single_pass_lookback(api, oracle, seg, fused):
     """Calls of one to four images take dec_scan_entry (pixel offsets + speculated slots by a single-pass look-back over tagged words,
