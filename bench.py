@@ -649,19 +649,20 @@ def main() -> None:
         t_warm = time.perf_counter()
         while time.perf_counter() - t_warm < 0.3:
             enc1(); dec1()
-        dt = timed(lambda: (enc1(), dec1()), 50)
-        dt_e = timed(enc1, 50)
-        dt_d = timed(dec1, 50)
+        med3 = lambda fn: sorted(timed(fn, 50) for _ in range(3))[1]      # (median of three blocks of 50 calls: one block now and then catches a hiccup of 25 %)
+        dt = med3(lambda: (enc1(), dec1()))
+        dt_e = med3(enc1)
+        dt_d = med3(dec1)
         # the same encode with its units handed out by workgroup index (qoimi_set_encode_small_call_order: what the drop-in qoi_encode
         # takes; a caller of the device API must then ask qoimi_encode_status before reading the streams)
         ctx.set_encode_small_call_order(True)
         for _ in range(20):
             enc1()
-        dt_e_idx = timed(enc1, 50)
+        dt_e_idx = med3(enc1)
         ctx.encode_status(stream)
         ctx.set_encode_small_call_order(False)
         enc1(); ctx.encode_status(stream)
-        single = {"workload": f"1 x {w}x{h} RGBA frame, encode + decode, device-resident, wall clock incl. launches (Infinity-Cache resident on repeat runs)",
+        single = {"workload": f"1 x {w}x{h} RGBA frame, encode + decode, device-resident, wall clock incl. launches (Infinity-Cache resident on repeat runs); every figure the median of three blocks of 50 calls",
                   "ms": round(dt * 1e3, 4), "mpixels_per_s": round(npx / dt / 1e6, 1),
                   "encode_ms": round(dt_e * 1e3, 4), "decode_ms": round(dt_d * 1e3, 4),
                   "encode_ms_units_by_workgroup_index": round(dt_e_idx * 1e3, 4),
