@@ -1651,9 +1651,12 @@ static void launch_encode_t(EncParams p, hipStream_t st, KernelTimer* tm, int ph
     // there IS work - flat content - a grid-stride loop over few long-lived workgroups is the slow way to run enc_sets (a persistent
     // grid costs it 20 %, profiles/r04_s1_enc_knobs.txt): large calls get 1/32 of the full grid (256 flat 4K frames: 8.5 -> 7.3 ms;
     // 1/8: 7.0 ms, but its empty launches cost the photographs 0.7 %; 1/32: 0.2 %).
-    const uint32_t gen_div = p.gen_small_div ? p.gen_small_div : 32u;            // (QOIMI_ENC_GEN_GRID_DIV, under QOIMI_TUNING: qoimi_ctx_create)
+    // (round 6: 1/8 for calls of up to 128 K units, whose empty launch of up to 16 K workgroups is ~10 us: the mixed directory's qoimi_encode_images - a third of
+    // its images flat - 1.39 -> 1.26 ms; 128 UI frames behind a batch of photographs stay at 3.1 ms against 2.8 primed: that is the first pass a primed call skips)
+    const uint32_t most = p.n_units > slab_blocks ? p.n_units : slab_blocks;
+    const uint32_t gen_div = p.gen_small_div ? p.gen_small_div : (most <= 131072u ? 8u : 32u);            // (QOIMI_ENC_GEN_GRID_DIV, under QOIMI_TUNING: qoimi_ctx_create)
     uint32_t small = 2048u;
-    { const uint32_t big = (p.n_units > slab_blocks ? p.n_units : slab_blocks) / gen_div; if (big > small) small = big; }
+    { const uint32_t big = most / gen_div; if (big > small) small = big; }
     tm->mark(kT_begin, st);
     if (phases & kEncSlabs) {
     if (warm) {
