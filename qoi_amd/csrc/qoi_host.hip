@@ -853,7 +853,7 @@ static int decode_some(qoimi_ctx* c, const void* d_streams, size_t stream_stride
     // (the context's previous call of a few images could not synchronise every segment - sprites with many alpha levels, noise - and paid for the
     // attempt: a wait, the parse, everything again through the chains.  The next such call takes the chains at once - and run descriptors for
     // long runs, a launch more on a path that no longer counts them; a call that synchronises everything switches back.  A lone 4K sprite
-    // frame: 587 -> 285 us, profiles/r06_s34_single_kinds.txt)
+    // frame: 587 -> 404 us, profiles/r06_s34_single_kinds.txt; since the second sync run-up of dec_transcode<0> only streams built against the synchronisation get here)
     const bool skip_fused = n_images <= 4 && c->dec_few_syncfail && c->dec_fused_adapt;
     const bool fused_layout = c->dec_fused && !skip_fused && n_images <= 4 && c->dec_fine &&
                               (small_seg || (B % 128u == 0u && B / 128u >= 1u && B / 128u <= 64u && ((B / 128u) & (B / 128u - 1u)) == 0u));
